@@ -1,0 +1,172 @@
+/*
+ * plsx.h -- C ABI of the MI355X PLS-C resampling engine (libplsx.so).
+ *
+ * Drop-in boundary for the resampling seam of netneurolab/pypyls: the calls
+ *     BasePLS.permutation / BasePLS.bootstrap / BasePLS.split_half
+ * dispatch `_single_perm` / `_single_boot` once per resample through
+ * `utils.get_par_func` (pyls/base.py:490-507, 644-650; pyls/utils.py:252-279).
+ * This library replaces that per-resample dispatch by batched device work.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ or torch types.
+ *   - every `d_*` pointer is a DEVICE pointer owned by the caller (the Python
+ *     host obtains them from torch tensors' data_ptr()); fp64, row-major
+ *     C-order unless stated; index arrays int32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     Work is enqueued asynchronously; call plsx_sync() (or synchronise the
+ *     stream yourself) before reading outputs.
+ *   - every entry returns 0 on success or a negative plsx_status; the message
+ *     is available from plsx_last_error().  No C++ exception crosses the ABI,
+ *     the library never frees caller buffers.
+ *   - one context per GPU, not shared between host threads.
+ */
+#ifndef PLSX_H_
+#define PLSX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plsx_ctx plsx_ctx;
+
+enum plsx_status {
+    PLSX_OK = 0,
+    PLSX_ERR_ARG = -1,       /* bad shape / flag / null pointer            */
+    PLSX_ERR_UNSUPPORTED = -2, /* shape outside what the device path covers */
+    PLSX_ERR_HIP = -3,       /* HIP runtime failure (incl. out of memory)   */
+    PLSX_ERR_STATE = -4      /* call order violated (e.g. no data set)      */
+};
+
+enum plsx_method {
+    PLSX_BEHAVIORAL = 0,     /* pyls/types/behavioral.py  (R = stacked per-cell xcorr)   */
+    PLSX_MEANCENTERED = 1    /* pyls/types/meancentered.py (R = cell means - ref. mean)  */
+};
+
+/* flags for plsx_set_data */
+#define PLSX_FLAG_COVARIANCE 1u   /* xcorr(..., covariance=True), pyls/compute.py:86-87 */
+
+/* Library / ABI version (major*1000 + minor). */
+int plsx_version(void);
+
+/* Largest stacked-Y dimension T' = J*T (behavioral) or J (mean-centred) the
+ * on-chip Jacobi solver handles. */
+int plsx_max_tprime(void);
+
+/* Create / destroy the per-GPU context (streams, scratch).               */
+int plsx_ctx_create(int device, plsx_ctx** out);
+int plsx_ctx_destroy(plsx_ctx* ctx);
+const char* plsx_last_error(const plsx_ctx* ctx);
+int plsx_sync(plsx_ctx* ctx);
+
+/*
+ * Bind the data set.  Replaces what BasePLS.__init__ stores in self.inputs /
+ * self.dummy (pyls/base.py:254-283).
+ *   d_X          (S, B) fp64
+ *   d_Y          (S, T) fp64, NULL for PLSX_MEANCENTERED
+ *   d_cell_of_row (S,) int32, cell index in [0, J): group-major then condition
+ *                (pyls/utils.py:178-197)
+ *   n_groups * n_cond == J
+ *   mean_centering in {0,1,2} (pyls/compute.py:267-317), ignored for behavioral
+ * The library keeps its own centred, padded copy; the caller may release d_X /
+ * d_Y afterwards.
+ */
+int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_Y,
+                  const int32_t* d_cell_of_row, int S, int B, int T,
+                  int n_groups, int n_cond, int mean_centering, unsigned flags,
+                  void* stream);
+
+/* Number of latent variables L = min(T', B) and T' for the bound data set. */
+int plsx_num_lv(const plsx_ctx* ctx);
+int plsx_tprime(const plsx_ctx* ctx);
+
+/*
+ * Cross-covariance matrices of resampled data -- gen_covcorr
+ * (pyls/types/behavioral.py:27-52, pyls/types/meancentered.py:50-73) applied
+ * to (X[xsrc], Y[ysrc]) for n resamples at once.
+ *   d_xsrc, d_ysrc  (n, S) int32: row of X / of Y placed at each position;
+ *                   NULL means the identity; an entry of -1 in d_xsrc drops the
+ *                   position (split-half masks, pyls/base.py:760-762).
+ *   d_R             (n, T', B) fp64 out
+ * Mainly a test / inspection hook: the batched entries below keep R on chip /
+ * in library scratch.
+ */
+int plsx_crosscov_batch(plsx_ctx* ctx, const int32_t* d_xsrc, const int32_t* d_ysrc,
+                        int n, double* d_R, void* stream);
+
+/*
+ * Decomposition of the un-resampled data -- BasePLS.svd (pyls/base.py:401-437
+ * -> pyls/compute.py:10-52) without the sign convention (the host applies
+ * sklearn's svd_flip rule and hands the result back via plsx_set_original).
+ *   d_xw (B, L), d_sv (L,), d_yw (T', L)  out
+ */
+int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void* stream);
+
+/* Fix the original decomposition used for Procrustes alignment
+ * (`original=` of _single_perm / _single_boot, pyls/base.py:505,648). */
+int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv,
+                      const double* d_yw, void* stream);
+
+/* Centred projection (X - colmean(X)) @ W for W given as (B, L): the device
+ * part of `x_scores = X @ x_weights` (pyls/base.py:364).  d_out (S, L). */
+int plsx_project(plsx_ctx* ctx, const double* d_W, int L, double* d_out, void* stream);
+/* Column means of X, (B,) out. */
+int plsx_colmean(plsx_ctx* ctx, double* d_mean, void* stream);
+
+/*
+ * Permutation null -- BasePLS.permutation / _single_perm with
+ * use_permind=True (pyls/base.py:601-712).
+ *   d_perm_idx (n, S) int32  one permutation per ROW (transpose of the
+ *              reference's (S, P) permsamples)
+ *   rotate     Procrustes-rotate onto the original y_weights (base.py:696-700)
+ *              or return the raw singular values (:702)
+ *   d_out_sv   (n, L) out
+ */
+int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate,
+                    double* d_out_sv, void* stream);
+
+/*
+ * Bootstrap -- BasePLS.bootstrap / _single_boot (pyls/base.py:439-576).
+ *   d_boot_idx (n, S) int32  one bootstrap sample per ROW
+ *   d_usum, d_usq (B, L)  accumulated IN PLACE: += sum_r U_r, += sum_r U_r**2
+ *                 with U_r the Procrustes-rotated, singular-value-scaled left
+ *                 singular vectors (base.py:510-511, 570)
+ *   d_distrib  (n, T', L) out: gen_distrib of every bootstrap (base.py:574)
+ */
+int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
+                    double* d_usum, double* d_usq, double* d_distrib, void* stream);
+
+/*
+ * Split-half reliability -- BasePLS.split_half (pyls/base.py:714-770) for ONE
+ * (possibly permuted) data arrangement and m split masks.
+ *   d_perm_idx (S,) int32 or NULL (un-permuted data)
+ *   d_masks    (m, S) uint8, 1 = row belongs to the first half
+ *   d_ud (B, L), d_vd (T', L): U @ inv(d), V @ inv(d) of that arrangement;
+ *              NULL for both = decompose on the device first (the case inside
+ *              _single_perm, base.py:705-708)
+ *   d_ucorr, d_vcorr (m, L) out: per-split correlations (caller averages)
+ */
+int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx,
+                          const uint8_t* d_masks, int m,
+                          const double* d_ud, const double* d_vd,
+                          double* d_ucorr, double* d_vcorr, void* stream);
+
+/* Bootstrap ratios -- compute.boot_rel (pyls/compute.py:212-237), elementwise
+ * on (B, L) arrays: se = sqrt(|usq - usum^2/n| / (n-1)), bsr = orig / se. */
+int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum,
+                  const double* d_usq, int n_boot, long long count,
+                  double* d_bsr, double* d_se, void* stream);
+
+/* Performance counters of the last perm/boot call: fills up to `cap` doubles:
+ * [0] kernel ms of the cross-product kernel (HIP events on the launch stream),
+ * [1] its launch count, [2] resamples per launch group, [3] M tiles per block,
+ * [4] super-batch size. Returns the number written. */
+int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
+/* Enable (1) / disable (0) event timing of the cross-product kernel. */
+int plsx_set_timing(plsx_ctx* ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSX_H_ */

@@ -1,0 +1,628 @@
+// plsx_api.hip -- host side of libplsx.so: context, planning, kernel launches.
+// C ABI declared in include/plsx.h.  gfx950 only.
+#include "plsx_kernels.h"
+#include "../../include/plsx.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct plsx_ctx {
+    int device = 0;
+    std::string err;
+    bool has_data = false, has_orig = false;
+    // problem
+    int method = 0, S = 0, B = 0, T = 0, J = 0, n_groups = 0, n_cond = 1, mc = 0, cov = 0;
+    int Tp = 0, Tpp = 0, L = 0, Kpad = 0, nks = 0, Bx = 0, Bpad = 0;
+    // plan
+    int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, Gcap = 0, Galloc = 0;
+    int nks_t = 0, LT = 0;
+    size_t group_stride = 0;
+    long long strideR = 0;
+    std::vector<int> h_cell_start, h_cell_len;
+    // device buffers
+    Buf Xc, xmean, Y, cell_of_row, cell_start, cell_len, out_row, mom_idx, mom_n;
+    Buf Afrag, R, Gm, Pm, part, Mfrag, U0T, V0, d0, tmpW;
+    // timing of the cross-product kernel
+    int timing = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double last_ms = 0.0;
+    int last_launches = 0;
+};
+
+namespace {
+
+int fail(plsx_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(ctx, PLSX_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCHCHK()                                                                       \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return fail(ctx, PLSX_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(plsx_ctx* ctx, Buf& b, size_t bytes, bool zero = false)
+{
+    if (b.bytes < bytes) {
+        if (b.p) HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+        HIPCHK(hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+        if (zero) HIPCHK(hipMemset(b.p, 0, bytes));
+    }
+    return 0;
+}
+
+void release(Buf& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+template <class T>
+T* ptr(const Buf& b) { return static_cast<T*>(b.p); }
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// Choose resamples per group so that data + moment tiles fill MT tiles.
+void plan_groups(plsx_ctx* c)
+{
+    c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;
+    const int Jw = c->scaled ? c->J : 0;
+    int best = 1;
+    for (int n = 1; n <= 512; ++n) {
+        int td = ceil_div(n * c->Tp, 16), tw = Jw ? ceil_div(n * Jw, 16) : 0;
+        if (td + 2 * tw <= c->MT && tw * 16 <= 48) best = n; else break;
+    }
+    c->npg = best;
+    c->w0 = ceil_div(best * c->Tp, 16);
+    const int tw = Jw ? ceil_div(best * Jw, 16) : 0;
+    c->sq0 = c->w0 + tw;
+    c->nmom_pad = tw * 16;
+    if (!c->scaled) { c->sq0 = c->MT; c->w0 = c->MT; }   // every tile is a data tile, B operand x
+    c->group_stride = (size_t)c->nks * c->MT * 64;
+    const int ncolblk = c->Bpad / 128;
+    int g = round_up(std::max(1, ceil_div(2048, ncolblk)), 8);
+    g = std::min(std::max(g, 8), 64);
+    const char* env = getenv("PLSX_SCRATCH_GB");
+    const double budget = (env ? atof(env) : 16.0) * 1073741824.0;
+    while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);
+    c->Gcap = g;
+}
+
+int upload_rowmaps(plsx_ctx* ctx)
+{
+    const int rows = ctx->MT * 16;
+    std::vector<int> out_row(rows, -1), mom_idx(rows, -1);
+    const int data_tiles = ctx->scaled ? ctx->w0 : ceil_div(ctx->npg * ctx->Tp, 16);
+    (void)data_tiles;
+    for (int rr = 0; rr < ctx->npg; ++rr)
+        for (int t = 0; t < ctx->Tp; ++t) {
+            int row = rr * ctx->Tp + t;
+            out_row[row] = rr * ctx->Tpp + t;
+            if (ctx->scaled) mom_idx[row] = rr * ctx->J + t / ctx->T;
+        }
+    if (ensure(ctx, ctx->out_row, rows * sizeof(int))) return PLSX_ERR_HIP;
+    if (ensure(ctx, ctx->mom_idx, rows * sizeof(int))) return PLSX_ERR_HIP;
+    HIPCHK(hipMemcpy(ctx->out_row.p, out_row.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->mom_idx.p, mom_idx.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// scratch for `groups` groups of resamples
+int ensure_scratch(plsx_ctx* ctx, int groups)
+{
+    groups = std::min(std::max(groups, 1), ctx->Gcap);
+    if (groups <= ctx->Galloc) return 0;
+    const size_t nb = (size_t)groups * ctx->npg;
+    if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * ctx->group_stride * 8)) return e;
+    // R: rows t >= Tp of every resample stay zero forever (memset on alloc)
+    if (int e = ensure(ctx, ctx->R, nb * ctx->Tpp * (size_t)ctx->Bpad * 8, true)) return e;
+    if (int e = ensure(ctx, ctx->mom_n, (size_t)groups * std::max(ctx->nmom_pad, 16) * 8, true)) return e;
+    if (int e = ensure(ctx, ctx->Gm, nb * ctx->Tp * ctx->Tp * 8)) return e;
+    if (int e = ensure(ctx, ctx->Pm, nb * ctx->Tp * ctx->L * 8)) return e;
+    if (int e = ensure(ctx, ctx->Mfrag, nb * ctx->nks_t * ctx->LT * 64 * 8)) return e;
+    ctx->Galloc = groups;
+    return 0;
+}
+
+template <int MT>
+int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
+{
+    const size_t stage = (size_t)2 * XP_KT * MT * 64 * 8;
+    const size_t epi = (size_t)8 * 2 * ctx->nmom_pad * 16 * 8;
+    const size_t lds = std::max(stage, epi);
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const int ncolblk = ctx->Bpad / 128;
+    dim3 grid(ncolblk * groups), block(512);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(k_xprod<MT>, grid, block, lds, st,
+                       ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
+                       ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
+                       ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
+                       std::max(ctx->nmom_pad, 0), groups, ctx->w0, ctx->sq0);
+    LAUNCHCHK();
+    if (ctx->timing) {
+        HIPCHK(hipEventRecord(e1, st));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return 0;
+}
+
+// Build the A operands of `nres` resamples and run the cross-product kernel:
+// afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
+// [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
+int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st)
+{
+    const int groups = ceil_div(nres, ctx->npg);
+    if (int e = ensure_scratch(ctx, groups)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
+    GroupLayout lay;
+    lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT;
+    lay.w0 = ctx->w0; lay.sq0 = ctx->sq0; lay.Tpp = ctx->Tpp;
+    if (ctx->method == PLSX_BEHAVIORAL) {
+        dim3 grid(nres, ctx->J), block(256);
+        const size_t lds = (size_t)2 * ctx->T * 8;
+        hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ptr<double>(ctx->Y), ctx->T, ctx->S,
+                           ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay,
+                           ctx->cov, ctx->scaled, ptr<double>(ctx->Afrag), ctx->group_stride,
+                           ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16));
+    } else {
+        dim3 grid(nres), block(256);
+        hipLaunchKernelGGL(k_build_A_mc, grid, block, 0, st, ctx->S, ctx->J, ctx->n_cond, ctx->mc,
+                           ptr<int>(ctx->cell_of_row), xsrc, lay, ptr<double>(ctx->Afrag),
+                           ctx->group_stride);
+    }
+    LAUNCHCHK();
+    if (ctx->MT == 24) return launch_xprod_t<24>(ctx, groups, st);
+    if (ctx->MT == 16) return launch_xprod_t<16>(ctx, groups, st);
+    return launch_xprod_t<8>(ctx, groups, st);
+}
+
+// C1 = A.B1^T (and C2 = A.B2^T), batched, contraction over K columns.
+int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
+           const double* B1, long long strideB1, int ldb1, int N1,
+           const double* B2, long long strideB2, int ldb2, int N2, int K, int batch,
+           double* C1, long long strideC1, int ldc1, double* C2, long long strideC2, int ldc2,
+           hipStream_t st)
+{
+    NtArgs a;
+    a.A = A; a.strideA = strideA; a.lda = lda; a.Ma = Ma;
+    a.B1 = B1; a.strideB1 = strideB1; a.ldb1 = ldb1; a.N1 = N1;
+    a.B2 = B2; a.strideB2 = strideB2; a.ldb2 = ldb2; a.N2 = N2;
+    a.K = K; a.batch = batch;
+    a.mtiles = ceil_div(Ma, 64);
+    a.ntiles = ceil_div(std::max(N1, B2 ? N2 : 0), 64);
+    const int tiles = a.mtiles * a.ntiles;
+    int nchunk = std::max(1, ceil_div(2048, batch * tiles));
+    nchunk = std::min(nchunk, std::max(1, K / 256));
+    a.kchunk = round_up(ceil_div(K, nchunk), NT_KB);
+    nchunk = ceil_div(K, a.kchunk);
+    const size_t bytes = (size_t)nchunk * batch * 2 * tiles * 4096 * 8;
+    if (int e = ensure(ctx, ctx->part, bytes)) return e;
+    a.part = ptr<double>(ctx->part);
+    dim3 grid(nchunk, tiles, batch), block(256);
+    hipLaunchKernelGGL(k_nt_gemm, grid, block, 0, st, a);
+    LAUNCHCHK();
+    {
+        dim3 g(ceil_div(Ma * N1, 256), batch);
+        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,
+                           a.ntiles, 0, C1, strideC1, ldc1, Ma, N1);
+        LAUNCHCHK();
+    }
+    if (B2) {
+        dim3 g(ceil_div(Ma * N2, 256), batch);
+        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,
+                           a.ntiles, 1, C2, strideC2, ldc2, Ma, N2);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
+{
+    const int n = a.n, ld = n | 1;
+    const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_small, dim3(nres), dim3(256), lds, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
+int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
+{
+    dim3 grid(ceil_div(ceil_div(ctx->B, 16), 4)), block(256);
+#define URARGS ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), \
+               nres, ctx->B, ctx->L, usum, usq, out
+    switch (ctx->LT) {
+        case 1: hipLaunchKernelGGL(k_urot<1>, grid, block, 0, st, URARGS); break;
+        case 2: hipLaunchKernelGGL(k_urot<2>, grid, block, 0, st, URARGS); break;
+        case 3: hipLaunchKernelGGL(k_urot<3>, grid, block, 0, st, URARGS); break;
+        case 4: hipLaunchKernelGGL(k_urot<4>, grid, block, 0, st, URARGS); break;
+        case 5: hipLaunchKernelGGL(k_urot<5>, grid, block, 0, st, URARGS); break;
+        default: hipLaunchKernelGGL(k_urot<6>, grid, block, 0, st, URARGS); break;
+    }
+#undef URARGS
+    LAUNCHCHK();
+    return 0;
+}
+
+SmallArgs small_args(plsx_ctx* ctx, int mode)
+{
+    SmallArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = mode; a.n = ctx->Tp; a.L = ctx->L; a.rotate = 1;
+    a.G = ptr<double>(ctx->Gm); a.P = ptr<double>(ctx->Pm);
+    a.V0 = ptr<double>(ctx->V0); a.d0 = ptr<double>(ctx->d0);
+    a.Mfrag = ptr<double>(ctx->Mfrag); a.nks_t = ctx->nks_t; a.LT = ctx->LT;
+    return a;
+}
+
+#define NEED_DATA()                                                             \
+    if (!ctx) return PLSX_ERR_ARG;                                              \
+    if (!ctx->has_data) return fail(ctx, PLSX_ERR_STATE, "plsx_set_data has not been called")
+#define NEED_ORIG()                                                             \
+    NEED_DATA();                                                                \
+    if (!ctx->has_orig) return fail(ctx, PLSX_ERR_STATE, "plsx_set_original has not been called")
+
+}  // namespace
+
+extern "C" {
+
+int plsx_version(void) { return 1000; }
+int plsx_max_tprime(void) { return PLSX_MAX_TP; }
+
+int plsx_ctx_create(int device, plsx_ctx** out)
+{
+    if (!out) return PLSX_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return PLSX_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return PLSX_ERR_HIP;
+    plsx_ctx* c = new (std::nothrow) plsx_ctx();
+    if (!c) return PLSX_ERR_HIP;
+    c->device = device;
+    *out = c;
+    return PLSX_OK;
+}
+
+int plsx_ctx_destroy(plsx_ctx* ctx)
+{
+    if (!ctx) return PLSX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (Buf* b : {&ctx->Xc, &ctx->xmean, &ctx->Y, &ctx->cell_of_row, &ctx->cell_start, &ctx->cell_len,
+                   &ctx->out_row, &ctx->mom_idx, &ctx->mom_n, &ctx->Afrag, &ctx->R, &ctx->Gm, &ctx->Pm,
+                   &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW})
+        release(*b);
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete ctx;
+    return PLSX_OK;
+}
+
+const char* plsx_last_error(const plsx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int plsx_sync(plsx_ctx* ctx)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    return PLSX_OK;
+}
+
+int plsx_num_lv(const plsx_ctx* ctx) { return (ctx && ctx->has_data) ? ctx->L : PLSX_ERR_STATE; }
+int plsx_tprime(const plsx_ctx* ctx) { return (ctx && ctx->has_data) ? ctx->Tp : PLSX_ERR_STATE; }
+
+int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_Y,
+                  const int32_t* d_cell_of_row, int S, int B, int T, int n_groups, int n_cond,
+                  int mean_centering, unsigned flags, void* stream)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!d_X || !d_cell_of_row || S < 2 || B < 1 || n_groups < 1 || n_cond < 1)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: bad shape or null pointer");
+    if (method != PLSX_BEHAVIORAL && method != PLSX_MEANCENTERED)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: unknown method");
+    if (method == PLSX_BEHAVIORAL && (!d_Y || T < 1))
+        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: behavioral PLS needs Y");
+    if (mean_centering < 0 || mean_centering > 2)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: mean_centering must be 0, 1 or 2");
+    const int J = n_groups * n_cond;
+    const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : J;
+    if (Tp > PLSX_MAX_TP) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the on-chip solver limit %d", Tp,
+                 PLSX_MAX_TP);
+        return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
+    }
+    ctx->has_data = ctx->has_orig = false;
+    ctx->Galloc = 0;
+    ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_BEHAVIORAL) ? T : 0;
+    ctx->J = J; ctx->n_groups = n_groups; ctx->n_cond = n_cond; ctx->mc = mean_centering;
+    ctx->cov = (flags & PLSX_FLAG_COVARIANCE) ? 1 : 0;
+    ctx->Tp = Tp; ctx->Tpp = round_up(Tp, 4); ctx->L = std::min(Tp, B);
+    ctx->Kpad = round_up(S, 4 * XP_KT); ctx->nks = ctx->Kpad / 4;
+    ctx->Bx = B + ctx->L; ctx->Bpad = round_up(ctx->Bx, 128);
+    ctx->nks_t = ctx->Tpp / 4; ctx->LT = ceil_div(ctx->L, 16);
+    ctx->strideR = (long long)ctx->Tpp * ctx->Bpad;
+    ctx->MT = 24;
+
+    // cell layout (host copy): cells must be contiguous row ranges (pyls/utils.py:178-197)
+    std::vector<int> cells(S);
+    HIPCHK(hipMemcpy(cells.data(), d_cell_of_row, S * sizeof(int), hipMemcpyDeviceToHost));
+    ctx->h_cell_start.assign(J, 0);
+    ctx->h_cell_len.assign(J, 0);
+    for (int i = 0; i < S; ++i) {
+        int c = cells[i];
+        if (c < 0 || c >= J || (i > 0 && c < cells[i - 1]))
+            return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: cell_of_row must be non-decreasing in [0, J)");
+        if (ctx->h_cell_len[c] == 0) ctx->h_cell_start[c] = i;
+        ctx->h_cell_len[c]++;
+    }
+    for (int c = 0; c < J; ++c)
+        if (ctx->h_cell_len[c] < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: empty cell");
+
+    if (int e = ensure(ctx, ctx->cell_of_row, S * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->cell_start, J * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->cell_len, J * sizeof(int))) return e;
+    HIPCHK(hipMemcpy(ctx->cell_of_row.p, cells.data(), S * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->cell_start.p, ctx->h_cell_start.data(), J * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->cell_len.p, ctx->h_cell_len.data(), J * sizeof(int), hipMemcpyHostToDevice));
+
+    const size_t xbytes = (size_t)ctx->Kpad * ctx->Bpad * 8;
+    if (int e = ensure(ctx, ctx->Xc, xbytes)) return e;
+    if (int e = ensure(ctx, ctx->xmean, (size_t)ctx->Bpad * 8)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Xc.p, 0, xbytes, st));
+    HIPCHK(hipMemsetAsync(ctx->xmean.p, 0, (size_t)ctx->Bpad * 8, st));
+    hipLaunchKernelGGL(k_colmean, dim3(ceil_div(B, 256)), dim3(256), 0, st, d_X, S, B, ptr<double>(ctx->xmean));
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_center_pad, dim3(ceil_div(B, 256), S), dim3(256), 0, st, d_X,
+                       ptr<double>(ctx->xmean), S, B, ptr<double>(ctx->Xc), ctx->Bpad);
+    LAUNCHCHK();
+    if (method == PLSX_BEHAVIORAL) {
+        if (int e = ensure(ctx, ctx->Y, (size_t)S * T * 8)) return e;
+        HIPCHK(hipMemcpyAsync(ctx->Y.p, d_Y, (size_t)S * T * 8, hipMemcpyDeviceToDevice, st));
+    }
+    plan_groups(ctx);
+    if (int e = upload_rowmaps(ctx)) return e;
+    if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
+    if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
+    if (int e = ensure(ctx, ctx->d0, (size_t)ctx->L * 8)) return e;
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->has_data = true;
+    return PLSX_OK;
+}
+
+int plsx_colmean(plsx_ctx* ctx, double* d_mean, void* stream)
+{
+    NEED_DATA();
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_mean, ctx->xmean.p, (size_t)ctx->B * 8, hipMemcpyDeviceToDevice,
+                          static_cast<hipStream_t>(stream)));
+    return PLSX_OK;
+}
+
+int plsx_crosscov_batch(plsx_ctx* ctx, const int32_t* d_xsrc, const int32_t* d_ysrc, int n,
+                        double* d_R, void* stream)
+{
+    NEED_DATA();
+    if (n < 1 || !d_R) return fail(ctx, PLSX_ERR_ARG, "plsx_crosscov_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = ctx->Gcap * ctx->npg;
+    for (int off = 0; off < n; off += nb) {
+        const int m = std::min(nb, n - off);
+        const int* xs = d_xsrc ? d_xsrc + (size_t)off * ctx->S : nullptr;
+        const int* ys = d_ysrc ? d_ysrc + (size_t)off * ctx->S : nullptr;
+        if (int e = run_xprod(ctx, xs, ys, m, st)) return e;
+        dim3 g(ceil_div(ctx->Tp * ctx->B, 256), m);
+        hipLaunchKernelGGL(k_gather_cols, g, dim3(256), 0, st, ptr<double>(ctx->R), ctx->strideR,
+                           ctx->Bpad, 0, ctx->Tp, ctx->B, d_R + (size_t)off * ctx->Tp * ctx->B);
+        LAUNCHCHK();
+    }
+    return PLSX_OK;
+}
+
+int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void* stream)
+{
+    NEED_DATA();
+    if (!d_xw || !d_sv || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_decompose: null output");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int e = run_xprod(ctx, nullptr, nullptr, 1, st)) return e;
+    const double* R = ptr<double>(ctx->R);
+    if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                       nullptr, 0, 0, 0, ctx->B, 1, ptr<double>(ctx->Gm), 0, ctx->Tp, nullptr, 0, 0, st))
+        return e;
+    SmallArgs a = small_args(ctx, SMALL_DECOMP);
+    a.out_V = d_yw; a.out_d = d_sv;
+    if (int e = run_small(ctx, a, 1, st)) return e;
+    return run_urot(ctx, 1, nullptr, nullptr, d_xw, st);
+}
+
+int plsx_project(plsx_ctx* ctx, const double* d_W, int L, double* d_out, void* stream)
+{
+    NEED_DATA();
+    if (!d_W || !d_out || L < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_project: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int e = ensure(ctx, ctx->tmpW, (size_t)L * ctx->Bpad * 8)) return e;
+    HIPCHK(hipMemsetAsync(ctx->tmpW.p, 0, (size_t)L * ctx->Bpad * 8, st));
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(L, 32), ceil_div(ctx->B, 32)), dim3(32, 8), 0, st,
+                       d_W, ctx->B, L, L, ptr<double>(ctx->tmpW), ctx->Bpad);
+    LAUNCHCHK();
+    return run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, ctx->S, ptr<double>(ctx->tmpW), 0, ctx->Bpad, L,
+                  nullptr, 0, 0, 0, ctx->B, 1, d_out, 0, L, nullptr, 0, 0, st);
+}
+
+int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv, const double* d_yw,
+                      void* stream)
+{
+    NEED_DATA();
+    if (!d_xw || !d_sv || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_set_original: null input");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->V0.p, d_yw, (size_t)ctx->Tp * ctx->L * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d0.p, d_sv, (size_t)ctx->L * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ctx->L, 32), ceil_div(ctx->B, 32)), dim3(32, 8), 0, st,
+                       d_xw, ctx->B, ctx->L, ctx->L, ptr<double>(ctx->U0T), ctx->Bpad);
+    LAUNCHCHK();
+    // centred scores (X - mean) @ normalize(U0) into the extra columns [B, B+L)
+    // of the feature matrix: the cross-product kernel then yields gen_distrib
+    // (behavioral.py:78-80, meancentered.py:97-102) as L extra columns of R.
+    // U0 columns are unit norm (or zero for null LVs), so normalize() is the identity.
+    if (int e = run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, ctx->S, ptr<double>(ctx->U0T), 0, ctx->Bpad,
+                       ctx->L, nullptr, 0, 0, 0, ctx->B, 1, ptr<double>(ctx->Xc) + ctx->B, 0, ctx->Bpad,
+                       nullptr, 0, 0, st))
+        return e;
+    ctx->has_orig = true;
+    return PLSX_OK;
+}
+
+int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate, double* d_out_sv,
+                    void* stream)
+{
+    NEED_ORIG();
+    if (!d_perm_idx || !d_out_sv || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = ctx->Gcap * ctx->npg;
+    for (int off = 0; off < n; off += nb) {
+        const int m = std::min(nb, n - off);
+        const int* idx = d_perm_idx + (size_t)off * ctx->S;
+        // behavioral permutes Y (base.py:599), mean-centred permutes X (meancentered.py:125)
+        const int* xs = (ctx->method == PLSX_BEHAVIORAL) ? nullptr : idx;
+        const int* ys = (ctx->method == PLSX_BEHAVIORAL) ? idx : nullptr;
+        if (int e = run_xprod(ctx, xs, ys, m, st)) return e;
+        const double* R = ptr<double>(ctx->R);
+        if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                           nullptr, 0, 0, 0, ctx->B, m, ptr<double>(ctx->Gm), (long long)ctx->Tp * ctx->Tp,
+                           ctx->Tp, nullptr, 0, 0, st))
+            return e;
+        SmallArgs a = small_args(ctx, SMALL_PERM);
+        a.rotate = rotate ? 1 : 0;
+        a.out_sv = d_out_sv + (size_t)off * ctx->L;
+        if (int e = run_small(ctx, a, m, st)) return e;
+    }
+    return PLSX_OK;
+}
+
+int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
+                    double* d_distrib, void* stream)
+{
+    NEED_ORIG();
+    if (!d_boot_idx || !d_usum || !d_usq || !d_distrib || n < 1)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_boot_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = ctx->Gcap * ctx->npg;
+    for (int off = 0; off < n; off += nb) {
+        const int m = std::min(nb, n - off);
+        const int* idx = d_boot_idx + (size_t)off * ctx->S;
+        if (int e = run_xprod(ctx, idx, idx, m, st)) return e;
+        const double* R = ptr<double>(ctx->R);
+        if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                           ptr<double>(ctx->U0T), 0, ctx->Bpad, ctx->L, ctx->B, m,
+                           ptr<double>(ctx->Gm), (long long)ctx->Tp * ctx->Tp, ctx->Tp,
+                           ptr<double>(ctx->Pm), (long long)ctx->Tp * ctx->L, ctx->L, st))
+            return e;
+        SmallArgs a = small_args(ctx, SMALL_BOOT);
+        if (int e = run_small(ctx, a, m, st)) return e;
+        if (int e = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e;
+        dim3 g(ceil_div(ctx->Tp * ctx->L, 256), m);
+        hipLaunchKernelGGL(k_gather_cols, g, dim3(256), 0, st, R, ctx->strideR, ctx->Bpad, ctx->B, ctx->Tp,
+                           ctx->L, d_distrib + (size_t)off * ctx->Tp * ctx->L);
+        LAUNCHCHK();
+    }
+    return PLSX_OK;
+}
+
+int plsx_split_half_batch(plsx_ctx* ctx, const int32_t*, const uint8_t*, int, const double*,
+                          const double*, double*, double*, void*)
+{
+    return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_split_half_batch: not implemented in this build");
+}
+
+int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, const double* d_usq,
+                  int n_boot, long long count, double* d_bsr, double* d_se, void* stream)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_orig || !d_usum || !d_usq || !d_bsr || !d_se || count < 1 || n_boot < 2)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_boot_rel: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_boot_rel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_orig, d_usum, d_usq, (double)n_boot, count,
+                       d_bsr, d_se);
+    LAUNCHCHK();
+    return PLSX_OK;
+}
+
+int plsx_set_timing(plsx_ctx* ctx, int enable)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    ctx->timing = enable ? 1 : 0;
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    ctx->events.clear();
+    return PLSX_OK;
+}
+
+int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
+{
+    plsx_ctx* ctx = const_cast<plsx_ctx*>(cctx);
+    if (!ctx || !out || cap < 1) return PLSX_ERR_ARG;
+    double ms = 0.0;
+    for (auto& ev : ctx->events) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess)
+            ms += t;
+    }
+    double vals[5] = {ms, (double)ctx->events.size(), (double)ctx->npg, (double)ctx->MT,
+                      (double)ctx->Gcap * ctx->npg};
+    int n = std::min(cap, 5);
+    for (int i = 0; i < n; ++i) out[i] = vals[i];
+    return n;
+}
+
+}  // extern "C"

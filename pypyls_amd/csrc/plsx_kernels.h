@@ -1,0 +1,780 @@
+// plsx_kernels.h -- gfx950 (CDNA4) device kernels of the PLS-C resampling engine.
+//
+// All arithmetic is IEEE fp64.  The three GEMM-shaped kernels use the fp64
+// matrix instruction v_mfma_f64_16x16x4_f64 (one 16x16 tile, K=4 per issue):
+//   A operand: lane l holds A[m = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][n = l & 15]
+//   C/D:       lane l, reg i holds D[m = (l >> 4) + 4*i][n = l & 15]
+// (MI355X guide: cdna_hip_programming.md section 3, "f64 MFMA does NOT use
+// these maps").  Every kernel keeps the long feature axis B on the lane-fast
+// index so HBM accesses are row-contiguous.
+//
+//   k_xprod      R = scale o (A . X)          (n*T' x S) . (S x B)     "K_R"
+//   k_nt_gemm    C = P . Q^T, contraction over B (Gram / projections)  "K_G"
+//   k_urot       U = R^T . M, fused sum / sum-of-squares accumulation  "K_U"
+//   k_small      T'xT' Jacobi eigen-solve + Procrustes polar factor    "K4-K6"
+//
+// Reference semantics implemented (pyls/...): compute.xcorr :55-94,
+// behavioral.gen_covcorr :27-52, compute.get_mean_center :267-357,
+// compute.svd :10-52, compute.procrustes :240-264, base._single_perm :654-712,
+// base._single_boot :530-576.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define PLSX_MAX_TP 96          // largest T' handled by the on-chip solver
+#define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
+{
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// data preparation
+// ---------------------------------------------------------------------------
+
+// Column means of X (S x B, ld = B) -> mean[B]; one thread per column, rows
+// summed in order (deterministic).
+__global__ void k_colmean(const double* __restrict__ X, int S, int B, double* __restrict__ mean)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int i = 0; i < S; ++i) s += X[(size_t)i * B + b];
+    mean[b] = s / (double)S;
+}
+
+// Xc[i][b] = X[i][b] - mean[b]  into the padded buffer (Kpad x ldx); padding
+// rows / columns are zeroed by a memset beforehand.
+__global__ void k_center_pad(const double* __restrict__ X, const double* __restrict__ mean,
+                             int S, int B, double* __restrict__ Xc, int ldx)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.y;
+    if (b >= B || i >= S) return;
+    Xc[(size_t)i * ldx + b] = X[(size_t)i * B + b] - mean[b];
+}
+
+// Offset (in doubles) of element (row, k) inside one group's fragment-ordered
+// A operand: [kstep][mtile][lane], lane = (k & 3) * 16 + (row & 15).
+__device__ __forceinline__ size_t afrag_off(int row, int k, int MT)
+{
+    return ((size_t)(k >> 2) * MT + (row >> 4)) * 64 + ((k & 3) << 4) + (row & 15);
+}
+
+struct GroupLayout {
+    int n;        // resamples per group
+    int Tp;       // data rows per resample (T' = J*T or J)
+    int J;        // cells
+    int T;        // Y features (behavioral) or 0
+    int MT;       // M tiles per block (template value)
+    int w0;       // first weight tile (first-moment rows), == sq0 when unscaled
+    int sq0;      // first second-moment tile, == total tiles when unscaled
+    int Tpp;      // T' rounded up to 4 (row pitch of R per resample)
+};
+
+// Behavioral PLS: build the A operand of resample r, cell j.
+//   A[(rr*Tp + j*T + t)][xsrc[p]] += zscore(Y[ysrc[p]][t]) / (n_j - 1)
+//   weight / sq rows [rr*J + j][xsrc[p]] += 1
+// z-scoring is over the positions of cell j that the resample keeps
+// (pyls/compute.py:83-87 applied per cell, behavioral.py:49-52).
+// grid (n_resamples, J), block 256.  dynamic LDS: 2*Tn doubles.
+__global__ void k_build_A_behav(const double* __restrict__ Y, int T, int S,
+                                const int* __restrict__ cell_start, const int* __restrict__ cell_len,
+                                const int* __restrict__ xsrc, const int* __restrict__ ysrc,
+                                GroupLayout lay, int covariance, int scaled,
+                                double* __restrict__ Afrag, size_t group_stride,
+                                double* __restrict__ mom_n, int nmom_pad)
+{
+    extern __shared__ double sm_b[];
+    const int r = blockIdx.x, j = blockIdx.y;
+    const int g = r / lay.n, rr = r % lay.n;
+    const int start = cell_start[j], len = cell_len[j];
+    const int* xs = xsrc ? xsrc + (size_t)r * S : nullptr;
+    const int* ys = ysrc ? ysrc + (size_t)r * S : nullptr;
+    double* mean = sm_b;            // [T]
+    double* rstd = sm_b + T;        // [T]
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+
+    if (tid == 0) {
+        int c = 0;
+        for (int p = start; p < start + len; ++p) c += (xs ? xs[p] : p) >= 0;
+        s_cnt = c;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    // per-feature mean / std over the kept positions, rows visited in order
+    for (int t = tid; t < T; t += blockDim.x) {
+        double s = 0.0;
+        for (int p = start; p < start + len; ++p) {
+            int xi = xs ? xs[p] : p;
+            if (xi < 0) continue;
+            int yi = ys ? ys[p] : p;
+            s += Y[(size_t)yi * T + t];
+        }
+        double m = s / (double)cnt;
+        double q = 0.0;
+        for (int p = start; p < start + len; ++p) {
+            int xi = xs ? xs[p] : p;
+            if (xi < 0) continue;
+            int yi = ys ? ys[p] : p;
+            double d = Y[(size_t)yi * T + t] - m;
+            q += d * d;
+        }
+        mean[t] = m;
+        rstd[t] = covariance ? 1.0 : 1.0 / sqrt(q / (double)(cnt - 1));
+    }
+    __syncthreads();
+    double* A = Afrag + (size_t)g * group_stride;
+    const double inv_nm1 = 1.0 / (double)(cnt - 1);
+    const int total = len * T;
+    for (int idx = tid; idx < total; idx += blockDim.x) {
+        int pl = idx / T, t = idx - pl * T;
+        int p = start + pl;
+        int xi = xs ? xs[p] : p;
+        if (xi < 0) continue;
+        int yi = ys ? ys[p] : p;
+        double v = (Y[(size_t)yi * T + t] - mean[t]) * rstd[t] * inv_nm1;
+        int row = rr * lay.Tp + j * T + t;
+        atomicAdd(A + afrag_off(row, xi, lay.MT), v);
+    }
+    if (scaled) {
+        for (int pl = tid; pl < len; pl += blockDim.x) {
+            int p = start + pl;
+            int xi = xs ? xs[p] : p;
+            if (xi < 0) continue;
+            int mrow = rr * lay.J + j;
+            atomicAdd(A + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), 1.0);
+            atomicAdd(A + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), 1.0);
+        }
+        if (tid == 0) mom_n[(size_t)g * nmom_pad + rr * lay.J + j] = (double)cnt;
+    }
+}
+
+// Mean-centred PLS: A = (cell-averaging - reference-averaging) weights, so
+// that A . X = cell means minus the mean_centering reference mean
+// (pyls/compute.py:267-357 with means=True).  grid (n_resamples), block 256.
+__global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
+                             const int* __restrict__ cell_of_pos,
+                             const int* __restrict__ xsrc, GroupLayout lay,
+                             double* __restrict__ Afrag, size_t group_stride)
+{
+    __shared__ int cnt[PLSX_MAX_TP];
+    const int r = blockIdx.x;
+    const int g = r / lay.n, rr = r % lay.n;
+    const int* xs = xsrc ? xsrc + (size_t)r * S : nullptr;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < J; j += blockDim.x) cnt[j] = 0;
+    __syncthreads();
+    for (int p = tid; p < S; p += blockDim.x)
+        if ((xs ? xs[p] : p) >= 0) atomicAdd(&cnt[cell_of_pos[p]], 1);
+    __syncthreads();
+    const int n_groups = J / n_cond;
+    int ntot = 0;
+    for (int j = 0; j < J; ++j) ntot += cnt[j];
+    double* A = Afrag + (size_t)g * group_stride;
+    for (int p = tid; p < S; p += blockDim.x) {
+        int xi = xs ? xs[p] : p;
+        if (xi < 0) continue;
+        int j = cell_of_pos[p];
+        int gj = j / n_cond, cj = j % n_cond;
+        double own = 1.0 / (double)cnt[j];
+        int ngrp = 0;
+        for (int c = 0; c < n_cond; ++c) ngrp += cnt[gj * n_cond + c];
+        for (int j2 = 0; j2 < J; ++j2) {
+            double coef = (j2 == j) ? own : 0.0;
+            if (mean_centering == 0) {
+                if (j2 / n_cond == gj) coef -= 1.0 / (double)ngrp;
+            } else if (mean_centering == 1) {
+                if (j2 % n_cond == cj) coef -= own / (double)n_groups;
+            } else {
+                coef -= 1.0 / (double)ntot;
+            }
+            if (coef != 0.0) atomicAdd(A + afrag_off(rr * lay.Tp + j2, xi, lay.MT), coef);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K_R: resampled cross-product  R[r] = scale o (A_r . X)
+// ---------------------------------------------------------------------------
+//
+// One block = 128 feature columns x one group of n resamples (all of its
+// n*T' (+ moment) rows): 8 waves, wave w owns the 16-column tile w and every
+// M tile, so X is streamed from HBM exactly once per group straight into MFMA
+// B fragments (no LDS, no reuse to exploit) while the small A operand (shared
+// by all 8 waves and by every block of the group) is staged through LDS in
+// fragment order -> conflict-free ds_read_b64, one read per MFMA.
+// Block id -> (column block, group) with the group as the fast index: block b
+// runs on XCD b % 8, so with 8 groups every XCD's L2 keeps one group's A.
+//
+// Rows of a group: [0, w0*16) data rows (n*T' packed), then first-moment rows
+// (weights, B operand x), then second-moment rows (same weights, B operand
+// x*x).  The epilogue turns the two moments into 1/std of the resampled
+// feature inside the cell (ddof = 1, pyls/compute.py:84) and scales R.
+#define XP_KT 2                 // k-steps (of 4 rows) per LDS stage
+template <int MT>
+__global__ __launch_bounds__(512, 2)
+void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
+             const double* __restrict__ X, int ldx, int nks,
+             double* __restrict__ R, int ldr, int rows_per_group,
+             const int* __restrict__ out_row, const int* __restrict__ mom_idx,
+             const double* __restrict__ mom_n, int nmom_pad,
+             int n_groups, int w0, int sq0)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int STAGE = XP_KT * MT * 64;           // doubles per stage
+    constexpr int PASSES = STAGE / 1024;             // 512 threads x double2
+    static_assert(STAGE % 1024 == 0, "MT must be a multiple of 8");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x % n_groups;
+    const int colblk = blockIdx.x / n_groups;
+    const int col = colblk * 128 + wave * 16 + (lane & 15);
+    const int kq = lane >> 4;
+
+    const double* Ag = Afrag + (size_t)grp * group_stride;
+    const double* Xp = X + (size_t)kq * ldx + col;
+
+    d4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    const int nkt = nks / XP_KT;
+    // prologue: stage 0 of A, first X fragments
+    {
+        const d2* src = reinterpret_cast<const d2*>(Ag);
+        d2* dst = reinterpret_cast<d2*>(smem);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) dst[p * 512 + tid] = src[p * 512 + tid];
+    }
+    double xb[XP_KT];
+#pragma unroll
+    for (int s = 0; s < XP_KT; ++s) xb[s] = Xp[(size_t)(s * 4) * ldx];
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nkt);
+        d2 stg[PASSES];
+        double xn[XP_KT];
+        if (more) {
+            const d2* src = reinterpret_cast<const d2*>(Ag + (size_t)(kt + 1) * STAGE);
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) stg[p] = src[p * 512 + tid];
+#pragma unroll
+            for (int s = 0; s < XP_KT; ++s) xn[s] = Xp[(size_t)(((kt + 1) * XP_KT + s) * 4) * ldx];
+        }
+        const double* sA = smem + cur * STAGE + lane;
+#pragma unroll
+        for (int s = 0; s < XP_KT; ++s) {
+            const double b = xb[s];
+            const double bsq = b * b;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const double a = sA[(s * MT + m) * 64];
+                acc[m] = mfma_f64(a, (m < sq0) ? b : bsq, acc[m]);
+            }
+        }
+        if (more) {
+            d2* dst = reinterpret_cast<d2*>(smem + (cur ^ 1) * STAGE);
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) dst[p * 512 + tid] = stg[p];
+#pragma unroll
+            for (int s = 0; s < XP_KT; ++s) xb[s] = xn[s];
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: feature scale from the moment tiles -------------------
+    // lane (kq, c) reg i of a weight tile holds m1 of moment row
+    // (tile-w0)*16 + kq + 4*i, and the same lane/reg of the matching sq tile
+    // holds m2 of that row.
+    // (nmom_pad == (sq0 - w0) * 16; the A stages are dead, reuse their LDS)
+    double* sS = smem + wave * (2 * nmom_pad * 16);  // m1 -> scale: [nmom_pad][16] per wave
+    double* sQ = sS + nmom_pad * 16;                 // m2
+    const int ntw = sq0 - w0;
+    if (ntw > 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m >= w0 && m < sq0 + ntw) {
+                double* dst = (m < sq0) ? sS + (m - w0) * 256 : sQ + (m - sq0) * 256;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[(kq + 4 * i) * 16 + (lane & 15)] = acc[m][i];
+            }
+        }
+    }
+    __syncthreads();
+    if (ntw > 0) {
+        for (int mr = kq; mr < nmom_pad; mr += 4) {
+            const int o = mr * 16 + (lane & 15);
+            const double m1 = sS[o], m2 = sQ[o];
+            const double nn = mom_n[(size_t)grp * nmom_pad + mr];
+            const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);
+            sS[o] = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+        }
+    }
+    __syncthreads();
+    double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        if (m < w0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m * 16 + kq + 4 * i;
+                const int orow = out_row[row];
+                if (orow >= 0) {
+                    const int mi = mom_idx[row];
+                    const double sc = (mi >= 0) ? sS[mi * 16 + (lane & 15)] : 1.0;
+                    Rg[(size_t)orow * ldr] = acc[m][i] * sc;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K_G: C[b] = A_b . B_b^T  (and optionally C2[b] = A_b . B2^T), long
+// contraction axis split across blocks; partial 64x64 tiles are summed in a
+// fixed order by k_reduce_part (deterministic, no atomics).
+// ---------------------------------------------------------------------------
+#define NT_KB 32                 // contraction columns per LDS stage
+#define NT_LD 34                 // LDS row pitch (doubles): 34 = 2 mod 32 -> conflict-free b64 reads
+struct NtArgs {
+    const double* A;  long long strideA; int lda; int Ma;
+    const double* B1; long long strideB1; int ldb1; int N1;
+    const double* B2; long long strideB2; int ldb2; int N2;   // B2 == nullptr: single product
+    int K;            // contraction length (columns)
+    int kchunk;       // columns per block (multiple of NT_KB)
+    int mtiles, ntiles;  // 64-tiles of the output
+    double* part;     // [nchunk][batch][2][mtiles*ntiles][64*64]
+    int batch;
+};
+
+__global__ __launch_bounds__(256)
+void k_nt_gemm(NtArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double sA[64 * NT_LD];
+    __shared__ __attribute__((aligned(16))) double sB1[64 * NT_LD];
+    __shared__ __attribute__((aligned(16))) double sB2[64 * NT_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x;
+    const int tile = blockIdx.y;
+    const int b = blockIdx.z;
+    const int tm = tile / a.ntiles, tn = tile % a.ntiles;
+    const bool two = (a.B2 != nullptr);
+    const int k0 = chunk * a.kchunk;
+    const int k1 = min(a.K, k0 + a.kchunk);
+
+    const double* Ab = a.A + (size_t)b * a.strideA;
+    const double* B1b = a.B1 + (size_t)b * a.strideB1;
+    const double* B2b = two ? a.B2 + (size_t)b * a.strideB2 : nullptr;
+
+    const int seg = tid & 15;       // double2 slot inside a 32-column row piece
+    const int rbase = tid >> 4;     // 0..15
+    d4 acc1[4], acc2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc1[i] = (d4){0, 0, 0, 0}; acc2[i] = (d4){0, 0, 0, 0}; }
+
+    for (int kk = k0; kk < k1; kk += NT_KB) {
+        const int c = kk + seg * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = rbase + 16 * i;
+            d2 va = (d2){0, 0}, v1 = (d2){0, 0}, v2 = (d2){0, 0};
+            const int ra = tm * 64 + rl;
+            if (ra < a.Ma) {
+                const double* p = Ab + (size_t)ra * a.lda + c;
+                if (c + 1 < k1) va = *reinterpret_cast<const d2*>(p);
+                else if (c < k1) va = (d2){p[0], 0.0};
+            }
+            const int rb = tn * 64 + rl;
+            if (rb < a.N1) {
+                const double* p = B1b + (size_t)rb * a.ldb1 + c;
+                if (c + 1 < k1) v1 = *reinterpret_cast<const d2*>(p);
+                else if (c < k1) v1 = (d2){p[0], 0.0};
+            }
+            if (two && rb < a.N2) {
+                const double* p = B2b + (size_t)rb * a.ldb2 + c;
+                if (c + 1 < k1) v2 = *reinterpret_cast<const d2*>(p);
+                else if (c < k1) v2 = (d2){p[0], 0.0};
+            }
+            *reinterpret_cast<d2*>(&sA[rl * NT_LD + seg * 2]) = va;
+            *reinterpret_cast<d2*>(&sB1[rl * NT_LD + seg * 2]) = v1;
+            if (two) *reinterpret_cast<d2*>(&sB2[rl * NT_LD + seg * 2]) = v2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < NT_KB / 4; ++ks) {
+            const int off = (lane & 15) * NT_LD + ks * 4 + (lane >> 4);
+            const double fa = sA[wave * 16 * NT_LD + off];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc1[nt] = mfma_f64(fa, sB1[nt * 16 * NT_LD + off], acc1[nt]);
+                if (two) acc2[nt] = mfma_f64(fa, sB2[nt * 16 * NT_LD + off], acc2[nt]);
+            }
+        }
+        __syncthreads();
+    }
+    const size_t tiles = (size_t)a.mtiles * a.ntiles;
+    double* out = a.part + ((((size_t)chunk * a.batch + b) * 2) * tiles + tile) * 4096;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = wave * 16 + (lane >> 4) + 4 * i, n = nt * 16 + (lane & 15);
+            out[m * 64 + n] = acc1[nt][i];
+            if (two) out[tiles * 4096 + m * 64 + n] = acc2[nt][i];
+        }
+}
+
+// C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
+__global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
+                              int mtiles, int ntiles, int which,
+                              double* __restrict__ C, long long strideC, int ldc, int M, int N)
+{
+    const int b = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * N) return;
+    const int m = idx / N, n = idx % N;
+    const int tile = (m / 64) * ntiles + (n / 64);
+    const size_t tiles = (size_t)mtiles * ntiles;
+    const size_t off = ((size_t)which * tiles + tile) * 4096 + (m % 64) * 64 + (n % 64);
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c)
+        s += part[(((size_t)c * batch + b) * 2) * tiles * 4096 + off];
+    C[(size_t)b * strideC + (size_t)m * ldc + n] = s;
+}
+
+// ---------------------------------------------------------------------------
+// K4-K6: small dense solver, one block per resample.
+// ---------------------------------------------------------------------------
+//
+// One-sided (Hestenes) Jacobi with a round-robin parallel ordering: columns
+// of A (m x n, column-major, pitch ld) are orthogonalised by plane rotations
+// applied from the right; the same rotations are applied to V (mv x n).  Each
+// column pair is handled by an 8-lane group (dot products reduced with
+// wavefront shuffles); 32 pairs per pass of the 256-thread block.
+__device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+{
+    const int tid = threadIdx.x;
+    const int sub = tid & 7, grp = tid >> 3;
+    const int np = (n + 1) >> 1, ne = np * 2;
+    const double tol = 1e-15;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int step = 0; step < ne - 1; ++step) {
+            for (int pr = grp; pr < np; pr += 32) {
+                int p, q;
+                if (pr == 0) { p = step; q = ne - 1; }
+                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= n) continue;
+                double* ap = A + (size_t)p * ld;
+                double* aq = A + (size_t)q * ld;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = sub; i < m; i += 8) {
+                    double x = ap[i], y = aq[i];
+                    alpha += x * x; beta += y * y; gamma += x * y;
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    alpha += __shfl_xor(alpha, o);
+                    beta += __shfl_xor(beta, o);
+                    gamma += __shfl_xor(gamma, o);
+                }
+                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = sub; i < m; i += 8) {
+                    double x = ap[i], y = aq[i];
+                    ap[i] = c * x - s * y; aq[i] = s * x + c * y;
+                }
+                double* vp = V + (size_t)p * ld;
+                double* vq = V + (size_t)q * ld;
+                for (int i = sub; i < mv; i += 8) {
+                    double x = vp[i], y = vq[i];
+                    vp[i] = c * x - s * y; vq[i] = s * x + c * y;
+                }
+                if (sub == 0) *flag = 1;
+            }
+            __syncthreads();
+        }
+        const int any = *flag;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+enum { SMALL_DECOMP = 0, SMALL_PERM = 1, SMALL_BOOT = 2 };
+
+struct SmallArgs {
+    int mode;
+    int n;             // T'
+    int L;             // latent variables kept (min(T', B))
+    int rotate;        // PERM: Procrustes-rotate (1) or raw singular values (0)
+    const double* G;   // [nres][n][n]
+    const double* P;   // BOOT: [nres][n][L]   P = R_b . U0
+    const double* V0;  // PERM: original y_weights (n x L), row-major
+    const double* d0;  // BOOT: original singular values (L) for the live mask
+    double* out_sv;    // PERM: [nres][L]
+    double* out_V;     // DECOMP: (n x L) row-major
+    double* out_d;     // DECOMP: (L)
+    double* Mfrag;     // BOOT / DECOMP: [nres][nks_t][LT][64] fragment-ordered M (T' x L)
+    int nks_t, LT;
+};
+
+__global__ __launch_bounds__(256)
+void k_small(SmallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_s[];
+    const int n = a.n, L = a.L;
+    const int ld = n | 1;
+    double* bufA = sm_s;                     // n x ld
+    double* bufV = sm_s + (size_t)n * ld;    // n x ld
+    double* lam = bufV + (size_t)n * ld;     // [n] eigenvalues of G (unsorted)
+    double* sig = lam + n;                   // [n] singular values of temp
+    int* rank = reinterpret_cast<int*>(sig + n);   // [n] rank of physical column (0 = largest)
+    int* order = rank + n;                         // [n] physical column of rank k
+    __shared__ int s_flag;
+    __shared__ double s_dmax;
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x;
+    const double* G = a.G + (size_t)r * n * n;
+
+    for (int idx = tid; idx < n * n; idx += blockDim.x) {
+        int c = idx / n, i = idx % n;
+        bufA[c * ld + i] = G[(size_t)i * n + c];
+        bufV[c * ld + i] = (i == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
+    // eigenvalues = column norms of G.V (G is PSD)
+    for (int c = tid; c < n; c += blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) { double x = bufA[c * ld + i]; s += x * x; }
+        lam[c] = sqrt(s);
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += blockDim.x) {
+        int rk = 0;
+        const double lc = lam[c];
+        for (int o = 0; o < n; ++o) {
+            const double lo = lam[o];
+            rk += (lo > lc) || (lo == lc && o < c);
+        }
+        rank[c] = rk;
+        order[rk] = c;
+    }
+    __syncthreads();
+    if (tid == 0) s_dmax = sqrt(lam[order[0]]);
+    __syncthreads();
+    const double dmax = s_dmax;
+
+    if (a.mode == SMALL_DECOMP) {
+        for (int idx = tid; idx < n * L; idx += blockDim.x) {
+            int t = idx / L, k = idx % L;
+            a.out_V[(size_t)t * L + k] = bufV[order[k] * ld + t];
+        }
+        for (int k = tid; k < L; k += blockDim.x) a.out_d[k] = sqrt(lam[order[k]]);
+        // M = V diag(1/d) for live LVs (zero otherwise): U = R^T . M
+        const int tot = a.nks_t * a.LT * 64;
+        for (int idx = tid; idx < tot; idx += blockDim.x) {
+            int lane = idx & 63, lt = (idx >> 6) % a.LT, ks = (idx >> 6) / a.LT;
+            int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
+            double v = 0.0;
+            if (t < n && l < L) {
+                double d = sqrt(lam[order[l]]);
+                if (d > PLSX_RANK_RTOL * dmax) v = bufV[order[l] * ld + t] / d;
+            }
+            a.Mfrag[(size_t)r * tot + idx] = v;
+        }
+        return;
+    }
+
+    if (a.mode == SMALL_PERM && !a.rotate) {
+        for (int k = tid; k < L; k += blockDim.x)
+            a.out_sv[(size_t)r * L + k] = sqrt(lam[order[k]]);
+        return;
+    }
+
+    // temp (L x n, column c = physical eigenvector c) into bufA
+    if (a.mode == SMALL_PERM) {
+        // temp[a][c] = sum_t V0[t][a] V[t][c]   (pyls/compute.py:260)
+        for (int idx = tid; idx < L * n; idx += blockDim.x) {
+            int c = idx / L, aa = idx % L;
+            double s = 0.0;
+            if (rank[c] < L)
+                for (int t = 0; t < n; ++t) s += a.V0[(size_t)t * L + aa] * bufV[c * ld + t];
+            bufA[c * ld + aa] = s;
+        }
+        __syncthreads();
+        // accumulator := diag(d): rotations give Z = diag(d) . Pv
+        for (int idx = tid; idx < n * n; idx += blockDim.x) {
+            int c = idx / n, i = idx % n;
+            bufV[c * ld + i] = (i == c && rank[c] < L) ? sqrt(lam[c]) : 0.0;
+        }
+    } else {
+        // temp[a][c] = sum_t P[t][a] V[t][c] / d_c  = (U0^T U_b)[a][c], live LVs only
+        const double* P = a.P + (size_t)r * n * L;
+        const double d0max = a.d0[0];
+        for (int idx = tid; idx < L * n; idx += blockDim.x) {
+            int c = idx / L, aa = idx % L;
+            double s = 0.0;
+            const double dc = sqrt(lam[c]);
+            if (rank[c] < L && dc > PLSX_RANK_RTOL * dmax && a.d0[aa] > PLSX_RANK_RTOL * d0max) {
+                for (int t = 0; t < n; ++t) s += P[(size_t)t * L + aa] * bufV[c * ld + t];
+                s /= dc;
+            }
+            bufA[c * ld + aa] = s;
+        }
+    }
+    __syncthreads();
+    jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
+    for (int c = tid; c < n; c += blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < L; ++i) { double x = bufA[c * ld + i]; s += x * x; }
+        sig[c] = sqrt(s);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int c = 0; c < n; ++c) mx = fmax(mx, sig[c]);
+        s_dmax = mx;
+    }
+    __syncthreads();
+    const double smin = 1e-12 * s_dmax;
+
+    if (a.mode == SMALL_PERM) {
+        // (dQ)[k][l] = sum_c Z[k][c] W[l][c] / sig_c ; ssd_l = || (dQ)[:, l] ||
+        for (int l = tid; l < L; l += blockDim.x) {
+            double ss = 0.0;
+            for (int k = 0; k < n; ++k) {
+                double s = 0.0;
+                for (int c = 0; c < n; ++c)
+                    if (sig[c] > smin) s += bufV[c * ld + k] * bufA[c * ld + l] / sig[c];
+                ss += s * s;
+            }
+            a.out_sv[(size_t)r * L + l] = sqrt(ss);
+        }
+    } else {
+        // M[t][l] = sum_c (V Pv)[t][c] W[l][c] / sig_c   -> U_rot = R_b^T . M
+        const int tot = a.nks_t * a.LT * 64;
+        for (int idx = tid; idx < tot; idx += blockDim.x) {
+            int lane = idx & 63, lt = (idx >> 6) % a.LT, ks = (idx >> 6) / a.LT;
+            int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
+            double s = 0.0;
+            if (t < n && l < L)
+                for (int c = 0; c < n; ++c)
+                    if (sig[c] > smin) s += bufV[c * ld + t] * bufA[c * ld + l] / sig[c];
+            a.Mfrag[(size_t)r * tot + idx] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K_U: U_r = R_r^T . M_r for a batch of resamples; either accumulate
+// usum += sum_r U_r, usq += sum_r U_r^2 (pyls/base.py:510-511) with the
+// (16 x L) tile kept in registers across the whole batch, or write U.
+// One wave per 16 feature columns, 4 waves per block.
+// ---------------------------------------------------------------------------
+template <int LT>
+__global__ __launch_bounds__(256)
+void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
+            const double* __restrict__ Mfrag, int nres, int B, int L,
+            double* __restrict__ usum, double* __restrict__ usq, double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b0 = (blockIdx.x * 4 + wave) * 16;
+    if (b0 >= B) return;
+    d4 sum[LT], sq[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) { sum[l] = (d4){0, 0, 0, 0}; sq[l] = (d4){0, 0, 0, 0}; }
+    const size_t mstride = (size_t)nks_t * LT * 64;
+    for (int r = 0; r < nres; ++r) {
+        d4 acc[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
+        const double* Rp = R + (size_t)r * strideR + (size_t)(lane >> 4) * ldr + b0 + (lane & 15);
+        const double* Mp = Mfrag + (size_t)r * mstride + lane;
+        for (int ks = 0; ks < nks_t; ++ks) {
+            const double a = Rp[(size_t)ks * 4 * ldr];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a, Mp[(ks * LT + l) * 64], acc[l]);
+        }
+#pragma unroll
+        for (int l = 0; l < LT; ++l) {
+            sum[l] += acc[l];
+            sq[l] += acc[l] * acc[l];
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LT; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = b0 + (lane >> 4) + 4 * i, k = l * 16 + (lane & 15);
+            if (b < B && k < L) {
+                const size_t o = (size_t)b * L + k;
+                if (out) out[o] = sum[l][i];
+                else { usum[o] += sum[l][i]; usq[o] += sq[l][i]; }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+
+// dst (C x Rr) = src (Rr x C)^T ; tiled through LDS.
+__global__ void k_transpose(const double* __restrict__ src, int rows, int cols, int lds_,
+                            double* __restrict__ dst, int ldd)
+{
+    __shared__ double tile[32][33];
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int c = c0 + i, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
+    }
+}
+
+// out[r][t][l] = R[r][t][col0 + l]  (bootstrap distrib columns / crosscov copy-out)
+__global__ void k_gather_cols(const double* __restrict__ R, long long strideR, int ldr, int col0,
+                              int Tp, int ncol, double* __restrict__ out)
+{
+    const int r = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Tp * ncol) return;
+    const int t = idx / ncol, l = idx % ncol;
+    out[((size_t)r * Tp + t) * ncol + l] = R[(size_t)r * strideR + (size_t)t * ldr + col0 + l];
+}
+
+// compute.boot_rel (pyls/compute.py:212-237)
+__global__ void k_boot_rel(const double* __restrict__ orig, const double* __restrict__ usum,
+                           const double* __restrict__ usq, double n, long long count,
+                           double* __restrict__ bsr, double* __restrict__ se)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double s = usum[i];
+    const double e = sqrt(fabs(usq[i] - s * s / n) / (n - 1.0));
+    se[i] = e;
+    bsr[i] = orig[i] / e;
+}
+
+__global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * S) dst[i] = i % S;
+}

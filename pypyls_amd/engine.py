@@ -1,0 +1,259 @@
+"""
+ctypes binding of libplsx.so (C ABI: include/plsx.h) and a thin device-side
+engine object.  PyTorch-ROCm tensors are used only as device-memory handles
+(`data_ptr()`) and for host<->device copies; all arithmetic on the resampling
+path runs in the hand-written HIP kernels of csrc/.
+
+There is NO CPU fallback: without the built library or without a GPU every
+entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _build
+
+_LIB = None
+
+PLSX_BEHAVIORAL = 0
+PLSX_MEANCENTERED = 1
+PLSX_FLAG_COVARIANCE = 1
+
+
+class PlsxError(RuntimeError):
+    pass
+
+
+def _load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.lib_path()
+    if not os.path.exists(path):
+        raise PlsxError(
+            'libplsx.so is not built ({}). Run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (needs hipcc). There is no CPU fallback.'.format(path))
+    lib = ctypes.CDLL(path)
+    vp, i32, c_d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    sig = {
+        'plsx_version': ([], i32),
+        'plsx_max_tprime': ([], i32),
+        'plsx_ctx_create': ([i32, ctypes.POINTER(vp)], i32),
+        'plsx_ctx_destroy': ([vp], i32),
+        'plsx_last_error': ([vp], ctypes.c_char_p),
+        'plsx_sync': ([vp], i32),
+        'plsx_set_data': ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_uint, vp], i32),
+        'plsx_num_lv': ([vp], i32),
+        'plsx_tprime': ([vp], i32),
+        'plsx_crosscov_batch': ([vp, vp, vp, i32, vp, vp], i32),
+        'plsx_decompose': ([vp, vp, vp, vp, vp], i32),
+        'plsx_set_original': ([vp, vp, vp, vp, vp], i32),
+        'plsx_project': ([vp, vp, i32, vp, vp], i32),
+        'plsx_colmean': ([vp, vp, vp], i32),
+        'plsx_perm_batch': ([vp, vp, i32, i32, vp, vp], i32),
+        'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
+        'plsx_split_half_batch': ([vp, vp, vp, i32, vp, vp, vp, vp, vp], i32),
+        'plsx_boot_rel': ([vp, vp, vp, vp, i32, ctypes.c_longlong, vp, vp, vp], i32),
+        'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
+        'plsx_set_timing': ([vp, i32], i32),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)            # AttributeError if a symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _LIB = lib
+    return lib
+
+
+def exported_symbols():
+    """Names declared in include/plsx.h that the loaded library exports."""
+    lib = _load()
+    names = ['plsx_version', 'plsx_max_tprime', 'plsx_ctx_create', 'plsx_ctx_destroy',
+             'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
+             'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
+             'plsx_colmean', 'plsx_perm_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
+             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing']
+    return [n for n in names if hasattr(lib, n)]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Engine(object):
+    """One device context.  All ndarray arguments / results are host numpy
+    arrays unless a method says it returns a device tensor."""
+
+    def __init__(self, device=None):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise PlsxError('no AMD GPU visible to PyTorch-ROCm: the PLS resampling engine has '
+                            'no CPU fallback')
+        self.lib = _load()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device('cuda', self.device_index)
+        ctx = ctypes.c_void_p()
+        rc = self.lib.plsx_ctx_create(self.device_index, ctypes.byref(ctx))
+        if rc != 0:
+            raise PlsxError('plsx_ctx_create failed with status {}'.format(rc))
+        self.ctx = ctx
+        self.S = self.B = self.L = self.Tp = 0
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.plsx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.plsx_last_error(self.ctx)
+            raise PlsxError('libplsx status {}: {}'.format(rc, msg.decode() if msg else ''))
+
+    def _stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, arr, dtype):
+        torch = _torch()
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
+        return t.to(self.device, non_blocking=False)
+
+    def _empty(self, shape, dtype=None):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype or torch.float64, device=self.device)
+
+    def _zeros(self, shape):
+        torch = _torch()
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
+
+    def sync(self):
+        self._check(self.lib.plsx_sync(self.ctx))
+
+    # -- data -------------------------------------------------------------
+    def set_data(self, X, Y, cell_of_row, n_groups, n_cond, method, mean_centering=0,
+                 covariance=False):
+        """X (S, B), Y (S, T) or None: numpy arrays or device tensors."""
+        torch = _torch()
+        dX = X if isinstance(X, torch.Tensor) else self._dev(X, np.float64)
+        dY = None
+        if Y is not None:
+            dY = Y if isinstance(Y, torch.Tensor) else self._dev(Y, np.float64)
+        dC = self._dev(cell_of_row, np.int32)
+        S, B = dX.shape
+        T = 0 if dY is None else dY.shape[1]
+        flags = PLSX_FLAG_COVARIANCE if covariance else 0
+        self._check(self.lib.plsx_set_data(
+            self.ctx, int(method), dX.data_ptr(), None if dY is None else dY.data_ptr(),
+            dC.data_ptr(), S, B, T, int(n_groups), int(n_cond), int(mean_centering), flags,
+            self._stream()))
+        self.sync()
+        self.S, self.B, self.T = S, B, T
+        self.L = self.lib.plsx_num_lv(self.ctx)
+        self.Tp = self.lib.plsx_tprime(self.ctx)
+
+    def colmean(self):
+        out = self._empty((self.B,))
+        self._check(self.lib.plsx_colmean(self.ctx, out.data_ptr(), self._stream()))
+        self.sync()
+        return out.cpu().numpy()
+
+    def _index_rows(self, samples):
+        """(S, n) reference layout -> (n, S) int32 device tensor."""
+        samples = np.asarray(samples)
+        if samples.ndim != 2 or samples.shape[0] != self.S:
+            raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'
+                             .format(self.S, samples.shape))
+        return self._dev(samples.T, np.int32)
+
+    # -- kernels ----------------------------------------------------------
+    def crosscov(self, xsrc=None, ysrc=None, n=None):
+        """gen_covcorr of n resamples; xsrc / ysrc (S, n) or None (identity)."""
+        dx = None if xsrc is None else self._index_rows(xsrc)
+        dy = None if ysrc is None else self._index_rows(ysrc)
+        if n is None:
+            n = (dx if dx is not None else dy).shape[0] if (dx is not None or dy is not None) else 1
+        out = self._empty((n, self.Tp, self.B))
+        self._check(self.lib.plsx_crosscov_batch(
+            self.ctx, None if dx is None else dx.data_ptr(), None if dy is None else dy.data_ptr(),
+            int(n), out.data_ptr(), self._stream()))
+        self.sync()
+        return out.cpu().numpy()
+
+    def decompose(self):
+        """-> x_weights (B, L), singvals (L,), y_weights (T', L), raw signs."""
+        xw, sv, yw = self._empty((self.B, self.L)), self._empty((self.L,)), self._empty((self.Tp, self.L))
+        self._check(self.lib.plsx_decompose(self.ctx, xw.data_ptr(), sv.data_ptr(), yw.data_ptr(),
+                                            self._stream()))
+        self.sync()
+        return xw.cpu().numpy(), sv.cpu().numpy(), yw.cpu().numpy()
+
+    def set_original(self, x_weights, singvals, y_weights):
+        self._orig_xw = self._dev(x_weights, np.float64)
+        sv, yw = self._dev(singvals, np.float64), self._dev(y_weights, np.float64)
+        self._check(self.lib.plsx_set_original(self.ctx, self._orig_xw.data_ptr(), sv.data_ptr(),
+                                               yw.data_ptr(), self._stream()))
+        self.sync()
+
+    def project(self, W):
+        """(X - colmean) @ W for W (B, L) -> (S, L)."""
+        dW = self._dev(W, np.float64)
+        out = self._empty((self.S, dW.shape[1]))
+        self._check(self.lib.plsx_project(self.ctx, dW.data_ptr(), dW.shape[1], out.data_ptr(),
+                                          self._stream()))
+        self.sync()
+        return out.cpu().numpy()
+
+    def perm(self, permsamples, rotate=True):
+        """permsamples (S, P) -> permuted singular values (L, P)."""
+        idx = self._index_rows(permsamples)
+        n = idx.shape[0]
+        out = self._empty((n, self.L))
+        self._check(self.lib.plsx_perm_batch(self.ctx, idx.data_ptr(), n, 1 if rotate else 0,
+                                             out.data_ptr(), self._stream()))
+        self.sync()
+        return out.cpu().numpy().T.copy()
+
+    def boot(self, bootsamples, usum=None, usq=None):
+        """bootsamples (S, R) -> (usum, usq) device tensors (B, L), accumulated in
+        place when given, and distrib (T', L, R) numpy."""
+        idx = self._index_rows(bootsamples)
+        n = idx.shape[0]
+        if usum is None:
+            usum, usq = self._zeros((self.B, self.L)), self._zeros((self.B, self.L))
+        dist = self._empty((n, self.Tp, self.L))
+        self._check(self.lib.plsx_boot_batch(self.ctx, idx.data_ptr(), n, usum.data_ptr(),
+                                             usq.data_ptr(), dist.data_ptr(), self._stream()))
+        self.sync()
+        return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
+
+    def boot_rel(self, orig, usum, usq, n_boot):
+        """compute.boot_rel on the device; orig numpy or tensor (B, L)."""
+        torch = _torch()
+        d_orig = orig if isinstance(orig, torch.Tensor) else self._dev(orig, np.float64)
+        bsr, se = self._empty(tuple(usum.shape)), self._empty(tuple(usum.shape))
+        self._check(self.lib.plsx_boot_rel(self.ctx, d_orig.data_ptr(), usum.data_ptr(), usq.data_ptr(),
+                                           int(n_boot), usum.numel(), bsr.data_ptr(), se.data_ptr(),
+                                           self._stream()))
+        self.sync()
+        return bsr.cpu().numpy(), se.cpu().numpy()
+
+    # -- measurement --------------------------------------------------------
+    def set_timing(self, enable=True):
+        self._check(self.lib.plsx_set_timing(self.ctx, 1 if enable else 0))
+
+    def last_timing(self):
+        buf = (ctypes.c_double * 8)()
+        n = self.lib.plsx_last_timing(self.ctx, buf, 8)
+        keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch']
+        return {k: buf[i] for i, k in enumerate(keys[:max(n, 0)])}

@@ -1,0 +1,129 @@
+"""Kernel-level parity (through the C ABI) against the oracle. GPU only."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from pypyls_amd.engine import Engine
+    return Engine()
+
+
+def _data(S, B, T, seed=0, signal=0.5):
+    rs = np.random.RandomState(seed)
+    X = rs.randn(S, B) + 3.0 * rs.rand(1, B)
+    Y = rs.randn(S, T) + 1.5
+    k = min(T, B)
+    Y[:, :k] += signal * X[:, :k]
+    return X, Y, rs
+
+
+def _setup(eng, X, Y, groups, n_cond, method='behavioral', covariance=False, mc=0):
+    from pypyls_amd import resampling as rsmp
+    eng.set_data(X, Y if method == 'behavioral' else None, rsmp.cell_of_row(groups, n_cond),
+                 len(groups), n_cond, 0 if method == 'behavioral' else 1,
+                 mean_centering=mc, covariance=covariance)
+    return ref.Spec(method, groups, n_cond, covariance, mc)
+
+
+CASES = [
+    dict(S=40, B=300, T=6, groups=[40], n_cond=1),
+    dict(S=46, B=130, T=4, groups=[11, 12], n_cond=2),
+    dict(S=36, B=70, T=5, groups=[12], n_cond=3, covariance=True),
+    dict(S=20, B=3, T=3, groups=[20], n_cond=1),
+    dict(S=30, B=7, T=5, groups=[15, 15], n_cond=1),          # T' = 10 > B = 7
+    dict(S=81, B=1000, T=10, groups=[81], n_cond=1),
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_crosscov_and_decompose_behavioral(case):
+    case = dict(case)
+    cov = case.pop('covariance', False)
+    X, Y, rs = _data(case['S'], case['B'], case['T'])
+    eng = _engine()
+    spec = _setup(eng, X, Y, case['groups'], case['n_cond'], covariance=cov)
+    from pypyls_amd import resampling as rsmp
+    R0 = eng.crosscov(n=1)[0]
+    assert_close(R0, ref.gen_covcorr(spec, X, Y, spec.dummy), 1e-10, what='R original')
+    perms = rsmp.gen_permsamp(case['groups'], case['n_cond'], 5, seed=1)
+    boots = rsmp.gen_bootsamp(case['groups'], case['n_cond'], 5, seed=2)
+    Rp = eng.crosscov(ysrc=perms)
+    Rb = eng.crosscov(xsrc=boots, ysrc=boots)
+    for i in range(5):
+        assert_close(Rp[i], ref.gen_covcorr(spec, X, Y[perms[:, i]], spec.dummy), 1e-10, what='R perm')
+        assert_close(Rb[i], ref.gen_covcorr(spec, X[boots[:, i]], Y[boots[:, i]], spec.dummy),
+                     1e-10, what='R boot')
+    xw, sv, yw = eng.decompose()
+    U, d, V = ref.decompose(spec, X, Y)
+    assert_close(sv, np.diag(d), 1e-9, what='singvals')
+    sgn = np.sign(np.sum(xw * U, axis=0))
+    assert_close(xw * sgn, U, 1e-7, what='x_weights')
+    assert_close(yw * sgn, V, 1e-7, what='y_weights')
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_perm_and_boot_behavioral(case):
+    case = dict(case)
+    cov = case.pop('covariance', False)
+    X, Y, rs = _data(case['S'], case['B'], case['T'], seed=3)
+    eng = _engine()
+    spec = _setup(eng, X, Y, case['groups'], case['n_cond'], covariance=cov)
+    from pypyls_amd import resampling as rsmp
+    U, d, V = ref.decompose(spec, X, Y)
+    eng.set_original(U, np.diag(d), V)
+    perms = rsmp.gen_permsamp(case['groups'], case['n_cond'], 9, seed=1)
+    got = eng.perm(perms, rotate=True)
+    want = np.stack([ref.single_perm(spec, X, Y, perms[:, i], V)[0] for i in range(9)], -1)
+    assert_close(got, want, 1e-8, what='rotated perm singvals')
+    spec.rotate = False
+    got = eng.perm(perms, rotate=False)
+    want = np.stack([ref.single_perm(spec, X, Y, perms[:, i], V)[0] for i in range(9)], -1)
+    assert_close(got, want, 1e-8, what='raw perm singvals')
+    boots = rsmp.gen_bootsamp(case['groups'], case['n_cond'], 9, seed=2)
+    usum, usq, dist = eng.boot(boots)
+    ws, wq, wd = np.zeros_like(U), np.zeros_like(U), []
+    for i in range(9):
+        dd, ub = ref.single_boot(spec, X, Y, boots[:, i], U, d)
+        ws += ub
+        wq += ub ** 2
+        wd.append(dd)
+    assert_close(usum.cpu().numpy(), ws, 1e-7, what='u_sum')
+    assert_close(usq.cpu().numpy(), wq, 1e-7, what='u_square')
+    assert_close(dist, np.stack(wd, -1), 1e-7, what='distrib')
+
+
+@pytest.mark.parametrize('mc', [0, 1, 2])
+def test_meancentered(mc):
+    rs = np.random.RandomState(5)
+    groups, n_cond = [8, 9, 10], 2
+    X = rs.randn(54, 400)
+    X[:18] += 0.8
+    X[27:] -= 0.5
+    eng = _engine()
+    spec = _setup(eng, X, None, groups, n_cond, method='meancentered', mc=mc)
+    from pypyls_amd import resampling as rsmp
+    Y = spec.dummy.astype(float)
+    assert_close(eng.crosscov(n=1)[0], ref.gen_covcorr(spec, X, Y, spec.dummy), 1e-10, what='R')
+    U, d, V = ref.decompose(spec, X, Y)
+    live = ref.live_lvs(d)
+    xw, sv, yw = eng.decompose()
+    assert_close(sv[live], np.diag(d)[live], 1e-9, what='singvals')
+    eng.set_original(U, np.diag(d), V)
+    perms = rsmp.gen_permsamp(groups, n_cond, 7, seed=1)
+    got = eng.perm(perms)
+    want = np.stack([ref.single_perm(spec, X, Y, perms[:, i], V)[0] for i in range(7)], -1)
+    assert_close(got[live], want[live], 1e-8, what='perm')
+    boots = rsmp.gen_bootsamp(groups, n_cond, 7, seed=2)
+    usum, usq, dist = eng.boot(boots)
+    ws, wd = np.zeros_like(U), []
+    for i in range(7):
+        dd, ub = ref.single_boot(spec, X, Y, boots[:, i], U, d)
+        ws += ub
+        wd.append(dd)
+    assert_close(usum.cpu().numpy()[:, live], ws[:, live], 1e-7, what='u_sum')
+    assert_close(dist[:, live], np.stack(wd, -1)[:, live], 1e-7, what='distrib')

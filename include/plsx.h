@@ -153,10 +153,17 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx,
                           double* d_ucorr, double* d_vcorr, void* stream);
 
 /* Bootstrap ratios -- compute.boot_rel (pyls/compute.py:212-237), elementwise
- * on (B, L) arrays: se = sqrt(|usq - usum^2/n| / (n-1)), bsr = orig / se. */
+ * on (B, L) arrays: se = sqrt(|usq - usum^2/n| / (n-1)), bsr = orig / se.
+ * add_orig != 0 first adds the original back (usum + orig, usq + orig^2) as
+ * behavioral / regression PLS do (pyls/types/behavioral.py:201-203); `n` is
+ * then n_boot + 1. */
 int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum,
-                  const double* d_usq, int n_boot, long long count,
+                  const double* d_usq, int n, int add_orig, long long count,
                   double* d_bsr, double* d_se, void* stream);
+
+/* On-box fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, 8
+ * independent accumulators per wave): measured TFLOP/s -> *tflops. */
+int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops);
 
 /* Performance counters of the last perm/boot call: fills up to `cap` doubles:
  * [0] kernel ms of the cross-product kernel (HIP events on the launch stream),

@@ -586,16 +586,41 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t*, const uint8_t*, int, co
 }
 
 int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, const double* d_usq,
-                  int n_boot, long long count, double* d_bsr, double* d_se, void* stream)
+                  int n_boot, int add_orig, long long count, double* d_bsr, double* d_se, void* stream)
 {
     if (!ctx) return PLSX_ERR_ARG;
     if (!d_orig || !d_usum || !d_usq || !d_bsr || !d_se || count < 1 || n_boot < 2)
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_rel: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_boot_rel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), d_orig, d_usum, d_usq, (double)n_boot, count,
+                       static_cast<hipStream_t>(stream), d_orig, d_usum, d_usq, (double)n_boot, add_orig, count,
                        d_bsr, d_se);
     LAUNCHCHK();
+    return PLSX_OK;
+}
+
+int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops)
+{
+    if (!ctx || !tflops) return PLSX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int blocks = 256 * 8, iters = 4096;
+    Buf tmp;
+    if (int e = ensure(ctx, tmp, (size_t)blocks * 256 * 8)) return e;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, ptr<double>(tmp), 64);   // warm-up
+    HIPCHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, ptr<double>(tmp), iters);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    release(tmp);
+    const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
     return PLSX_OK;
 }
 

@@ -762,19 +762,39 @@ __global__ void k_gather_cols(const double* __restrict__ R, long long strideR, i
 
 // compute.boot_rel (pyls/compute.py:212-237)
 __global__ void k_boot_rel(const double* __restrict__ orig, const double* __restrict__ usum,
-                           const double* __restrict__ usq, double n, long long count,
+                           const double* __restrict__ usq, double n, int add_orig, long long count,
                            double* __restrict__ bsr, double* __restrict__ se)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const double s = usum[i];
-    const double e = sqrt(fabs(usq[i] - s * s / n) / (n - 1.0));
+    const double o = orig[i];
+    const double s = usum[i] + (add_orig ? o : 0.0);
+    const double q = usq[i] + (add_orig ? o * o : 0.0);
+    const double e = sqrt(fabs(q - s * s / n) / (n - 1.0));
     se[i] = e;
-    bsr[i] = orig[i] / e;
+    bsr[i] = o / e;
 }
 
 __global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n * S) dst[i] = i % S;
+}
+
+// fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave,
+// 4 waves per block; used to confirm the fp64 matrix peak on the box.
+__global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ out, int iters)
+{
+    d4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double a = 1e-3 * (double)(threadIdx.x & 63), b = 1.0 + 1e-6 * (double)blockIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = mfma_f64(a, b, acc[j]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }

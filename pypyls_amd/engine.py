@@ -54,9 +54,10 @@ def _load():
         'plsx_perm_batch': ([vp, vp, i32, i32, vp, vp], i32),
         'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
         'plsx_split_half_batch': ([vp, vp, vp, i32, vp, vp, vp, vp, vp], i32),
-        'plsx_boot_rel': ([vp, vp, vp, vp, i32, ctypes.c_longlong, vp, vp, vp], i32),
+        'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
+        'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -73,7 +74,7 @@ def exported_symbols():
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
              'plsx_colmean', 'plsx_perm_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
-             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing']
+             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -237,18 +238,44 @@ class Engine(object):
         self.sync()
         return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
 
-    def boot_rel(self, orig, usum, usq, n_boot):
-        """compute.boot_rel on the device; orig numpy or tensor (B, L)."""
+    # -- device-resident variants (no host copies, no sync): bench / pipelines --
+    def index_tensor(self, samples):
+        """(S, n) host index array -> (n, S) int32 device tensor."""
+        return self._index_rows(samples)
+
+    def perm_into(self, idx_dev, out_dev, rotate=True):
+        """idx_dev (n, S) int32 device tensor, out_dev (n, L) fp64 device tensor."""
+        self._check(self.lib.plsx_perm_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
+                                             1 if rotate else 0, out_dev.data_ptr(), self._stream()))
+
+    def boot_into(self, idx_dev, usum, usq, dist_dev):
+        """idx_dev (n, S) int32; usum / usq (B, L) accumulated in place; dist_dev
+        (n, T', L)."""
+        self._check(self.lib.plsx_boot_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
+                                             usum.data_ptr(), usq.data_ptr(), dist_dev.data_ptr(),
+                                             self._stream()))
+
+    def boot_rel(self, orig, usum, usq, n_boot, add_orig=False):
+        """compute.boot_rel on the device; orig numpy or tensor (B, L).  With
+        add_orig the original is added back first and ``n_boot`` must already
+        be R + 1 (behavioral.py:201-207)."""
         torch = _torch()
         d_orig = orig if isinstance(orig, torch.Tensor) else self._dev(orig, np.float64)
         bsr, se = self._empty(tuple(usum.shape)), self._empty(tuple(usum.shape))
         self._check(self.lib.plsx_boot_rel(self.ctx, d_orig.data_ptr(), usum.data_ptr(), usq.data_ptr(),
-                                           int(n_boot), usum.numel(), bsr.data_ptr(), se.data_ptr(),
+                                           int(n_boot), 1 if add_orig else 0, usum.numel(),
+                                           bsr.data_ptr(), se.data_ptr(),
                                            self._stream()))
         self.sync()
         return bsr.cpu().numpy(), se.cpu().numpy()
 
     # -- measurement --------------------------------------------------------
+    def mfma_f64_peak(self):
+        """Measured fp64 MFMA TFLOP/s of this GPU (microbenchmark)."""
+        v = ctypes.c_double()
+        self._check(self.lib.plsx_mfma_f64_peak(self.ctx, ctypes.byref(v)))
+        return v.value
+
     def set_timing(self, enable=True):
         self._check(self.lib.plsx_set_timing(self.ctx, 1 if enable else 0))
 

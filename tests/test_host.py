@@ -1,0 +1,145 @@
+"""CPU-only host logic: C-ABI library loads and exports every declared
+symbol, containers, finalisation helpers, multi-rank collection (gloo)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import cpu_ref as ref
+
+
+def test_library_exports_every_declared_symbol():
+    from pypyls_amd import _build, engine
+    _build.build()
+    hdr = open(os.path.join(ROOT, 'include', 'plsx.h')).read()
+    declared = set(re.findall(r'\b(plsx_[a-z_]+)\s*\(', hdr))
+    assert len(declared) >= 18
+    exported = set(engine.exported_symbols())
+    assert declared <= exported, declared - exported
+    lib = engine._load()
+    assert lib.plsx_version() >= 1000
+    assert lib.plsx_max_tprime() == 96
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    from pypyls_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(engine.PlsxError):
+        engine.Engine()
+    import pypyls_amd as pls
+    with pytest.raises(engine.PlsxError):
+        pls.behavioral_pls(np.random.rand(10, 4), np.random.rand(10, 2), n_perm=2, n_boot=2,
+                           test_split=0)
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, 'pypyls_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert 'oracle' not in src, f
+
+
+def test_structures():
+    """pyls/tests/test_structures.py:9-33, test_utils.py ResDict semantics."""
+    from pypyls_amd import PLSInputs, PLSResults
+    inp = PLSInputs(X=1, Y=2, n_split=0, test_split=0, n_proc=-1, notakey=5)
+    assert 'notakey' not in inp and inp.n_split is None and inp.test_split is None
+    assert inp.n_proc == (os.cpu_count() or 1)
+    assert PLSInputs(n_proc='max').n_proc == (os.cpu_count() or 1)
+    assert PLSInputs(n_proc=-2).n_proc == (os.cpu_count() or 1) - 1
+    with pytest.raises(ValueError):
+        PLSInputs(test_size=1)
+    with pytest.raises(ValueError):
+        PLSInputs(test_size=-0.5)
+    res = PLSResults(x_weights=np.ones(3), bogus=1)
+    assert 'bogus' not in res
+    res['alsobogus'] = 2
+    assert 'alsobogus' not in res
+    assert res == PLSResults(x_weights=np.ones(3))
+    assert res != PLSResults(x_weights=np.zeros(3))
+    assert str(res) == 'PLSResults(x_weights)'
+    for sub in ('permres', 'bootres', 'splitres', 'cvres', 'inputs'):
+        assert sub in res
+
+
+def test_hostmath_against_oracle():
+    from pypyls_amd import hostmath
+    rs = np.random.RandomState(0)
+    d = np.sort(rs.rand(5))[::-1]
+    perm = rs.rand(5, 40)
+    np.testing.assert_array_equal(hostmath.perm_sig(d, perm), ref.perm_sig(np.diag(d), perm))
+    np.testing.assert_allclose(hostmath.varexp(d), np.diag(ref.varexp(np.diag(d))))
+    b = rs.rand(3, 4, 50)
+    for a, c in zip(hostmath.boot_ci(b, 90), ref.boot_ci(b, 90)):
+        np.testing.assert_array_equal(a, c)
+    xw, yw = rs.randn(20, 4), rs.randn(4, 4)
+    a, b2 = hostmath.sign_convention(xw, yw)
+    assert np.all(a[np.argmax(np.abs(a), 0), range(4)] > 0)
+    xw, yw = rs.randn(3, 3), rs.randn(7, 3)
+    a, b2 = hostmath.sign_convention(xw, yw)
+    assert np.all(b2[np.argmax(np.abs(b2), 0), range(3)] > 0)
+    X, Y = rs.randn(30, 4), rs.randn(30, 3)
+    cells = ref.dummy_label([8, 7], 2) - 1
+    spec = ref.Spec('behavioral', [8, 7], 2)
+    np.testing.assert_allclose(hostmath.cellwise_xcorr(X, Y, cells, 4),
+                               ref.gen_covcorr(spec, X, Y, spec.dummy), atol=1e-13)
+
+
+def test_shard_bounds():
+    from pypyls_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 8, 100, 10001):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+from pypyls_amd import parallel
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank, world = parallel.rank_world()
+L, Tp, B, P, R = 3, 4, 11, 7, 5
+rs = np.random.RandomState(0)
+perm_all = rs.rand(L, P); dist_all = rs.rand(Tp, L, R)
+usum_parts = rs.rand(world, B, L); usq_parts = rs.rand(world, B, L)
+lo, hi = parallel.shard_bounds(P, rank, world)
+bl, bh = parallel.shard_bounds(R, rank, world)
+perm, dd, usum, usq = parallel.collect(perm_all[:, lo:hi], P, dist_all[:, :, bl:bh], R,
+                                       torch.from_numpy(usum_parts[rank]), torch.from_numpy(usq_parts[rank]))
+assert np.array_equal(perm, perm_all) and np.array_equal(dd, dist_all)
+want = usum_parts[0].copy()
+for r in range(1, world): want += usum_parts[r]
+assert np.array_equal(usum.numpy(), want)
+# permutation-only call
+perm2, d2, u2, q2 = parallel.collect(perm_all[:, lo:hi], P, None, 0, None, None)
+assert np.array_equal(perm2, perm_all) and d2 is None and u2 is None
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_collect_multiprocess_gloo(tmp_path, world):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29512 + world))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(29512 + world), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == world

@@ -62,14 +62,14 @@ def cpu_baseline(X, Y, x_weights, y_weights, n_each, seed=1234):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--S', type=int, default=500)
     ap.add_argument('--B', type=int, default=200000)
     ap.add_argument('--T', type=int, default=50)
-    ap.add_argument('--perms', type=int, default=224, help='permutations per step per GPU')
-    ap.add_argument('--boots', type=int, default=224, help='bootstraps per step per GPU')
-    ap.add_argument('--cpu-sample', type=int, default=2,
+    ap.add_argument('--perms', type=int, default=1008, help='permutations per step per GPU')
+    ap.add_argument('--boots', type=int, default=1008, help='bootstraps per step per GPU')
+    ap.add_argument('--cpu-sample', type=int, default=8,
                     help='permutations and bootstraps (each) timed for the CPU baseline; 0 = skip')
     args = ap.parse_args()
 

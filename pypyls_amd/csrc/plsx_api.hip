@@ -37,6 +37,7 @@ struct plsx_ctx {
     Buf Afrag, R, Gm, Pm, part, Mfrag, U0T, V0, d0, tmpW;
     // timing of the cross-product kernel
     int timing = 0;
+    int variant = 0;        // cross-product kernel variant (PLSX_XPROD_VARIANT, tuning only)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double last_ms = 0.0;
     int last_launches = 0;
@@ -101,17 +102,22 @@ void plan_groups(plsx_ctx* c)
         if (td + 2 * tw <= c->MT && tw * 16 <= 48) best = n; else break;
     }
     c->npg = best;
-    c->w0 = ceil_div(best * c->Tp, 16);
+    // tile order inside a group: data tiles, (unused tiles,) first-moment
+    // (weight) tiles, second-moment tiles LAST (the kernel's static split)
     const int tw = Jw ? ceil_div(best * Jw, 16) : 0;
-    c->sq0 = c->w0 + tw;
+    c->sq0 = c->MT - tw;
+    c->w0 = c->sq0 - tw;
     c->nmom_pad = tw * 16;
-    if (!c->scaled) { c->sq0 = c->MT; c->w0 = c->MT; }   // every tile is a data tile, B operand x
     c->group_stride = (size_t)c->nks * c->MT * 64;
     const int ncolblk = c->Bpad / 128;
+    // super-batch = g groups.  Large enough that (a) the cross-product grid
+    // covers the chip many times over and (b) the latency-bound small-solver
+    // launch (one block per resample) has >= 2 blocks per CU to overlap.
     int g = round_up(std::max(1, ceil_div(2048, ncolblk)), 8);
-    g = std::min(std::max(g, 8), 64);
+    g = std::max(g, round_up(ceil_div(512, std::max(best, 1)), 8));
+    g = std::min(std::max(g, 8), 128);
     const char* env = getenv("PLSX_SCRATCH_GB");
-    const double budget = (env ? atof(env) : 16.0) * 1073741824.0;
+    const double budget = (env ? atof(env) : 48.0) * 1073741824.0;
     while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);
     c->Gcap = g;
 }
@@ -152,37 +158,57 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
     return 0;
 }
 
-template <int MT>
+template <int MT, int NW, int KT, int NSQ>
 int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 {
-    const size_t stage = (size_t)2 * XP_KT * MT * 64 * 8;
-    const size_t epi = (size_t)8 * 2 * ctx->nmom_pad * 16 * 8;
+    const size_t stage = (size_t)2 * KT * MT * 64 * 8;
+    const size_t epi = (size_t)NW * 2 * ctx->nmom_pad * 16 * 8;
     const size_t lds = std::max(stage, epi);
     static size_t configured = 0;
     if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    const int ncolblk = ctx->Bpad / 128;
-    dim3 grid(ncolblk * groups), block(512);
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    dim3 grid(ncolblk * round_up(groups, 8)), block(NW * 64);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         HIPCHK(hipEventCreate(&e0));
         HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(k_xprod<MT>, grid, block, lds, st,
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ>), grid, block, lds, st,
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
-                       std::max(ctx->nmom_pad, 0), groups, ctx->w0, ctx->sq0);
+                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->w0, ctx->sq0);
     LAUNCHCHK();
     if (ctx->timing) {
         HIPCHK(hipEventRecord(e1, st));
         ctx->events.emplace_back(e0, e1);
     }
     return 0;
+}
+
+template <int NW, int KT>
+int launch_xprod_nsq(plsx_ctx* ctx, int groups, hipStream_t st)
+{
+    switch (ctx->MT - ctx->sq0) {          // number of second-moment tiles (0..3)
+        case 0: return launch_xprod_t<24, NW, KT, 0>(ctx, groups, st);
+        case 1: return launch_xprod_t<24, NW, KT, 1>(ctx, groups, st);
+        case 2: return launch_xprod_t<24, NW, KT, 2>(ctx, groups, st);
+        default: return launch_xprod_t<24, NW, KT, 3>(ctx, groups, st);
+    }
+}
+
+int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
+{
+    switch (ctx->variant) {
+        case 1: return launch_xprod_nsq<8, 2>(ctx, groups, st);
+        case 2: return launch_xprod_nsq<8, 1>(ctx, groups, st);
+        default: return launch_xprod_nsq<4, 1>(ctx, groups, st);
+    }
 }
 
 // Build the A operands of `nres` resamples and run the cross-product kernel:
@@ -210,9 +236,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
                            ctx->group_stride);
     }
     LAUNCHCHK();
-    if (ctx->MT == 24) return launch_xprod_t<24>(ctx, groups, st);
-    if (ctx->MT == 16) return launch_xprod_t<16>(ctx, groups, st);
-    return launch_xprod_t<8>(ctx, groups, st);
+    return launch_xprod(ctx, groups, st);
 }
 
 // C1 = A.B1^T (and C2 = A.B2^T), batched, contraction over K columns.
@@ -383,7 +407,8 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     ctx->J = J; ctx->n_groups = n_groups; ctx->n_cond = n_cond; ctx->mc = mean_centering;
     ctx->cov = (flags & PLSX_FLAG_COVARIANCE) ? 1 : 0;
     ctx->Tp = Tp; ctx->Tpp = round_up(Tp, 4); ctx->L = std::min(Tp, B);
-    ctx->Kpad = round_up(S, 4 * XP_KT); ctx->nks = ctx->Kpad / 4;
+    ctx->Kpad = round_up(S, 8); ctx->nks = ctx->Kpad / 4;
+    { const char* v = getenv("PLSX_XPROD_VARIANT"); ctx->variant = v ? atoi(v) : 0; }
     ctx->Bx = B + ctx->L; ctx->Bpad = round_up(ctx->Bx, 128);
     ctx->nks_t = ctx->Tpp / 4; ctx->LT = ceil_div(ctx->L, 16);
     ctx->strideR = (long long)ctx->Tpp * ctx->Bpad;

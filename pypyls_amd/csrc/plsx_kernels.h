@@ -217,25 +217,36 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
 // (weights, B operand x), then second-moment rows (same weights, B operand
 // x*x).  The epilogue turns the two moments into 1/std of the resampled
 // feature inside the cell (ddof = 1, pyls/compute.py:84) and scales R.
-#define XP_KT 2                 // k-steps (of 4 rows) per LDS stage
-template <int MT>
-__global__ __launch_bounds__(512, 2)
+// NW waves per block (block = NW*16 feature columns), KT k-steps per LDS stage.
+// NSQ = number of second-moment tiles; they are the LAST NSQ tiles of the block
+// (static split: no per-tile operand select in the MFMA loop -- VALU work between
+// fp64 MFMAs costs matrix-pipe issue slots on gfx950, measured 8 %).
+template <int MT, int NW, int KT, int NSQ>
+__global__ __launch_bounds__(NW * 64, 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
              double* __restrict__ R, int ldr, int rows_per_group,
              const int* __restrict__ out_row, const int* __restrict__ mom_idx,
              const double* __restrict__ mom_n, int nmom_pad,
-             int n_groups, int w0, int sq0)
+             int n_groups, int ncolblk, int w0, int sq0)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int STAGE = XP_KT * MT * 64;           // doubles per stage
-    constexpr int PASSES = STAGE / 1024;             // 512 threads x double2
-    static_assert(STAGE % 1024 == 0, "MT must be a multiple of 8");
+    constexpr int NT = NW * 64;                      // threads
+    constexpr int STAGE = KT * MT * 64;              // doubles per stage
+    constexpr int PASSES = (STAGE + NT * 2 - 1) / (NT * 2);   // NT threads x double2
+    constexpr bool EVEN = (STAGE % (NT * 2)) == 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int grp = blockIdx.x % n_groups;
-    const int colblk = blockIdx.x / n_groups;
-    const int col = colblk * 128 + wave * 16 + (lane & 15);
+    // block id -> (group, column block): consecutive ids walk 8 groups (one per
+    // XCD: block b runs on XCD b % 8, so each XCD's L2 keeps ONE group's A
+    // operand at a time) and then the column blocks; groups beyond the first 8
+    // follow in further sweeps over the columns.
+    const int sweep = blockIdx.x / (8 * ncolblk);
+    const int within = blockIdx.x - sweep * (8 * ncolblk);
+    const int grp = sweep * 8 + (within & 7);
+    const int colblk = within >> 3;
+    if (grp >= n_groups) return;
+    const int col = colblk * (NW * 16) + wave * 16 + (lane & 15);
     const int kq = lane >> 4;
 
     const double* Ag = Afrag + (size_t)grp * group_stride;
@@ -245,48 +256,58 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int nkt = nks / XP_KT;
+    const int nkt = nks / KT;
     // prologue: stage 0 of A, first X fragments
     {
         const d2* src = reinterpret_cast<const d2*>(Ag);
         d2* dst = reinterpret_cast<d2*>(smem);
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) dst[p * 512 + tid] = src[p * 512 + tid];
+        for (int p = 0; p < PASSES; ++p)
+            if (EVEN || p * NT + tid < STAGE / 2) dst[p * NT + tid] = src[p * NT + tid];
     }
-    double xb[XP_KT];
+    double xb[KT];
 #pragma unroll
-    for (int s = 0; s < XP_KT; ++s) xb[s] = Xp[(size_t)(s * 4) * ldx];
+    for (int s = 0; s < KT; ++s) xb[s] = Xp[(size_t)(s * 4) * ldx];
+    // Force the first X fragments to be resident before the loop: a load still
+    // pending at the loop header makes hipcc place a near-draining
+    // s_waitcnt vmcnt(1) right after the next stage's loads are issued.
+#pragma unroll
+    for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(xb[s]));
     __syncthreads();
 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        const bool more = (kt + 1 < nkt);
+        // next stage (clamped on the last pass: a harmless re-load keeps the
+        // loop body branch-free so the waits sit right before the LDS write)
+        const int kn = min(kt + 1, nkt - 1);
         d2 stg[PASSES];
-        double xn[XP_KT];
-        if (more) {
-            const d2* src = reinterpret_cast<const d2*>(Ag + (size_t)(kt + 1) * STAGE);
+        double xn[KT];
+        {
+            const d2* src = reinterpret_cast<const d2*>(Ag + (size_t)kn * STAGE);
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) stg[p] = src[p * 512 + tid];
+            for (int p = 0; p < PASSES; ++p)
+                if (EVEN || p * NT + tid < STAGE / 2) stg[p] = src[p * NT + tid];
 #pragma unroll
-            for (int s = 0; s < XP_KT; ++s) xn[s] = Xp[(size_t)(((kt + 1) * XP_KT + s) * 4) * ldx];
+            for (int s = 0; s < KT; ++s) xn[s] = Xp[(size_t)((kn * KT + s) * 4) * ldx];
         }
         const double* sA = smem + cur * STAGE + lane;
 #pragma unroll
-        for (int s = 0; s < XP_KT; ++s) {
+        for (int s = 0; s < KT; ++s) {
             const double b = xb[s];
-            const double bsq = b * b;
+            const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const double a = sA[(s * MT + m) * 64];
-                acc[m] = mfma_f64(a, (m < sq0) ? b : bsq, acc[m]);
+                acc[m] = mfma_f64(a, (m < MT - NSQ) ? b : bsq, acc[m]);
             }
         }
-        if (more) {
+        {
             d2* dst = reinterpret_cast<d2*>(smem + (cur ^ 1) * STAGE);
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) dst[p * 512 + tid] = stg[p];
+            for (int p = 0; p < PASSES; ++p)
+                if (EVEN || p * NT + tid < STAGE / 2) dst[p * NT + tid] = stg[p];
 #pragma unroll
-            for (int s = 0; s < XP_KT; ++s) xb[s] = xn[s];
+            for (int s = 0; s < KT; ++s) xb[s] = xn[s];
         }
         __syncthreads();
     }

@@ -29,6 +29,9 @@ def _load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own HIP runtime; import it first so that the
+    # library binds to the runtime torch already loaded (one runtime/process).
+    import torch  # noqa: F401
     path = _build.lib_path()
     if not os.path.exists(path):
         raise PlsxError(

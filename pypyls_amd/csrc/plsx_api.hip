@@ -158,15 +158,15 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
     return 0;
 }
 
-template <int MT, int NW, int KT, int NSQ>
+template <int MT, int NW, int KT, int NSQ, int DBG = 0>
 int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 {
     const size_t stage = (size_t)2 * KT * MT * 64 * 8;
-    const size_t epi = (size_t)NW * 2 * ctx->nmom_pad * 16 * 8;
+    const size_t epi = (size_t)NW * 2 * NSQ * 16 * 16 * 8 + (size_t)2 * MT * 16 * 4;
     const size_t lds = std::max(stage, epi);
     static size_t configured = 0;
     if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ>),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ, DBG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -178,11 +178,11 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
         HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ>), grid, block, lds, st,
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ, DBG>), grid, block, lds, st,
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
-                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->w0, ctx->sq0);
+                       std::max(ctx->nmom_pad, 0), groups, ncolblk);
     LAUNCHCHK();
     if (ctx->timing) {
         HIPCHK(hipEventRecord(e1, st));
@@ -206,7 +206,14 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 {
     switch (ctx->variant) {
         case 1: return launch_xprod_nsq<8, 2>(ctx, groups, st);
+        case 3: return launch_xprod_nsq<4, 2>(ctx, groups, st);
         case 2: return launch_xprod_nsq<8, 1>(ctx, groups, st);
+        case 11: return launch_xprod_t<24, 4, 1, 1, 1>(ctx, groups, st);   // tuning probes (wrong results)
+        case 12: return launch_xprod_t<24, 4, 1, 1, 2>(ctx, groups, st);
+        case 13: return launch_xprod_t<24, 4, 1, 1, 3>(ctx, groups, st);
+        case 14: return launch_xprod_t<24, 4, 1, 1, 4>(ctx, groups, st);
+        case 16: return launch_xprod_t<24, 4, 1, 1, 6>(ctx, groups, st);
+        case 17: return launch_xprod_t<24, 4, 1, 1, 7>(ctx, groups, st);
         default: return launch_xprod_nsq<4, 1>(ctx, groups, st);
     }
 }

@@ -218,17 +218,34 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
 // x*x).  The epilogue turns the two moments into 1/std of the resampled
 // feature inside the cell (ddof = 1, pyls/compute.py:84) and scales R.
 // NW waves per block (block = NW*16 feature columns), KT k-steps per LDS stage.
+// Copy one fragment-ordered A stage (STAGE doubles) global -> LDS with the
+// LDS-DMA path: each wave instruction moves 64 lanes x 16 B into
+// wave-uniform-base + lane*16, i.e. a straight lane-linear memcpy.
+template <int NT, int PASSES, bool EVEN, int STAGE>
+__device__ __forceinline__ void stage_copy(const double* __restrict__ src, double* dst, int tid)
+{
+    const int wbase = (tid >> 6) * 64;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (EVEN || p * NT + wbase < STAGE / 2) {
+            __builtin_amdgcn_global_load_lds(
+                (const void*)(src + (size_t)(p * NT + tid) * 2),
+                (__attribute__((address_space(3))) void*)(dst + (size_t)(p * NT + wbase) * 2), 16, 0, 0);
+        }
+    }
+}
+
 // NSQ = number of second-moment tiles; they are the LAST NSQ tiles of the block
 // (static split: no per-tile operand select in the MFMA loop -- VALU work between
 // fp64 MFMAs costs matrix-pipe issue slots on gfx950, measured 8 %).
-template <int MT, int NW, int KT, int NSQ>
+template <int MT, int NW, int KT, int NSQ, int DBG = 0>
 __global__ __launch_bounds__(NW * 64, 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
              double* __restrict__ R, int ldr, int rows_per_group,
              const int* __restrict__ out_row, const int* __restrict__ mom_idx,
              const double* __restrict__ mom_n, int nmom_pad,
-             int n_groups, int ncolblk, int w0, int sq0)
+             int n_groups, int ncolblk)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = NW * 64;                      // threads
@@ -258,13 +275,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     const int nkt = nks / KT;
     // prologue: stage 0 of A, first X fragments
-    {
-        const d2* src = reinterpret_cast<const d2*>(Ag);
-        d2* dst = reinterpret_cast<d2*>(smem);
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            if (EVEN || p * NT + tid < STAGE / 2) dst[p * NT + tid] = src[p * NT + tid];
-    }
+    stage_copy<NT, PASSES, EVEN, STAGE>(Ag, smem, tid);
     double xb[KT];
 #pragma unroll
     for (int s = 0; s < KT; ++s) xb[s] = Xp[(size_t)(s * 4) * ldx];
@@ -280,13 +291,12 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         // next stage (clamped on the last pass: a harmless re-load keeps the
         // loop body branch-free so the waits sit right before the LDS write)
         const int kn = min(kt + 1, nkt - 1);
-        d2 stg[PASSES];
         double xn[KT];
-        {
-            const d2* src = reinterpret_cast<const d2*>(Ag + (size_t)kn * STAGE);
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p)
-                if (EVEN || p * NT + tid < STAGE / 2) stg[p] = src[p * NT + tid];
+        if (!(DBG & 2)) {
+            // A stage kn: global -> LDS DMA (global_load_lds_dwordx4: no staging
+            // VGPRs, no ds_write pass), into the buffer every wave finished
+            // reading before the barrier that ended the previous pass.
+            stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE, tid);
 #pragma unroll
             for (int s = 0; s < KT; ++s) xn[s] = Xp[(size_t)((kn * KT + s) * 4) * ldx];
         }
@@ -297,65 +307,70 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const double a = sA[(s * MT + m) * 64];
+                const double a = (DBG & 1) ? b : sA[(s * MT + m) * 64];
                 acc[m] = mfma_f64(a, (m < MT - NSQ) ? b : bsq, acc[m]);
             }
         }
-        {
-            d2* dst = reinterpret_cast<d2*>(smem + (cur ^ 1) * STAGE);
-#pragma unroll
-            for (int p = 0; p < PASSES; ++p)
-                if (EVEN || p * NT + tid < STAGE / 2) dst[p * NT + tid] = stg[p];
+        if (!(DBG & 2)) {
 #pragma unroll
             for (int s = 0; s < KT; ++s) xb[s] = xn[s];
+            __syncthreads();             // (drains the DMA issued one pass ago, then barrier)
         }
-        __syncthreads();
     }
 
-    // ---- epilogue: feature scale from the moment tiles -------------------
-    // lane (kq, c) reg i of a weight tile holds m1 of moment row
-    // (tile-w0)*16 + kq + 4*i, and the same lane/reg of the matching sq tile
-    // holds m2 of that row.
-    // (nmom_pad == (sq0 - w0) * 16; the A stages are dead, reuse their LDS)
-    double* sS = smem + wave * (2 * nmom_pad * 16);  // m1 -> scale: [nmom_pad][16] per wave
-    double* sQ = sS + nmom_pad * 16;                 // m2
-    const int ntw = sq0 - w0;
-    if (ntw > 0) {
+    // ---- epilogue -----------------------------------------------------------
+    // Tile roles are static: data tiles [0, W0), first-moment (weight) tiles
+    // [W0, SQ0), second-moment tiles [SQ0, MT).  Lane (kq, c) reg i of weight
+    // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
+    // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
+    constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
+    double* sS = smem + wave * (2 * NMOM * 16);      // m1 -> 1/std : [NMOM][16] per wave
+    double* sQ = sS + NMOM * 16;                     // m2
+    int* s_out = reinterpret_cast<int*>(smem + NW * 2 * NMOM * 16);   // row maps, shared
+    int* s_mom = s_out + MT * 16;
+    for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+    if (NSQ > 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            if (m >= w0 && m < sq0 + ntw) {
-                double* dst = (m < sq0) ? sS + (m - w0) * 256 : sQ + (m - sq0) * 256;
+        for (int j = 0; j < NSQ; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[(kq + 4 * i) * 16 + (lane & 15)] = acc[m][i];
+            for (int i = 0; i < 4; ++i) {
+                sS[j * 256 + (kq + 4 * i) * 16 + (lane & 15)] = acc[W0 + j][i];
+                sQ[j * 256 + (kq + 4 * i) * 16 + (lane & 15)] = acc[SQ0 + j][i];
             }
-        }
     }
     __syncthreads();
-    if (ntw > 0) {
-        for (int mr = kq; mr < nmom_pad; mr += 4) {
+    if (NSQ > 0) {
+        for (int mr = kq; mr < NMOM; mr += 4) {
             const int o = mr * 16 + (lane & 15);
             const double m1 = sS[o], m2 = sQ[o];
             const double nn = mom_n[(size_t)grp * nmom_pad + mr];
             const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);
             sS[o] = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
         }
+        __syncthreads();
     }
-    __syncthreads();
     double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+    if (DBG & 4) {                       // tuning probe: skip the stores
+        double t = 0.0;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (m < w0) {
+        for (int m = 0; m < MT; ++m) t += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
+        if (t == 123.456) Rg[0] = t;
+        return;
+    }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m * 16 + kq + 4 * i;
-                const int orow = out_row[row];
-                if (orow >= 0) {
-                    const int mi = mom_idx[row];
-                    const double sc = (mi >= 0) ? sS[mi * 16 + (lane & 15)] : 1.0;
-                    Rg[(size_t)orow * ldr] = acc[m][i] * sc;
-                }
-            }
+    for (int m = 0; m < W0; ++m) {
+        int orow[4];
+        double sc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m * 16 + kq + 4 * i;
+            orow[i] = s_out[row];
+            const int mi = s_mom[row];
+            sc[i] = (NSQ > 0 && mi >= 0) ? sS[mi * 16 + (lane & 15)] : 1.0;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (orow[i] >= 0) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
     }
 }
 

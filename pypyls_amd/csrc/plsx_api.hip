@@ -286,6 +286,47 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     return 0;
 }
 
+// G_r (and P_r) of `nres` resamples held in ctx->R; T' <= 64 uses the
+// register-streamed k_gram, larger T' the generic tiled k_nt_gemm.
+int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
+{
+    const double* R = ptr<double>(ctx->R);
+    double* Gm = ptr<double>(ctx->Gm);
+    double* Pm = ptr<double>(ctx->Pm);
+    const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * ctx->L;
+    if (ctx->Tp > 64)
+        return run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                      with_p ? ptr<double>(ctx->U0T) : nullptr, 0, ctx->Bpad, ctx->L, ctx->B, nres,
+                      Gm, sG, ctx->Tp, with_p ? Pm : nullptr, sP, ctx->L, st);
+    int nchunk = std::max(1, ceil_div(4096, nres));
+    nchunk = std::min(nchunk, std::max(1, ctx->B / 512));
+    const int cols = round_up(ceil_div(ctx->B, nchunk), 16);
+    nchunk = ceil_div(ctx->B, cols);
+    if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
+    double* part = ptr<double>(ctx->part);
+    dim3 grid(nchunk, nres), block(256);
+    if (with_p)
+        hipLaunchKernelGGL(k_gram<true>, grid, block, 0, st, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                           ptr<double>(ctx->U0T), ctx->Bpad, ctx->L, ctx->B, cols, part, nres);
+    else
+        hipLaunchKernelGGL(k_gram<false>, grid, block, 0, st, R, ctx->strideR, ctx->Bpad, ctx->Tp,
+                           (const double*)nullptr, 0, ctx->L, ctx->B, cols, part, nres);
+    LAUNCHCHK();
+    {
+        dim3 g(ceil_div(ctx->Tp * ctx->Tp, 256), nres);
+        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 0, Gm, sG,
+                           ctx->Tp, ctx->Tp, ctx->Tp);
+        LAUNCHCHK();
+    }
+    if (with_p) {
+        dim3 g(ceil_div(ctx->Tp * ctx->L, 256), nres);
+        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 1, Pm, sP,
+                           ctx->L, ctx->Tp, ctx->L);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
     const int n = a.n, ld = n | 1;
@@ -504,10 +545,7 @@ int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     if (int e = run_xprod(ctx, nullptr, nullptr, 1, st)) return e;
-    const double* R = ptr<double>(ctx->R);
-    if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                       nullptr, 0, 0, 0, ctx->B, 1, ptr<double>(ctx->Gm), 0, ctx->Tp, nullptr, 0, 0, st))
-        return e;
+    if (int e = run_gram(ctx, 1, false, st)) return e;
     SmallArgs a = small_args(ctx, SMALL_DECOMP);
     a.out_V = d_yw; a.out_d = d_sv;
     if (int e = run_small(ctx, a, 1, st)) return e;
@@ -568,11 +606,7 @@ int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate,
         const int* xs = (ctx->method == PLSX_BEHAVIORAL) ? nullptr : idx;
         const int* ys = (ctx->method == PLSX_BEHAVIORAL) ? idx : nullptr;
         if (int e = run_xprod(ctx, xs, ys, m, st)) return e;
-        const double* R = ptr<double>(ctx->R);
-        if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                           nullptr, 0, 0, 0, ctx->B, m, ptr<double>(ctx->Gm), (long long)ctx->Tp * ctx->Tp,
-                           ctx->Tp, nullptr, 0, 0, st))
-            return e;
+        if (int e = run_gram(ctx, m, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_PERM);
         a.rotate = rotate ? 1 : 0;
         a.out_sv = d_out_sv + (size_t)off * ctx->L;
@@ -594,12 +628,8 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
         const int m = std::min(nb, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
         if (int e = run_xprod(ctx, idx, idx, m, st)) return e;
+        if (int e = run_gram(ctx, m, true, st)) return e;
         const double* R = ptr<double>(ctx->R);
-        if (int e = run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                           ptr<double>(ctx->U0T), 0, ctx->Bpad, ctx->L, ctx->B, m,
-                           ptr<double>(ctx->Gm), (long long)ctx->Tp * ctx->Tp, ctx->Tp,
-                           ptr<double>(ctx->Pm), (long long)ctx->Tp * ctx->L, ctx->L, st))
-            return e;
         SmallArgs a = small_args(ctx, SMALL_BOOT);
         if (int e = run_small(ctx, a, m, st)) return e;
         if (int e = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e;

@@ -469,6 +469,103 @@ void k_nt_gemm(NtArgs a)
         }
 }
 
+// ---------------------------------------------------------------------------
+// K_G (T' <= 64 fast path): G_r = R_r R_r^T and P_r = R_r U0 for one resample
+// and one column chunk per block, straight from HBM/L2 into MFMA fragments --
+// no LDS, no barriers, waves fully independent.
+//
+// The contraction index (feature column) may be assigned to MFMA k-slots in
+// any order as long as A and B operands agree, so lane (m = l & 15, q = l >> 4)
+// loads FOUR consecutive columns c0 + 4q .. 4q+3 of row m (two dwordx4; the
+// four q-groups together cover one full 128-byte line of the row) and element
+// s of that quad feeds k-step s.  Wave w owns output column tile w of G and of
+// P; it reads all four row tiles of R (shared with the other waves through
+// L1) plus row tile w of R / of U0^T as its B operands.
+// ---------------------------------------------------------------------------
+template <bool WITH_P>
+__global__ __launch_bounds__(256)
+void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
+            const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
+            double* __restrict__ part, int nres)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.x, r = blockIdx.y;
+    const int cbeg = chunk * cols_per_chunk;
+    const int cend = min(B, cbeg + cols_per_chunk);
+    const double* Rr = R + (size_t)r * strideR;
+    // rows beyond T' are clamped: they only feed output rows / columns >= T',
+    // which the reduction never reads
+    const double* pa[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) pa[a] = Rr + (size_t)min(16 * a + m, Tp - 1) * ldr + 4 * q;
+    const double* pb = Rr + (size_t)min(16 * w + m, Tp - 1) * ldr + 4 * q;
+    const double* pu = WITH_P ? U0T + (size_t)min(16 * w + m, L - 1) * ldu + 4 * q : nullptr;
+    d4 accG[4], accP[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
+
+    int c0 = cbeg;
+    const int cfull = cbeg + ((cend - cbeg) / 16) * 16;
+    d4 xa[4], xb, ub = (d4){0, 0, 0, 0};
+    if (c0 < cfull) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xa[a] = *reinterpret_cast<const d4*>(pa[a] + c0);
+        xb = *reinterpret_cast<const d4*>(pb + c0);
+        if (WITH_P) ub = *reinterpret_cast<const d4*>(pu + c0);
+    }
+    for (; c0 < cfull; c0 += 16) {
+        d4 na[4], nb, nu = (d4){0, 0, 0, 0};
+        const int cn = min(c0 + 16, cfull - 16);          // clamped prefetch (re-load on the last pass)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) na[a] = *reinterpret_cast<const d4*>(pa[a] + cn);
+        nb = *reinterpret_cast<const d4*>(pb + cn);
+        if (WITH_P) nu = *reinterpret_cast<const d4*>(pu + cn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                accG[a] = mfma_f64(xa[a][s], xb[s], accG[a]);
+                if (WITH_P) accP[a] = mfma_f64(xa[a][s], ub[s], accP[a]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xa[a] = na[a];
+        xb = nb;
+        ub = nu;
+    }
+    if (cfull < cend) {                                    // ragged tail: mask columns >= cend
+        const int cc = cfull + 4 * q;
+        d4 ta[4], tb, tu = (d4){0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ta[a][s] = (cc + s < cend) ? pa[a][cfull + s] : 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            tb[s] = (cc + s < cend) ? pb[cfull + s] : 0.0;
+            if (WITH_P) tu[s] = (cc + s < cend) ? pu[cfull + s] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                accG[a] = mfma_f64(ta[a][s], tb[s], accG[a]);
+                if (WITH_P) accP[a] = mfma_f64(ta[a][s], tu[s], accP[a]);
+            }
+    }
+    // partial tiles: [chunk][resample][which][64 x 64]
+    double* out = part + (((size_t)chunk * nres + r) * 2) * 4096;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * a + q + 4 * i, col = 16 * w + m;
+            out[row * 64 + col] = accG[a][i];
+            if (WITH_P) out[4096 + row * 64 + col] = accP[a][i];
+        }
+}
+
 // C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
 __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
                               int mtiles, int ntiles, int which,
@@ -740,7 +837,20 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
         for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
         const double* Rp = R + (size_t)r * strideR + (size_t)(lane >> 4) * ldr + b0 + (lane & 15);
         const double* Mp = Mfrag + (size_t)r * mstride + lane;
-        for (int ks = 0; ks < nks_t; ++ks) {
+        // issue the R-fragment loads of several k-steps ahead of their MFMAs
+        // (HBM-latency bound otherwise: one 512-byte request per wave in flight)
+        int ks = 0;
+        for (; ks + 4 <= nks_t; ks += 4) {
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = Rp[(size_t)(ks + u) * 4 * ldr];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int l = 0; l < LT; ++l)
+                    acc[l] = mfma_f64(a[u], Mp[((ks + u) * LT + l) * 64], acc[l]);
+        }
+        for (; ks < nks_t; ++ks) {
             const double a = Rp[(size_t)ks * 4 * ldr];
 #pragma unroll
             for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a, Mp[(ks * LT + l) * 64], acc[l]);

@@ -155,7 +155,8 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic_xprod.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tpath))
+                traffic = tj.get('hbm_bytes_per_launch') * units_per_launch / tj.get('resamples_per_launch')
             except Exception:
                 traffic = None
         # whole-pipeline fractions: perm and boot flops / bytes per resample

@@ -665,7 +665,7 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops)
 {
     if (!ctx || !tflops) return PLSX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    const int blocks = 256 * 8, iters = 4096;
+    const int blocks = 256 * 8, iters = 1 << 16;   // ~0.1 s: long enough for the clock to settle
     Buf tmp;
     if (int e = ensure(ctx, tmp, (size_t)blocks * 256 * 8)) return e;
     hipEvent_t e0, e1;

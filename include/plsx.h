@@ -138,18 +138,21 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
                     double* d_usum, double* d_usq, double* d_distrib, void* stream);
 
 /*
- * Split-half reliability -- BasePLS.split_half (pyls/base.py:714-770) for ONE
- * (possibly permuted) data arrangement and m split masks.
- *   d_perm_idx (S,) int32 or NULL (un-permuted data)
- *   d_masks    (m, S) uint8, 1 = row belongs to the first half
- *   d_ud (B, L), d_vd (T', L): U @ inv(d), V @ inv(d) of that arrangement;
- *              NULL for both = decompose on the device first (the case inside
- *              _single_perm, base.py:705-708)
- *   d_ucorr, d_vcorr (m, L) out: per-split correlations (caller averages)
+ * Split-half reliability -- BasePLS.split_half (pyls/base.py:714-770) for np
+ * data arrangements (the original data and/or permuted data, base.py:705-708)
+ * with ns split masks each.  For every arrangement the library decomposes
+ * the full sample on the device (U, d, V of THAT arrangement, as
+ * _single_perm does), then for every split computes the two half-sample
+ * cross-covariance matrices D1, D2 and
+ *     ucorr = efficient_corr(D1.T @ V/d, D2.T @ V/d)     (over the B features)
+ *     vcorr = efficient_corr(D1 @ U/d,  D2 @ U/d)        (over the T' rows)
+ *   d_perm_idx (np, S) int32, or NULL = one un-permuted arrangement per entry
+ *   d_masks    (np, ns, S) uint8, 1 = row belongs to the first half
+ *   d_ucorr, d_vcorr (np, ns, L) out: per-split correlations (caller averages
+ *              over the ns splits, base.py:770)
  */
-int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx,
-                          const uint8_t* d_masks, int m,
-                          const double* d_ud, const double* d_vd,
+int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np,
+                          const uint8_t* d_masks, int ns,
                           double* d_ucorr, double* d_vcorr, void* stream);
 
 /* Bootstrap ratios -- compute.boot_rel (pyls/compute.py:212-237), elementwise

@@ -35,6 +35,7 @@ struct plsx_ctx {
     // device buffers
     Buf Xc, xmean, Y, cell_of_row, cell_start, cell_len, out_row, mom_idx, mom_n;
     Buf Afrag, R, Gm, Pm, part, Mfrag, U0T, V0, d0, tmpW;
+    Buf Rfull, Vp, dp, Mvd, Cm, srcx, srcy, part2;     // split-half scratch
     // timing of the cross-product kernel
     int timing = 0;
     int variant = 0;        // cross-product kernel variant (PLSX_XPROD_VARIANT, tuning only)
@@ -286,18 +287,27 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     return 0;
 }
 
-// G_r (and P_r) of `nres` resamples held in ctx->R; T' <= 64 uses the
+// Gram-type products of `nres` resamples held in ctx->R.
+//   mode 0: G_r = R_r R_r^T                      -> Gm
+//   mode 1: G_r and P_r = R_r E^T                -> Gm, Pout
+//   mode 2: P_r = R_r E^T only                   -> Pout
+// E (Erows x B, leading dimension Bpad) is shared by all resamples (U0^T for the
+// bootstrap, the full-sample R for split-half).  T' <= 64 uses the
 // register-streamed k_gram, larger T' the generic tiled k_nt_gemm.
-int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
+int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, double* Pout,
+                hipStream_t st)
 {
     const double* R = ptr<double>(ctx->R);
     double* Gm = ptr<double>(ctx->Gm);
-    double* Pm = ptr<double>(ctx->Pm);
-    const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * ctx->L;
-    if (ctx->Tp > 64)
+    const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
+    if (ctx->Tp > 64 || Erows > 64) {
+        if (mode == 2)
+            return run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, E, 0, ctx->Bpad, Erows,
+                          nullptr, 0, 0, 0, ctx->B, nres, Pout, sP, Erows, nullptr, 0, 0, st);
         return run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                      with_p ? ptr<double>(ctx->U0T) : nullptr, 0, ctx->Bpad, ctx->L, ctx->B, nres,
-                      Gm, sG, ctx->Tp, with_p ? Pm : nullptr, sP, ctx->L, st);
+                      mode == 1 ? E : nullptr, 0, ctx->Bpad, Erows, ctx->B, nres,
+                      Gm, sG, ctx->Tp, mode == 1 ? Pout : nullptr, sP, Erows, st);
+    }
     int nchunk = std::max(1, ceil_div(4096, nres));
     nchunk = std::min(nchunk, std::max(1, ctx->B / 512));
     const int cols = round_up(ceil_div(ctx->B, nchunk), 16);
@@ -305,26 +315,31 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
     double* part = ptr<double>(ctx->part);
     dim3 grid(nchunk, nres), block(256);
-    if (with_p)
-        hipLaunchKernelGGL(k_gram<true>, grid, block, 0, st, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                           ptr<double>(ctx->U0T), ctx->Bpad, ctx->L, ctx->B, cols, part, nres);
-    else
-        hipLaunchKernelGGL(k_gram<false>, grid, block, 0, st, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                           (const double*)nullptr, 0, ctx->L, ctx->B, cols, part, nres);
+#define GRAM_ARGS R, ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres
+    if (mode == 0) hipLaunchKernelGGL(k_gram<0>, grid, block, 0, st, GRAM_ARGS);
+    else if (mode == 1) hipLaunchKernelGGL(k_gram<1>, grid, block, 0, st, GRAM_ARGS);
+    else hipLaunchKernelGGL(k_gram<2>, grid, block, 0, st, GRAM_ARGS);
+#undef GRAM_ARGS
     LAUNCHCHK();
-    {
+    if (mode != 2) {
         dim3 g(ceil_div(ctx->Tp * ctx->Tp, 256), nres);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 0, Gm, sG,
                            ctx->Tp, ctx->Tp, ctx->Tp);
         LAUNCHCHK();
     }
-    if (with_p) {
-        dim3 g(ceil_div(ctx->Tp * ctx->L, 256), nres);
-        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 1, Pm, sP,
-                           ctx->L, ctx->Tp, ctx->L);
+    if (mode != 0) {
+        dim3 g(ceil_div(ctx->Tp * Erows, 256), nres);
+        hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 1, Pout, sP,
+                           Erows, ctx->Tp, Erows);
         LAUNCHCHK();
     }
     return 0;
+}
+
+int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
+{
+    return run_gram_ex(ctx, nres, with_p ? 1 : 0, with_p ? ptr<double>(ctx->U0T) : nullptr, ctx->L,
+                       ptr<double>(ctx->Pm), st);
 }
 
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
@@ -406,7 +421,8 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
     (void)hipDeviceSynchronize();
     for (Buf* b : {&ctx->Xc, &ctx->xmean, &ctx->Y, &ctx->cell_of_row, &ctx->cell_start, &ctx->cell_len,
                    &ctx->out_row, &ctx->mom_idx, &ctx->mom_n, &ctx->Afrag, &ctx->R, &ctx->Gm, &ctx->Pm,
-                   &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW})
+                   &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW,
+                   &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -641,10 +657,71 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
     return PLSX_OK;
 }
 
-int plsx_split_half_batch(plsx_ctx* ctx, const int32_t*, const uint8_t*, int, const double*,
-                          const double*, double*, double*, void*)
+int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, const uint8_t* d_masks,
+                          int ns, double* d_ucorr, double* d_vcorr, void* stream)
 {
-    return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_split_half_batch: not implemented in this build");
+    NEED_DATA();
+    if (!d_masks || !d_ucorr || !d_vcorr || np < 1 || ns < 1)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_split_half_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int S = ctx->S, Tp = ctx->Tp, L = ctx->L;
+    const int nb = ((ctx->Gcap * ctx->npg) / 2) * 2;          // slots per super-batch (pairs of halves)
+    if (nb < 2) return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_split_half_batch: scratch too small");
+    if (int e = ensure(ctx, ctx->Rfull, (size_t)ctx->strideR * 8)) return e;
+    if (int e = ensure(ctx, ctx->Vp, (size_t)Tp * L * 8)) return e;
+    if (int e = ensure(ctx, ctx->dp, (size_t)L * 8)) return e;
+    if (int e = ensure(ctx, ctx->Mvd, (size_t)ctx->nks_t * ctx->LT * 64 * 8)) return e;
+    const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
+    for (int p = 0; p < np; ++p) {
+        const int* perm = d_perm_idx ? d_perm_idx + (size_t)p * S : nullptr;
+        // full-sample arrangement: R_p, then V_p, d_p and M = V_p / d_p (= vd, fragment order)
+        if (int e = run_xprod(ctx, permute_x ? perm : nullptr, permute_x ? nullptr : perm, 1, st)) return e;
+        HIPCHK(hipMemcpyAsync(ctx->Rfull.p, ctx->R.p, (size_t)ctx->strideR * 8, hipMemcpyDeviceToDevice, st));
+        if (int e = run_gram(ctx, 1, false, st)) return e;
+        SmallArgs a = small_args(ctx, SMALL_DECOMP);
+        a.out_V = ptr<double>(ctx->Vp); a.out_d = ptr<double>(ctx->dp); a.Mfrag = ptr<double>(ctx->Mvd);
+        if (int e = run_small(ctx, a, 1, st)) return e;
+        for (int off = 0; off < ns; off += nb / 2) {
+            const int m = std::min(nb / 2, ns - off);            // splits in this pass
+            if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
+            if (int e = ensure(ctx, ctx->srcy, (size_t)2 * m * S * sizeof(int))) return e;
+            hipLaunchKernelGGL(k_split_src, dim3(ceil_div(S, 256), 2 * m), dim3(256), 0, st, perm,
+                               d_masks + ((size_t)p * ns + off) * S, m, S, permute_x,
+                               ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
+            LAUNCHCHK();
+            if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy), 2 * m, st))
+                return e;
+            // C_h = D_h . R_p^T  (T' x T')
+            if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
+            if (int e = run_gram_ex(ctx, 2 * m, 2, ptr<double>(ctx->Rfull), Tp, ptr<double>(ctx->Cm), st)) return e;
+            // feature-axis sums of E_h = D_h^T . vd
+            const int ntile = ceil_div(ctx->B, 16);
+            int nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
+            const int tpc = ceil_div(ntile, nchunk);
+            nchunk = ceil_div(ntile, tpc);
+            const int lpad = ctx->LT * 16;
+            if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
+            dim3 grid(nchunk, m), block(256);
+#define UC_ARGS ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mvd), ctx->B, tpc, \
+                ptr<double>(ctx->part2), m
+            switch (ctx->LT) {
+                case 1: hipLaunchKernelGGL(k_ucorr_partial<1>, grid, block, 0, st, UC_ARGS); break;
+                case 2: hipLaunchKernelGGL(k_ucorr_partial<2>, grid, block, 0, st, UC_ARGS); break;
+                case 3: hipLaunchKernelGGL(k_ucorr_partial<3>, grid, block, 0, st, UC_ARGS); break;
+                case 4: hipLaunchKernelGGL(k_ucorr_partial<4>, grid, block, 0, st, UC_ARGS); break;
+                case 5: hipLaunchKernelGGL(k_ucorr_partial<5>, grid, block, 0, st, UC_ARGS); break;
+                default: hipLaunchKernelGGL(k_ucorr_partial<6>, grid, block, 0, st, UC_ARGS); break;
+            }
+#undef UC_ARGS
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m, lpad,
+                               ptr<double>(ctx->Cm), ptr<double>(ctx->Vp), ptr<double>(ctx->dp), Tp, L, ctx->B,
+                               d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
+            LAUNCHCHK();
+        }
+    }
+    return PLSX_OK;
 }
 
 int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, const double* d_usq,

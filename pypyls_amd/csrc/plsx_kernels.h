@@ -482,12 +482,14 @@ void k_nt_gemm(NtArgs a)
 // P; it reads all four row tiles of R (shared with the other waves through
 // L1) plus row tile w of R / of U0^T as its B operands.
 // ---------------------------------------------------------------------------
-template <bool WITH_P>
+// MODE 0: G only; 1: G and P; 2: P only (cross-Gram against a shared matrix).
+template <int MODE>
 __global__ __launch_bounds__(256)
 void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
             const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
             double* __restrict__ part, int nres)
 {
+    constexpr bool WITH_P = (MODE != 0), WITH_G = (MODE != 2);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int chunk = blockIdx.x, r = blockIdx.y;
@@ -525,7 +527,7 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                accG[a] = mfma_f64(xa[a][s], xb[s], accG[a]);
+                if (WITH_G) accG[a] = mfma_f64(xa[a][s], xb[s], accG[a]);
                 if (WITH_P) accP[a] = mfma_f64(xa[a][s], ub[s], accP[a]);
             }
         }
@@ -550,7 +552,7 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                accG[a] = mfma_f64(ta[a][s], tb[s], accG[a]);
+                if (WITH_G) accG[a] = mfma_f64(ta[a][s], tb[s], accG[a]);
                 if (WITH_P) accP[a] = mfma_f64(ta[a][s], tu[s], accP[a]);
             }
     }
@@ -561,7 +563,7 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 16 * a + q + 4 * i, col = 16 * w + m;
-            out[row * 64 + col] = accG[a][i];
+            if (WITH_G) out[row * 64 + col] = accG[a][i];
             if (WITH_P) out[4096 + row * 64 + col] = accP[a][i];
         }
 }
@@ -714,9 +716,9 @@ void k_small(SmallArgs a)
     if (a.mode == SMALL_DECOMP) {
         for (int idx = tid; idx < n * L; idx += blockDim.x) {
             int t = idx / L, k = idx % L;
-            a.out_V[(size_t)t * L + k] = bufV[order[k] * ld + t];
+            a.out_V[(size_t)r * n * L + (size_t)t * L + k] = bufV[order[k] * ld + t];
         }
-        for (int k = tid; k < L; k += blockDim.x) a.out_d[k] = sqrt(lam[order[k]]);
+        for (int k = tid; k < L; k += blockDim.x) a.out_d[(size_t)r * L + k] = sqrt(lam[order[k]]);
         // M = V diag(1/d) for live LVs (zero otherwise): U = R^T . M
         const int tot = a.nks_t * a.LT * 64;
         for (int idx = tid; idx < tot; idx += blockDim.x) {
@@ -925,6 +927,136 @@ __global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n * S) dst[i] = i % S;
+}
+
+// ---------------------------------------------------------------------------
+// split-half (BasePLS.split_half, pyls/base.py:714-770)
+// ---------------------------------------------------------------------------
+
+// Source-row tables of the 2*ns half samples of ONE arrangement:
+// slot 2*i + h keeps the positions whose mask equals (h == 0); behavioral PLS
+// permutes Y (ysrc = perm), mean-centred PLS permutes X (xsrc = perm).
+__global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restrict__ masks,
+                            int ns, int S, int permute_x, int* __restrict__ xsrc, int* __restrict__ ysrc)
+{
+    const int slot = blockIdx.y;
+    const int i = slot >> 1, h = slot & 1;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < S; p += gridDim.x * blockDim.x) {
+        const bool keep = (masks[(size_t)i * S + p] != 0) == (h == 0);
+        const int src = perm ? perm[p] : p;
+        xsrc[(size_t)slot * S + p] = keep ? (permute_x ? src : p) : -1;
+        ysrc[(size_t)slot * S + p] = permute_x ? p : src;
+    }
+}
+
+// E_h = D_h^T . M (M = V / d, fragment order) for the two halves of split
+// `pair` over one chunk of feature columns; accumulates per LV the five sums
+// (S1, S2, S11, S22, S12) over features needed for the Pearson correlation of
+// the projected left singular vectors (efficient_corr(D1.T @ vd, D2.T @ vd),
+// base.py:766).  grid (nchunk, npairs), 4 waves, partial sums per block.
+template <int LT>
+__global__ __launch_bounds__(256)
+void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
+                     const double* __restrict__ Mfrag, int B, int tiles_per_chunk,
+                     double* __restrict__ part /* [nchunk][npairs][5][LT*16] */, int npairs)
+{
+    __shared__ double red[4][5][LT * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, pair = blockIdx.y;
+    const double* R1 = R + (size_t)(2 * pair) * strideR;
+    const double* R2 = R1 + strideR;
+    double s1[LT], s2[LT], s11[LT], s22[LT], s12[LT];
+#pragma unroll
+    for (int l = 0; l < LT; ++l) s1[l] = s2[l] = s11[l] = s22[l] = s12[l] = 0.0;
+    const int ntile = (B + 15) / 16;
+    const int t0 = chunk * tiles_per_chunk, t1 = min(ntile, t0 + tiles_per_chunk);
+    for (int tile = t0 + wave; tile < t1; tile += 4) {
+        const int b0 = tile * 16;
+        d4 e1[LT], e2[LT];
+#pragma unroll
+        for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
+        const size_t off = (size_t)(lane >> 4) * ldr + b0 + (lane & 15);
+        for (int ks = 0; ks < nks_t; ++ks) {
+            const double a1 = R1[off + (size_t)ks * 4 * ldr];
+            const double a2 = R2[off + (size_t)ks * 4 * ldr];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                const double mv = Mfrag[((size_t)ks * LT + l) * 64 + lane];
+                e1[l] = mfma_f64(a1, mv, e1[l]);
+                e2[l] = mfma_f64(a2, mv, e2[l]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < LT; ++l)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (b0 + (lane >> 4) + 4 * i) < B;      // feature rows only
+                const double x = ok ? e1[l][i] : 0.0, y = ok ? e2[l][i] : 0.0;
+                s1[l] += x; s2[l] += y; s11[l] += x * x; s22[l] += y * y; s12[l] += x * y;
+            }
+    }
+    // reduce over the four row groups of the wave (lanes l, l+16, l+32, l+48)
+#pragma unroll
+    for (int l = 0; l < LT; ++l) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            s1[l] += __shfl_xor(s1[l], o); s2[l] += __shfl_xor(s2[l], o);
+            s11[l] += __shfl_xor(s11[l], o); s22[l] += __shfl_xor(s22[l], o);
+            s12[l] += __shfl_xor(s12[l], o);
+        }
+        if (lane < 16) {
+            red[wave][0][l * 16 + lane] = s1[l]; red[wave][1][l * 16 + lane] = s2[l];
+            red[wave][2][l * 16 + lane] = s11[l]; red[wave][3][l * 16 + lane] = s22[l];
+            red[wave][4][l * 16 + lane] = s12[l];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 5 * LT * 16; idx += blockDim.x) {
+        const int k = idx / (LT * 16), c = idx % (LT * 16);
+        part[(((size_t)chunk * npairs + pair) * 5 + k) * (LT * 16) + c] =
+            red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    }
+}
+
+// Final split-half correlations of one split (block = pair):
+//   ucorr[l] from the feature-axis sums; vcorr[l] = Pearson over the T' rows of
+//   F_h = C_h . (V d^-2) with C_h = D_h . R_full^T  (= D_h @ ud, base.py:767).
+__global__ void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int lpad,
+                              const double* __restrict__ C /* [2*npairs][n][n] */,
+                              const double* __restrict__ V /* n x L */, const double* __restrict__ d,
+                              int n, int L, int B, double* __restrict__ ucorr, double* __restrict__ vcorr)
+{
+    const int pair = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < nchunk; ++c)
+            for (int k = 0; k < 5; ++k) s[k] += part[(((size_t)c * npairs + pair) * 5 + k) * lpad + l];
+        const double nb = (double)B;
+        const double cov = s[4] - s[0] * s[1] / nb;
+        const double v1 = s[2] - s[0] * s[0] / nb, v2 = s[3] - s[1] * s[1] / nb;
+        double rr = cov / sqrt(v1 * v2);
+        ucorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);   // NaN stays NaN
+        // vcorr
+        const double* C1 = C + (size_t)(2 * pair) * n * n;
+        const double* C2 = C1 + (size_t)n * n;
+        const double inv = 1.0 / (d[l] * d[l]);
+        double f1s = 0, f2s = 0, f11 = 0, f22 = 0, f12 = 0;
+        for (int t = 0; t < n; ++t) {
+            double f1 = 0, f2 = 0;
+            for (int u = 0; u < n; ++u) {
+                const double vv = V[(size_t)u * L + l];
+                f1 += C1[(size_t)t * n + u] * vv;
+                f2 += C2[(size_t)t * n + u] * vv;
+            }
+            f1 *= inv; f2 *= inv;
+            f1s += f1; f2s += f2; f11 += f1 * f1; f22 += f2 * f2; f12 += f1 * f2;
+        }
+        const double nn = (double)n;
+        const double cv = f12 - f1s * f2s / nn;
+        const double w1 = f11 - f1s * f1s / nn, w2 = f22 - f2s * f2s / nn;
+        rr = cv / sqrt(w1 * w2);
+        vcorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);
+    }
 }
 
 // fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave,

@@ -56,7 +56,7 @@ def _load():
         'plsx_colmean': ([vp, vp, vp], i32),
         'plsx_perm_batch': ([vp, vp, i32, i32, vp, vp], i32),
         'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
-        'plsx_split_half_batch': ([vp, vp, vp, i32, vp, vp, vp, vp, vp], i32),
+        'plsx_split_half_batch': ([vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
@@ -240,6 +240,31 @@ class Engine(object):
                                              usq.data_ptr(), dist.data_ptr(), self._stream()))
         self.sync()
         return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
+
+    def split_half(self, masks, perms=None):
+        """Per-split correlations.  masks (np, S, ns) bool: one (S, ns) gen_splits
+        array per arrangement; perms (S, np) index array or None (original data).
+        Returns ucorr, vcorr of shape (np, L, ns)."""
+        torch = _torch()
+        masks = np.asarray(masks)
+        if masks.ndim == 2:
+            masks = masks[None]
+        n_arr, S, ns = masks.shape
+        if S != self.S:
+            raise ValueError('split masks must have S = {} rows'.format(self.S))
+        dm = torch.from_numpy(np.ascontiguousarray(masks.transpose(0, 2, 1), dtype=np.uint8)).to(self.device)
+        dp = None
+        if perms is not None:
+            dp = self._index_rows(perms)
+            if dp.shape[0] != n_arr:
+                raise ValueError('need one permutation per arrangement')
+        uc, vc = self._empty((n_arr, ns, self.L)), self._empty((n_arr, ns, self.L))
+        self._check(self.lib.plsx_split_half_batch(
+            self.ctx, None if dp is None else dp.data_ptr(), n_arr, dm.data_ptr(), ns,
+            uc.data_ptr(), vc.data_ptr(), self._stream()))
+        self.sync()
+        return (np.ascontiguousarray(uc.cpu().numpy().transpose(0, 2, 1)),
+                np.ascontiguousarray(vc.cpu().numpy().transpose(0, 2, 1)))
 
     # -- device-resident variants (no host copies, no sync): bench / pipelines --
     def index_tensor(self, samples):

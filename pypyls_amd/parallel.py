@@ -40,10 +40,10 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _flat_layout(L, Tp, B, n_perm, n_boot, world, with_boot):
+def _flat_layout(Lp, Tp, L, B, n_perm, n_boot, world, with_boot):
     pmax = shard_bounds(n_perm, 0, world)[1] if n_perm else 0
     rmax = shard_bounds(n_boot, 0, world)[1] if n_boot else 0
-    sizes = dict(perm=L * pmax, dist=Tp * L * rmax,
+    sizes = dict(perm=Lp * pmax, dist=Tp * L * rmax,
                  usum=B * L if with_boot else 0, usq=B * L if with_boot else 0)
     return pmax, rmax, sizes
 
@@ -61,16 +61,18 @@ def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
     with_boot = usum is not None
     device = usum.device if with_boot else torch.device(
         'cuda', torch.cuda.current_device()) if d.get_backend() == 'nccl' else torch.device('cpu')
-    L = local_perm.shape[0] if local_perm is not None else local_dist.shape[1]
+    # the permutation block may carry extra rows (split-half nulls ride along)
+    Lp = local_perm.shape[0] if local_perm is not None else 0
+    L = local_dist.shape[1] if local_dist is not None else (usum.shape[1] if with_boot else 0)
     Tp = local_dist.shape[0] if local_dist is not None else 0
     B = usum.shape[0] if with_boot else 0
-    pmax, rmax, sizes = _flat_layout(L, Tp, B, n_perm if local_perm is not None else 0,
+    pmax, rmax, sizes = _flat_layout(Lp, Tp, L, B, n_perm if local_perm is not None else 0,
                                      n_boot if local_dist is not None else 0, world, with_boot)
     total = sum(sizes.values())
     flat = torch.zeros(total, dtype=torch.float64, device=device)
     off = 0
     if sizes['perm']:
-        blk = np.zeros((L, pmax))
+        blk = np.zeros((Lp, pmax))
         blk[:, :local_perm.shape[1]] = local_perm
         flat[off:off + sizes['perm']] = torch.from_numpy(blk.ravel()).to(device)
     off += sizes['perm']
@@ -89,7 +91,7 @@ def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
     perm = dist_out = None
     off = 0
     if sizes['perm']:
-        host = gathered[:, off:off + sizes['perm']].cpu().numpy().reshape(world, L, pmax)
+        host = gathered[:, off:off + sizes['perm']].cpu().numpy().reshape(world, Lp, pmax)
         perm = np.concatenate([host[r][:, :np.diff(shard_bounds(n_perm, r, world))[0]]
                                for r in range(world)], axis=1)
     off += sizes['perm']

@@ -106,10 +106,18 @@ class _PLSCRun(object):
                 raise NotImplementedError(
                     'pre-permuted Y stacks (permindices=False, pyls/base.py:636-639) are not '
                     'supported by the device path yet')
-            if inp.get('n_split') is not None:
-                raise NotImplementedError('split-half resampling (n_split) is not available on '
-                                          'the device path in this build')
             permsamp = np.asarray(permsamp)
+        n_split = inp.get('n_split')
+        orig_splits = None
+        if permsamp is not None and n_split is not None:
+            # the reference draws the split masks of the ORIGINAL data from
+            # self.rs after the permutation arrays and before the bootstrap
+            # arrays (base.py:373-380); permutation i uses a fresh
+            # RandomState(i) (base.py:705-708, 738-742)
+            orig_splits = inp.get('_splitsamples')
+            if orig_splits is None:
+                orig_splits = resampling.gen_splits(inp.groups, inp.n_cond, n_split, seed=self.rs,
+                                                    test_size=0.5)
         if n_boot > 0:
             # BasePLS.bootstrap, base.py:439-528 (index arrays drawn AFTER the
             # permutation arrays, as in the reference's run_pls order)
@@ -129,9 +137,39 @@ class _PLSCRun(object):
             else:
                 usum, usq = eng._zeros((eng.B, L)), eng._zeros((eng.B, L))
                 local_dist = np.zeros((eng.Tp, L, 0))
+        local_uc = local_vc = None
+        if orig_splits is not None:
+            lo, hi = parallel.shard_bounds(permsamp.shape[1], rank, world)
+            pmasks = inp.get('_perm_splitsamples')
+            if pmasks is None:
+                pmasks = np.stack([resampling.gen_splits(inp.groups, inp.n_cond, n_split, seed=i,
+                                                         test_size=0.5) for i in range(lo, hi)]) \
+                    if hi > lo else np.zeros((0, len(X), n_split), bool)
+            else:
+                pmasks = np.asarray(pmasks)[lo:hi]
+            if hi > lo:
+                uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi])
+                local_uc, local_vc = uc.mean(axis=-1).T, vc.mean(axis=-1).T      # (L, p_loc)
+            else:
+                local_uc = local_vc = np.zeros((L, 0))
+            # ride along with the permutation block of the single collective
+            local_perm = np.vstack([local_perm, local_uc, local_vc])
         d_perm, distrib, usum, usq = parallel.collect(
             local_perm, permsamp.shape[1] if permsamp is not None else 0,
             local_dist, bootsamp.shape[1] if bootsamp is not None else 0, usum, usq)
+        if orig_splits is not None:
+            d_perm, ucorrs, vcorrs = d_perm[:L], d_perm[L:2 * L], d_perm[2 * L:]
+            uc, vc = eng.split_half(orig_splits)
+            orig_uc, orig_vc = uc[0].mean(axis=-1), vc[0].mean(axis=-1)
+            ci = inp.get('ci', 95)
+            ull, uul = hostmath.boot_ci(ucorrs, ci=ci)
+            vll, vul = hostmath.boot_ci(vcorrs, ci=ci)
+            res['splitres'].update(dict(
+                ucorr=orig_uc, vcorr=orig_vc,
+                ucorr_pvals=hostmath.perm_sig(orig_uc, ucorrs),
+                vcorr_pvals=hostmath.perm_sig(orig_vc, vcorrs),
+                ucorr_lolim=ull, vcorr_lolim=vll, ucorr_uplim=uul, vcorr_uplim=vul))
+            self.split_null = (ucorrs, vcorrs)
         if permsamp is not None:
             res['permres']['pvals'] = hostmath.perm_sig(sv, d_perm)
             res['permres']['permsamples'] = permsamp

@@ -91,6 +91,8 @@ class PLSInputs(KeyedRecord):
         'test_split', 'test_size', 'mean_centering', 'covariance', 'rotate',
         'ci', 'seed', 'verbose', 'n_proc', 'bootsamples', 'permsamples',
         'method', 'n_components', 'aggfunc', 'permindices',
+        # build-only knobs (filtered like any other key): pre-drawn split masks, engine
+        '_splitsamples', '_perm_splitsamples', '_engine',
     )
 
     def __init__(self, **kwargs):

@@ -21,9 +21,14 @@ def _run(g, method, with_samples=True, **extra):
     n_perm = g['ref_permres__perm_singval'].shape[1] if 'ref_permres__perm_singval' in g else 0
     n_boot = g['ref_bootres__bootsamples'].shape[1] if 'ref_bootres__bootsamples' in g else 0
     kw.update(n_perm=n_perm, n_boot=n_boot)
+    if 'n_split' in g:
+        kw['n_split'] = int(g['n_split'])
     if with_samples:
         kw['permsamples'] = g.get('ref_permres__permsamples')
         kw['bootsamples'] = g.get('ref_bootres__bootsamples')
+        if 'splitsamples' in g:          # the very masks the reference drew
+            kw['_splitsamples'] = g['splitsamples']
+            kw['_perm_splitsamples'] = g['perm_splitsamples']
     kw.update(extra)
     if method == 'behavioral':
         return pls.behavioral_pls(g['X'], g['Y'], covariance=bool(g.get('covariance', False)),
@@ -37,7 +42,9 @@ def _oracle(g, method):
                         rotate=bool(g.get('rotate', True)),
                         mean_centering=int(g.get('mean_centering', 0)),
                         permsamples=g.get('ref_permres__permsamples'),
-                        bootsamples=g.get('ref_bootres__bootsamples'))
+                        bootsamples=g.get('ref_bootres__bootsamples'),
+                        splitsamples=g.get('splitsamples'),
+                        perm_splitsamples=g.get('perm_splitsamples'))
 
 
 def _boots_full_rank(g):
@@ -75,22 +82,31 @@ def _compare(res, g, want, keep, boot_tight):
                     assert np.all(r >= 0.9), (k, r)
 
 
+def _compare_split(res, want, keep):
+    if not want.get('splitres'):
+        return
+    for k in ('ucorr', 'vcorr', 'ucorr_lolim', 'ucorr_uplim', 'vcorr_lolim', 'vcorr_uplim'):
+        assert_close(res['splitres'][k][keep], want['splitres'][k][keep], RTOL, what='splitres.' + k)
+    for k in ('ucorr_pvals', 'vcorr_pvals'):
+        np.testing.assert_allclose(res['splitres'][k][keep], want['splitres'][k][keep], atol=1e-12)
+
+
 def _ref_as_dict(g):
-    out = dict(permres={}, bootres={})
+    out = dict(permres={}, bootres={}, splitres={})
     for k, v in g.items():
         if k.startswith('ref_permres__'):
             out['permres'][k[13:]] = v
         elif k.startswith('ref_bootres__'):
             out['bootres'][k[13:]] = v
+        elif k.startswith('ref_splitres__'):
+            out['splitres'][k[14:]] = v
         elif k.startswith('ref_') and '__' not in k:
             out[k[4:]] = v
     return out
 
 
-BEHAV = [n for n in golden_names('bpls_') if 'split' not in n] + ['linnerud'] + \
-    [n for n in golden_names('mat_bpls') if 'nosplit' in n]
-MEANC = [n for n in golden_names('mpls_') if 'split' not in n] + \
-    [n for n in golden_names('mat_mpls') if 'nosplit' in n]
+BEHAV = golden_names('bpls_') + ['linnerud'] + golden_names('mat_bpls')
+MEANC = golden_names('mpls_') + golden_names('mat_mpls')
 
 
 @pytest.mark.parametrize('name', BEHAV)
@@ -100,6 +116,8 @@ def test_behavioral_vs_reference_and_oracle(name):
     keep = live_lvs(g['ref_singvals'])
     # (b) oracle: same algorithmic conventions -> tight everywhere
     _compare(res, g, _oracle(g, 'behavioral'), keep, boot_tight=True)
+    _compare_split(res, _oracle(g, 'behavioral'), keep)
+    _compare_split(res, _ref_as_dict(g), keep)
     # (a) the reference's own numbers; rank-deficient bootstrap rotations of the
     # reference are noise-defined (oracle.procrustes_live) -> functional check
     _compare(res, g, _ref_as_dict(g), keep, boot_tight=_boots_full_rank(g) and bool(np.all(keep)))
@@ -111,6 +129,8 @@ def test_meancentered_vs_reference_and_oracle(name):
     res = _run(g, 'meancentered')
     keep = live_lvs(g['ref_singvals'])
     _compare(res, g, _oracle(g, 'meancentered'), keep, boot_tight=True)
+    _compare_split(res, _oracle(g, 'meancentered'), keep)
+    _compare_split(res, _ref_as_dict(g), keep)
     _compare(res, g, _ref_as_dict(g), keep, boot_tight=False)
 
 

@@ -127,3 +127,67 @@ def test_meancentered(mc):
         wd.append(dd)
     assert_close(usum.cpu().numpy()[:, live], ws[:, live], 1e-7, what='u_sum')
     assert_close(dist[:, live], np.stack(wd, -1)[:, live], 1e-7, what='distrib')
+
+
+@pytest.mark.parametrize('case', [
+    dict(S=40, B=300, T=6, groups=[40], n_cond=1),
+    dict(S=46, B=130, T=4, groups=[11, 12], n_cond=2),
+    dict(S=36, B=70, T=5, groups=[12], n_cond=3, covariance=True),
+])
+def test_split_half_behavioral(case):
+    case = dict(case)
+    cov = case.pop('covariance', False)
+    X, Y, rs = _data(case['S'], case['B'], case['T'], seed=7)
+    eng = _engine()
+    spec = _setup(eng, X, Y, case['groups'], case['n_cond'], covariance=cov)
+    from pypyls_amd import resampling as rsmp
+    ns = 5
+    # original arrangement
+    masks = rsmp.gen_splits(case['groups'], case['n_cond'], ns, seed=3)
+    U, d, V = ref.decompose(spec, X, Y)
+    di = np.linalg.inv(d)
+    want_u = np.zeros((U.shape[1], ns))
+    want_v = np.zeros((U.shape[1], ns))
+    for i in range(ns):
+        u, v = ref.split_half(spec, X, Y, U @ di, V @ di, masks[:, [i]])
+        want_u[:, i], want_v[:, i] = u, v
+    uc, vc = eng.split_half(masks)
+    assert_close(uc[0], want_u, 1e-7, what='ucorr original')
+    assert_close(vc[0], want_v, 1e-7, what='vcorr original')
+    # permuted arrangements, each with its own masks
+    perms = rsmp.gen_permsamp(case['groups'], case['n_cond'], 3, seed=1)
+    pm = np.stack([rsmp.gen_splits(case['groups'], case['n_cond'], ns, seed=10 + i) for i in range(3)])
+    uc, vc = eng.split_half(pm, perms=perms)
+    for p in range(3):
+        Xp, Yp = ref.make_permutation(spec, X, Y, perms[:, p])
+        U, d, V = ref.decompose(spec, Xp, Yp)
+        di = np.linalg.inv(d)
+        for i in range(ns):
+            u, v = ref.split_half(spec, Xp, Yp, U @ di, V @ di, pm[p][:, [i]])
+            assert_close(uc[p][:, i], u, 1e-7, what='ucorr perm')
+            assert_close(vc[p][:, i], v, 1e-7, what='vcorr perm')
+
+
+def test_split_half_meancentered():
+    rs = np.random.RandomState(5)
+    groups, n_cond = [11, 13], 2
+    X = rs.randn(48, 300)
+    X[:20] += 0.7
+    eng = _engine()
+    spec = _setup(eng, X, None, groups, n_cond, method='meancentered', mc=0)
+    from pypyls_amd import resampling as rsmp
+    Y = spec.dummy.astype(float)
+    ns = 4
+    perms = rsmp.gen_permsamp(groups, n_cond, 2, seed=1)
+    pm = np.stack([rsmp.gen_splits(groups, n_cond, ns, seed=20 + i) for i in range(2)])
+    uc, vc = eng.split_half(pm, perms=perms)
+    for p in range(2):
+        Xp, Yp = ref.make_permutation(spec, X, Y, perms[:, p])
+        U, d, V = ref.decompose(spec, Xp, Yp)
+        live = ref.live_lvs(d)
+        dl = np.diag(d)[live]
+        ud, vd = U[:, live] / dl, V[:, live] / dl
+        for i in range(ns):
+            u, v = ref.split_half(spec, Xp, Yp, ud, vd, pm[p][:, [i]])
+            assert_close(uc[p][live, i], u, 1e-7, what='ucorr')
+            assert_close(vc[p][live, i], v, 1e-7, what='vcorr')

@@ -41,7 +41,9 @@ enum plsx_status {
 
 enum plsx_method {
     PLSX_BEHAVIORAL = 0,     /* pyls/types/behavioral.py  (R = stacked per-cell xcorr)   */
-    PLSX_MEANCENTERED = 1    /* pyls/types/meancentered.py (R = cell means - ref. mean)  */
+    PLSX_MEANCENTERED = 1,   /* pyls/types/meancentered.py (R = cell means - ref. mean)  */
+    PLSX_REGRESSION = 2      /* pyls/types/regression.py (SIMPLS); plsx_set_data takes
+                                globally centred X / Y, n_groups = 1 and n_cond = n_components */
 };
 
 /* flags for plsx_set_data */
@@ -154,6 +156,29 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np,
                           const uint8_t* d_masks, int ns,
                           double* d_ucorr, double* d_vcorr, void* stream);
+
+/*
+ * SIMPLS regression (pyls/types/regression.py:56-186, 248-373), solved per
+ * resample in the S-dimensional dual space (K = X0 X0^T); k = n_components.
+ *   plsx_simpls_decompose   original data: d_xwT (k, B) x_weights transposed,
+ *                           d_pctvar (k,) variance of Y explained, d_cvec (T, k)
+ *                           right singular vectors (sign rule input),
+ *                           d_yload (T, k) = Y^T (X W)
+ *   plsx_simpls_set_original  d_w0cT (k, B): column-centred original x_weights,
+ *                           transposed -- sign reference of the bootstrap
+ *                           (regression.py:317-320)
+ *   plsx_simpls_perm_batch  PLSRegression._single_perm (regression.py:329-373):
+ *                           d_perm_idx (n, S) permutes Y; d_out (n, k) pctvar of Y
+ *   plsx_simpls_boot_batch  PLSRegression._single_boot (regression.py:279-327):
+ *                           d_usum/d_usq (B, k) += sign-aligned x_weights (and
+ *                           squares); d_yload (n, T, k) = Yi^T (Xi W)
+ */
+int plsx_simpls_decompose(plsx_ctx* ctx, double* d_xwT, double* d_pctvar, double* d_cvec,
+                          double* d_yload, void* stream);
+int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream);
+int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, double* d_out, void* stream);
+int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum,
+                           double* d_usq, double* d_yload, void* stream);
 
 /* Bootstrap ratios -- compute.boot_rel (pyls/compute.py:212-237), elementwise
  * on (B, L) arrays: se = sqrt(|usq - usum^2/n| / (n-1)), bsr = orig / se.

@@ -15,3 +15,4 @@ from .structures import (PLSInputs, PLSResults, PLSBootResults, PLSPermResults, 
 from .resampling import (gen_permsamp, gen_bootsamp, gen_splits, dummy_code,  # noqa: F401
                          dummy_label, permute_cols)
 from .plsc import behavioral_pls, meancentered_pls  # noqa: F401
+from .regression import pls_regression  # noqa: F401

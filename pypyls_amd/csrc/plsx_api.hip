@@ -1,6 +1,7 @@
 // plsx_api.hip -- host side of libplsx.so: context, planning, kernel launches.
 // C ABI declared in include/plsx.h.  gfx950 only.
 #include "plsx_kernels.h"
+#include "plsx_simpls.h"
 #include "../../include/plsx.h"
 
 #include <algorithm>
@@ -36,6 +37,8 @@ struct plsx_ctx {
     Buf Xc, xmean, Y, cell_of_row, cell_start, cell_len, out_row, mom_idx, mom_n;
     Buf Afrag, R, Gm, Pm, part, Mfrag, U0T, V0, d0, tmpW;
     Buf Rfull, Vp, dp, Mvd, Cm, srcx, srcy, part2;     // split-half scratch
+    Buf Kmat, swork, spct, sc;                          // SIMPLS: K = Xc Xc^T, dual-solver scratch
+    int ncomp = 0;
     // timing of the cross-product kernel
     int timing = 0;
     int variant = 0;        // cross-product kernel variant (PLSX_XPROD_VARIANT, tuning only)
@@ -95,7 +98,7 @@ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // Choose resamples per group so that data + moment tiles fill MT tiles.
 void plan_groups(plsx_ctx* c)
 {
-    c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;
+    c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;   // mean-centred / regression: no feature scaling
     const int Jw = c->scaled ? c->J : 0;
     int best = 1;
     for (int n = 1; n <= 512; ++n) {
@@ -222,15 +225,19 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 // Build the A operands of `nres` resamples and run the cross-product kernel:
 // afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
 // [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
-int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st)
+int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
+              bool prebuilt = false)
 {
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
+    if (prebuilt) return launch_xprod(ctx, groups, st);       // A already scattered by the caller
     HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
     GroupLayout lay;
     lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT;
     lay.w0 = ctx->w0; lay.sq0 = ctx->sq0; lay.Tpp = ctx->Tpp;
-    if (ctx->method == PLSX_BEHAVIORAL) {
+    if (ctx->method == PLSX_REGRESSION) {
+        // A (dual weights) was scattered by k_simpls_dual; nothing to build here
+    } else if (ctx->method == PLSX_BEHAVIORAL) {
         dim3 grid(nres, ctx->J), block(256);
         const size_t lds = (size_t)2 * ctx->T * 8;
         hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ptr<double>(ctx->Y), ctx->T, ctx->S,
@@ -422,7 +429,8 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
     for (Buf* b : {&ctx->Xc, &ctx->xmean, &ctx->Y, &ctx->cell_of_row, &ctx->cell_start, &ctx->cell_len,
                    &ctx->out_row, &ctx->mom_idx, &ctx->mom_n, &ctx->Afrag, &ctx->R, &ctx->Gm, &ctx->Pm,
                    &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW,
-                   &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2})
+                   &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
+                   &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -451,14 +459,23 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     HIPCHK(hipSetDevice(ctx->device));
     if (!d_X || !d_cell_of_row || S < 2 || B < 1 || n_groups < 1 || n_cond < 1)
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: bad shape or null pointer");
-    if (method != PLSX_BEHAVIORAL && method != PLSX_MEANCENTERED)
+    if (method != PLSX_BEHAVIORAL && method != PLSX_MEANCENTERED && method != PLSX_REGRESSION)
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: unknown method");
-    if (method == PLSX_BEHAVIORAL && (!d_Y || T < 1))
-        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: behavioral PLS needs Y");
+    if (method != PLSX_MEANCENTERED && (!d_Y || T < 1))
+        return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: this method needs Y");
+    // PLSX_REGRESSION: n_cond carries n_components (rows of x_weights^T per resample)
+    const int ncomp = (method == PLSX_REGRESSION) ? n_cond : 0;
+    if (method == PLSX_REGRESSION) {
+        if (ncomp < 1 || ncomp > std::min(S - 1, B))
+            return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: n_components out of range");
+        n_groups = 1; n_cond = 1;
+    }
     if (mean_centering < 0 || mean_centering > 2)
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: mean_centering must be 0, 1 or 2");
     const int J = n_groups * n_cond;
-    const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : J;
+    const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
+    if (method == PLSX_REGRESSION && T > 64)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS on the device supports at most 64 Y columns");
     if (Tp > PLSX_MAX_TP) {
         char msg[160];
         snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the on-chip solver limit %d", Tp,
@@ -467,7 +484,8 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     }
     ctx->has_data = ctx->has_orig = false;
     ctx->Galloc = 0;
-    ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_BEHAVIORAL) ? T : 0;
+    ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_MEANCENTERED) ? 0 : T;
+    ctx->ncomp = ncomp;
     ctx->J = J; ctx->n_groups = n_groups; ctx->n_cond = n_cond; ctx->mc = mean_centering;
     ctx->cov = (flags & PLSX_FLAG_COVARIANCE) ? 1 : 0;
     ctx->Tp = Tp; ctx->Tpp = round_up(Tp, 4); ctx->L = std::min(Tp, B);
@@ -510,7 +528,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     hipLaunchKernelGGL(k_center_pad, dim3(ceil_div(B, 256), S), dim3(256), 0, st, d_X,
                        ptr<double>(ctx->xmean), S, B, ptr<double>(ctx->Xc), ctx->Bpad);
     LAUNCHCHK();
-    if (method == PLSX_BEHAVIORAL) {
+    if (method != PLSX_MEANCENTERED) {
         if (int e = ensure(ctx, ctx->Y, (size_t)S * T * 8)) return e;
         HIPCHK(hipMemcpyAsync(ctx->Y.p, d_Y, (size_t)S * T * 8, hipMemcpyDeviceToDevice, st));
     }
@@ -519,6 +537,13 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
     if (int e = ensure(ctx, ctx->d0, (size_t)ctx->L * 8)) return e;
+    if (method == PLSX_REGRESSION) {
+        // K = Xc Xc^T (S x S): the only B-sized work the dual-space SIMPLS solver needs
+        if (int e = ensure(ctx, ctx->Kmat, (size_t)S * S * 8)) return e;
+        if (int e = run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, S, ptr<double>(ctx->Xc), 0, ctx->Bpad, S,
+                           nullptr, 0, 0, 0, B, 1, ptr<double>(ctx->Kmat), 0, S, nullptr, 0, 0, st))
+            return e;
+    }
     HIPCHK(hipStreamSynchronize(st));
     ctx->has_data = true;
     return PLSX_OK;
@@ -720,6 +745,125 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
                                d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
             LAUNCHCHK();
         }
+    }
+    return PLSX_OK;
+}
+
+// ---- SIMPLS regression (pyls/types/regression.py) ---------------------------
+namespace {
+int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, bool scatter,
+                    double* pctvar, double* yload, double* cvec, hipStream_t st)
+{
+    const int S = ctx->S, T = ctx->T, k = ctx->ncomp;
+    const int groups = ceil_div(nres, ctx->npg);
+    if (int e = ensure_scratch(ctx, groups)) return e;
+    SimplsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.S = S; a.T = T; a.k = k;
+    a.K = ptr<double>(ctx->Kmat); a.Yc = ptr<double>(ctx->Y);
+    a.xsrc = xsrc; a.ysrc = ysrc;
+    a.work_stride = (size_t)S * (3 * T + 4 * k + 4);
+    if (int e = ensure(ctx, ctx->swork, (size_t)nres * a.work_stride * 8)) return e;
+    a.work = ptr<double>(ctx->swork);
+    a.pctvar = pctvar; a.yload = yload; a.cvec = cvec;
+    if (scatter) {
+        HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
+        a.Afrag = ptr<double>(ctx->Afrag); a.group_stride = ctx->group_stride;
+        a.lay.n = ctx->npg; a.lay.Tp = ctx->Tp; a.lay.J = 1; a.lay.T = T; a.lay.MT = ctx->MT;
+        a.lay.w0 = ctx->w0; a.lay.sq0 = ctx->sq0; a.lay.Tpp = ctx->Tpp;
+    }
+    const int ldh = T | 1;
+    const size_t lds = ((size_t)S + 3 * (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)2 * S * 4 + 64;
+    if (lds > 160 * 1024) return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS: S / T too large for the on-chip solver");
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_simpls_dual),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_simpls_dual, dim3(nres), dim3(512), lds, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+}  // namespace
+
+int plsx_simpls_decompose(plsx_ctx* ctx, double* d_xwT, double* d_pctvar, double* d_cvec, double* d_yload,
+                          void* stream)
+{
+    NEED_DATA();
+    if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
+    if (!d_xwT || !d_pctvar || !d_cvec || !d_yload) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_decompose: null output");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int e = run_simpls_dual(ctx, nullptr, nullptr, 1, true, d_pctvar, d_yload, d_cvec, st)) return e;
+    if (int e = run_xprod(ctx, nullptr, nullptr, 1, st, true)) return e;
+    hipLaunchKernelGGL(k_gather_cols, dim3(ceil_div(ctx->Tp * ctx->B, 256), 1), dim3(256), 0, st,
+                       ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, 0, ctx->Tp, ctx->B, d_xwT);
+    LAUNCHCHK();
+    return PLSX_OK;
+}
+
+int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream)
+{
+    NEED_DATA();
+    if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
+    if (!d_w0cT) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_set_original: null input");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(ctx->U0T.p, 0, (size_t)ctx->L * ctx->Bpad * 8, st));
+    HIPCHK(hipMemcpy2DAsync(ctx->U0T.p, (size_t)ctx->Bpad * 8, d_w0cT, (size_t)ctx->B * 8, (size_t)ctx->B * 8,
+                            ctx->ncomp, hipMemcpyDeviceToDevice, st));
+    ctx->has_orig = true;
+    return PLSX_OK;
+}
+
+int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, double* d_out, void* stream)
+{
+    NEED_DATA();
+    if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
+    if (!d_perm_idx || !d_out || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_perm_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = 2048;
+    if (int e = ensure(ctx, ctx->spct, (size_t)nb * ctx->T * ctx->ncomp * 8)) return e;
+    if (int e = ensure(ctx, ctx->sc, (size_t)nb * ctx->T * ctx->ncomp * 8)) return e;
+    for (int off = 0; off < n; off += nb) {
+        const int m = std::min(nb, n - off);
+        // Y is permuted, X is not (BasePLS.make_permutation, base.py:599)
+        if (int e = run_simpls_dual(ctx, nullptr, d_perm_idx + (size_t)off * ctx->S, m, false,
+                                    d_out + (size_t)off * ctx->ncomp, ptr<double>(ctx->spct),
+                                    ptr<double>(ctx->sc), st))
+            return e;
+    }
+    return PLSX_OK;
+}
+
+int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
+                           double* d_yload, void* stream)
+{
+    NEED_ORIG();
+    if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
+    if (!d_boot_idx || !d_usum || !d_usq || !d_yload || n < 1)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_boot_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int k = ctx->ncomp, T = ctx->T;
+    const int nb = ctx->Gcap * ctx->npg;
+    if (int e = ensure(ctx, ctx->spct, (size_t)nb * k * 8)) return e;
+    if (int e = ensure(ctx, ctx->sc, (size_t)nb * T * k * 8)) return e;
+    for (int off = 0; off < n; off += nb) {
+        const int m = std::min(nb, n - off);
+        const int* idx = d_boot_idx + (size_t)off * ctx->S;
+        double* yl = d_yload + (size_t)off * T * k;
+        if (int e = run_simpls_dual(ctx, idx, idx, m, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st))
+            return e;
+        if (int e = run_xprod(ctx, idx, idx, m, st, true)) return e;          // R_r = W_r^T (k x B)
+        // sign alignment against the (centred) original weights
+        if (int e = run_gram_ex(ctx, m, 2, ptr<double>(ctx->U0T), k, ptr<double>(ctx->Pm), st)) return e;
+        hipLaunchKernelGGL(k_simpls_signs, dim3(m), dim3(256), 0, st, ptr<double>(ctx->Pm), k, T, ctx->nks_t,
+                           ctx->LT, ptr<double>(ctx->Mfrag), yl);
+        LAUNCHCHK();
+        if (int e = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e;
     }
     return PLSX_OK;
 }

@@ -594,18 +594,18 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
 // of A (m x n, column-major, pitch ld) are orthogonalised by plane rotations
 // applied from the right; the same rotations are applied to V (mv x n).  Each
 // column pair is handled by an 8-lane group (dot products reduced with
-// wavefront shuffles); 32 pairs per pass of the 256-thread block.
+// wavefront shuffles); blockDim.x / 8 pairs per pass.
 __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag)
 {
     const int tid = threadIdx.x;
-    const int sub = tid & 7, grp = tid >> 3;
+    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
     const int np = (n + 1) >> 1, ne = np * 2;
     const double tol = 1e-15;
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
         for (int step = 0; step < ne - 1; ++step) {
-            for (int pr = grp; pr < np; pr += 32) {
+            for (int pr = grp; pr < np; pr += ngrp) {
                 int p, q;
                 if (pr == 0) { p = step; q = ne - 1; }
                 else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }

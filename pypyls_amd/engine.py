@@ -18,6 +18,7 @@ _LIB = None
 
 PLSX_BEHAVIORAL = 0
 PLSX_MEANCENTERED = 1
+PLSX_REGRESSION = 2
 PLSX_FLAG_COVARIANCE = 1
 
 
@@ -61,6 +62,10 @@ def _load():
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
         'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
+        'plsx_simpls_decompose': ([vp, vp, vp, vp, vp, vp], i32),
+        'plsx_simpls_set_original': ([vp, vp, vp], i32),
+        'plsx_simpls_perm_batch': ([vp, vp, i32, vp, vp], i32),
+        'plsx_simpls_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -77,7 +82,9 @@ def exported_symbols():
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
              'plsx_colmean', 'plsx_perm_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
-             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak']
+             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak',
+             'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
+             'plsx_simpls_boot_batch']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -265,6 +272,48 @@ class Engine(object):
         self.sync()
         return (np.ascontiguousarray(uc.cpu().numpy().transpose(0, 2, 1)),
                 np.ascontiguousarray(vc.cpu().numpy().transpose(0, 2, 1)))
+
+    # -- SIMPLS regression ---------------------------------------------------
+    def set_data_regression(self, Xc, Yc, n_components):
+        """Xc (S, B), Yc (S, T): globally column-centred data."""
+        self.set_data(Xc, Yc, np.zeros(len(Xc), np.int32), 1, int(n_components), PLSX_REGRESSION)
+        self.k = int(n_components)
+
+    def simpls_decompose(self):
+        """-> x_weights (B, k), pctvar_y (k,), cvec (T, k), y_loadings (T, k)."""
+        xwT, pct = self._empty((self.k, self.B)), self._empty((self.k,))
+        cv, yl = self._empty((self.T, self.k)), self._empty((self.T, self.k))
+        self._check(self.lib.plsx_simpls_decompose(self.ctx, xwT.data_ptr(), pct.data_ptr(), cv.data_ptr(),
+                                                   yl.data_ptr(), self._stream()))
+        self.sync()
+        return (np.ascontiguousarray(xwT.cpu().numpy().T), pct.cpu().numpy(), cv.cpu().numpy(),
+                yl.cpu().numpy())
+
+    def simpls_set_original(self, x_weights):
+        w0c = np.asarray(x_weights) - np.asarray(x_weights).mean(axis=0, keepdims=True)
+        d = self._dev(w0c.T, np.float64)
+        self._check(self.lib.plsx_simpls_set_original(self.ctx, d.data_ptr(), self._stream()))
+        self.sync()
+
+    def simpls_perm(self, permsamples):
+        """permsamples (S, P) -> pctvar of Y per permutation (k, P)."""
+        idx = self._index_rows(permsamples)
+        out = self._empty((idx.shape[0], self.k))
+        self._check(self.lib.plsx_simpls_perm_batch(self.ctx, idx.data_ptr(), idx.shape[0], out.data_ptr(),
+                                                    self._stream()))
+        self.sync()
+        return out.cpu().numpy().T.copy()
+
+    def simpls_boot(self, bootsamples):
+        """-> usum, usq device tensors (B, k) and y_loadings_boot (T, k, R)."""
+        idx = self._index_rows(bootsamples)
+        n = idx.shape[0]
+        usum, usq = self._zeros((self.B, self.k)), self._zeros((self.B, self.k))
+        yl = self._empty((n, self.T, self.k))
+        self._check(self.lib.plsx_simpls_boot_batch(self.ctx, idx.data_ptr(), n, usum.data_ptr(),
+                                                    usq.data_ptr(), yl.data_ptr(), self._stream()))
+        self.sync()
+        return usum, usq, np.ascontiguousarray(yl.cpu().numpy().transpose(1, 2, 0))
 
     # -- device-resident variants (no host copies, no sync): bench / pipelines --
     def index_tensor(self, samples):

@@ -78,11 +78,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('PLSX_BENCH_BACKEND', 'nccl')   # 'gloo' only for single-GPU dry runs
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -133,7 +137,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if backend == 'nccl' else torch.device('cpu'))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = eng.last_timing()

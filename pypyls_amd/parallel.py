@@ -59,8 +59,13 @@ def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
     import torch
     d = _dist()
     with_boot = usum is not None
-    device = usum.device if with_boot else torch.device(
-        'cuda', torch.cuda.current_device()) if d.get_backend() == 'nccl' else torch.device('cpu')
+    home = usum.device if with_boot else None
+    if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU
+        device = home if home is not None else torch.device('cuda', torch.cuda.current_device())
+    else:                                   # gloo (CPU tests / single-GPU dry runs)
+        device = torch.device('cpu')
+        if with_boot:
+            usum, usq = usum.to(device), usq.to(device)
     # the permutation block may carry extra rows (split-half nulls ride along)
     Lp = local_perm.shape[0] if local_perm is not None else 0
     L = local_dist.shape[1] if local_dist is not None else (usum.shape[1] if with_boot else 0)
@@ -107,4 +112,6 @@ def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
         for r in range(1, world):                      # fixed rank order
             usum += parts[r]
             usq += qarts[r]
+        if home is not None and usum.device != home:
+            usum, usq = usum.to(home), usq.to(home)
     return perm, dist_out, usum, usq

@@ -1,0 +1,66 @@
+"""Two ranks (gloo) sharing the one visible GPU: exercises the resample
+sharding + single-collective path of the front-end end to end and checks that
+the sharded result equals the single-rank result."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+import pypyls_amd as pls
+rs = np.random.RandomState(0)
+X = rs.randn(40, 300); Y = rs.randn(40, 5) + 0.4 * X[:, :5]
+res = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=0, seed=7, verbose=False)
+Xm = rs.randn(36, 200); Xm[:12] += 1.0
+rm = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=7, n_boot=7, seed=3, verbose=False)
+rr = pls.pls_regression(X, Y, n_components=3, n_perm=6, n_boot=5, seed=5, verbose=False)
+if dist.get_rank() == 0:
+    np.savez({out!r}, perm=res.permres.perm_singval, bsr=res.bootres.x_weights_normed,
+             ylb=res.bootres.y_loadings_boot, uc=res.splitres.ucorr_pvals, ul=res.splitres.ucorr_uplim,
+             mperm=rm.permres.perm_singval, mbsr=rm.bootres.x_weights_normed,
+             rperm=rr.permres.perm_singval, rbsr=rr.bootres.x_weights_normed)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    out = str(tmp_path / 'two.npz')
+    script = tmp_path / 'w.py'
+    script.write_text(_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    two = np.load(out)
+    import pypyls_amd as pls
+    rs = np.random.RandomState(0)
+    X = rs.randn(40, 300)
+    Y = rs.randn(40, 5) + 0.4 * X[:, :5]
+    res = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=0, seed=7, verbose=False)
+    Xm = rs.randn(36, 200)
+    Xm[:12] += 1.0
+    rm = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=7, n_boot=7, seed=3, verbose=False)
+    rr = pls.pls_regression(X, Y, n_components=3, n_perm=6, n_boot=5, seed=5, verbose=False)
+    np.testing.assert_allclose(two['perm'], res.permres.perm_singval, rtol=1e-12)
+    np.testing.assert_allclose(two['ylb'], res.bootres.y_loadings_boot, rtol=1e-12)
+    np.testing.assert_allclose(two['bsr'], res.bootres.x_weights_normed, rtol=1e-9)
+    np.testing.assert_allclose(two['uc'], res.splitres.ucorr_pvals, rtol=1e-12)
+    np.testing.assert_allclose(two['ul'], res.splitres.ucorr_uplim, rtol=1e-10)
+    np.testing.assert_allclose(two['mperm'], rm.permres.perm_singval, rtol=1e-12)
+    np.testing.assert_allclose(two['mbsr'], rm.bootres.x_weights_normed, rtol=1e-9)
+    np.testing.assert_allclose(two['rperm'], rr.permres.perm_singval, rtol=1e-12)
+    np.testing.assert_allclose(two['rbsr'], rr.bootres.x_weights_normed, rtol=1e-9)

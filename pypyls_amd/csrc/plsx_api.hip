@@ -282,13 +282,13 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     {
         dim3 g(ceil_div(Ma * N1, 256), batch);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,
-                           a.ntiles, 0, C1, strideC1, ldc1, Ma, N1);
+                           a.ntiles, 0, C1, strideC1, ldc1, Ma, N1, 0);
         LAUNCHCHK();
     }
     if (B2) {
         dim3 g(ceil_div(Ma * N2, 256), batch);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,
-                           a.ntiles, 1, C2, strideC2, ldc2, Ma, N2);
+                           a.ntiles, 1, C2, strideC2, ldc2, Ma, N2, 0);
         LAUNCHCHK();
     }
     return 0;
@@ -331,13 +331,13 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     if (mode != 2) {
         dim3 g(ceil_div(ctx->Tp * ctx->Tp, 256), nres);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 0, Gm, sG,
-                           ctx->Tp, ctx->Tp, ctx->Tp);
+                           ctx->Tp, ctx->Tp, ctx->Tp, 0);
         LAUNCHCHK();
     }
     if (mode != 0) {
         dim3 g(ceil_div(ctx->Tp * Erows, 256), nres);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 1, Pout, sP,
-                           Erows, ctx->Tp, Erows);
+                           Erows, ctx->Tp, Erows, 0);
         LAUNCHCHK();
     }
     return 0;

@@ -480,7 +480,9 @@ void k_nt_gemm(NtArgs a)
 // four q-groups together cover one full 128-byte line of the row) and element
 // s of that quad feeds k-step s.  Wave w owns output column tile w of G and of
 // P; it reads all four row tiles of R (shared with the other waves through
-// L1) plus row tile w of R / of U0^T as its B operands.
+// L1) plus row tile w of R / of U0^T as its B operands.  (Computing only the
+// upper triangle of G tiles was measured SLOWER: 36.7 vs 29.2 ms per 560
+// bootstraps -- the per-wave imbalance costs more than the 19 % MFMA saved.)
 // ---------------------------------------------------------------------------
 // MODE 0: G only; 1: G and P; 2: P only (cross-Gram against a shared matrix).
 template <int MODE>
@@ -571,19 +573,21 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
 // C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
 __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
                               int mtiles, int ntiles, int which,
-                              double* __restrict__ C, long long strideC, int ldc, int M, int N)
+                              double* __restrict__ C, long long strideC, int ldc, int M, int N, int sym)
 {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * N) return;
-    const int m = idx / N, n = idx % N;
+    int m = idx / N, n = idx % N;
+    const int mo = m, no = n;
+    if (sym && (m >> 4) > (n >> 4)) { const int t = m; m = n; n = t; }   // only 16x16 tiles (a <= w) were computed
     const int tile = (m / 64) * ntiles + (n / 64);
     const size_t tiles = (size_t)mtiles * ntiles;
     const size_t off = ((size_t)which * tiles + tile) * 4096 + (m % 64) * 64 + (n % 64);
     double s = 0.0;
     for (int c = 0; c < nchunk; ++c)
         s += part[(((size_t)c * batch + b) * 2) * tiles * 4096 + off];
-    C[(size_t)b * strideC + (size_t)m * ldc + n] = s;
+    C[(size_t)b * strideC + (size_t)mo * ldc + no] = s;
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,141 @@
+"""Edge cases and full-size properties of the device path (GPU only)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import cpu_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from pypyls_amd.engine import Engine
+    return Engine()
+
+
+def _bind(eng, X, Y, groups, n_cond, **kw):
+    from pypyls_amd import resampling as rsmp
+    eng.set_data(X, Y, rsmp.cell_of_row(groups, n_cond), len(groups), n_cond, 0, **kw)
+    return ref.Spec('behavioral', groups, n_cond, kw.get('covariance', False))
+
+
+@pytest.mark.parametrize('S,B,T,groups,n_cond', [
+    (90, 333, 80, [90], 1),          # T' = 80 > 64: generic tiled Gram path, LT = 5
+    (96, 211, 24, [24, 24], 2),      # T' = J*T = 4*24 = 96 = the solver limit, ragged B
+    (33, 17, 2, [33], 1),            # tiny, S not a multiple of 8, B < 128
+    (603, 140, 3, [603], 1),         # S > 512
+])
+def test_shapes_at_the_limits(S, B, T, groups, n_cond):
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(S + B)
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + (0.5 * X[:, :T] if B >= T else 0)
+    eng = _engine()
+    spec = _bind(eng, X, Y, groups, n_cond)
+    U, d, V = ref.decompose(spec, X, Y)
+    xw, sv, yw = eng.decompose()
+    live = sv > 1e-4 * sv[0]
+    assert_close(sv[live], np.diag(d)[live], 1e-7, what='singvals')
+    eng.set_original(U, np.diag(d), V)
+    perms = rsmp.gen_permsamp(groups, n_cond, 3, seed=1)
+    got = eng.perm(perms)
+    want = np.stack([ref.single_perm(spec, X, Y, perms[:, i], V)[0] for i in range(3)], -1)
+    assert_close(got, want, 1e-7, what='perm')
+    boots = rsmp.gen_bootsamp(groups, n_cond, 3, seed=2)
+    usum, usq, dist = eng.boot(boots)
+    ws, wd = np.zeros_like(U), []
+    for i in range(3):
+        dd, ub = ref.single_boot(spec, X, Y, boots[:, i], U, d)
+        ws += ub
+        wd.append(dd)
+    assert_close(usum.cpu().numpy()[:, live], ws[:, live], 1e-6, what='u_sum')
+    assert_close(dist[:, live], np.stack(wd, -1)[:, live], 1e-6, what='distrib')
+
+
+def test_unsupported_and_bad_arguments_fail_loudly():
+    from pypyls_amd.engine import PlsxError
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(0)
+    eng = _engine()
+    with pytest.raises(PlsxError):                       # T' = 97 > 96
+        eng.set_data(rs.randn(120, 50), rs.randn(120, 97), rsmp.cell_of_row([120], 1), 1, 1, 0)
+    with pytest.raises(PlsxError):                       # perm before set_data / set_original
+        _engine().perm(np.zeros((0, 1), int))
+    X, Y = rs.randn(30, 40), rs.randn(30, 3)
+    _bind(eng, X, Y, [30], 1)
+    with pytest.raises(PlsxError):                       # original not set
+        eng.perm(rsmp.gen_permsamp([30], 1, 2, seed=0))
+    with pytest.raises(ValueError):                      # wrong number of rows
+        eng.crosscov(ysrc=np.zeros((29, 2), int))
+    cells = np.array([0] * 10 + [1] * 10 + [0] * 10, np.int32)   # non-contiguous cells
+    with pytest.raises(PlsxError):
+        eng.set_data(X, Y, cells, 2, 1, 0)
+
+
+def test_single_resample_and_batch_boundaries():
+    """n = 1 and n straddling the group / super-batch sizes give the same
+    per-resample numbers as one big call."""
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(3)
+    X, Y = rs.randn(50, 500), rs.randn(50, 7)
+    eng = _engine()
+    spec = _bind(eng, X, Y, [50], 1)
+    U, d, V = ref.decompose(spec, X, Y)
+    eng.set_original(U, np.diag(d), V)
+    perms = rsmp.gen_permsamp([50], 1, 77, seed=1)
+    full = eng.perm(perms)
+    np.testing.assert_allclose(eng.perm(perms[:, :1]), full[:, :1], rtol=1e-12)
+    np.testing.assert_allclose(eng.perm(perms[:, 5:36]), full[:, 5:36], rtol=1e-12)
+    boots = rsmp.gen_bootsamp([50], 1, 40, seed=2)
+    u1, q1, d1 = eng.boot(boots)
+    u2, q2, d2a = eng.boot(boots[:, :13])
+    u2, q2, d2b = eng.boot(boots[:, 13:], usum=u2, usq=q2)
+    np.testing.assert_allclose(u2.cpu().numpy(), u1.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([d2a, d2b], -1), d1, rtol=1e-12)
+
+
+def test_full_size_properties():
+    """BASELINE size (X 500 x 200000, Y 500 x 50): size-independent properties
+    instead of an oracle run (one oracle resample takes ~5 s on the host)."""
+    from pypyls_amd import hostmath, resampling as rsmp
+    S, B, T = 500, 200000, 50
+    rs = np.random.RandomState(0)
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.3 * X[:, :T]
+    eng = _engine()
+    eng.set_data(X, Y, rsmp.cell_of_row([S], 1), 1, 1, 0)
+    xw, sv, yw = eng.decompose()
+    xw, yw = hostmath.sign_convention(xw, yw)
+    # decomposition: orthonormal factors, descending singular values, R = V d U^T on a sample
+    assert np.all(np.diff(sv) <= 0)
+    np.testing.assert_allclose(xw.T @ xw, np.eye(T), atol=1e-9)
+    np.testing.assert_allclose(yw.T @ yw, np.eye(T), atol=1e-9)
+    R = eng.crosscov(n=1)[0]
+    cols = rs.choice(B, 64, replace=False)
+    np.testing.assert_allclose((yw * sv) @ xw[cols].T, R[:, cols], atol=1e-9)
+    np.testing.assert_allclose(R[:, cols], ref.xcorr(X[:, cols], Y), atol=1e-11)
+    eng.set_original(xw, sv, yw)
+    ident = np.arange(S)[:, None]
+    # identity permutation: rotated singular values reproduce the originals
+    perms = np.hstack([ident, rsmp.gen_permsamp([S], 1, 6, seed=1)])
+    ssd = eng.perm(perms)
+    np.testing.assert_allclose(ssd[:, 0], sv, rtol=1e-9)
+    # Procrustes rotation preserves the total sum of squares
+    raw = eng.perm(perms, rotate=False)
+    np.testing.assert_allclose((ssd ** 2).sum(0), (raw ** 2).sum(0), rtol=1e-9)
+    # identity bootstrap: U_rot = U0 d0, distrib = y_loadings
+    boots = np.hstack([ident, rsmp.gen_bootsamp([S], 1, 3, seed=2)])
+    usum, usq, dist = eng.boot(boots[:, :1])
+    np.testing.assert_allclose(usum.cpu().numpy(), xw * sv, atol=1e-9)
+    np.testing.assert_allclose(usq.cpu().numpy(), (xw * sv) ** 2, atol=1e-9)
+    xs = eng.project(xw) + (eng.colmean() @ xw)[None]
+    np.testing.assert_allclose(dist[:, :, 0], ref.xcorr(xs, Y), atol=1e-9)
+    # accumulation is additive and order independent
+    u_all, q_all, _ = eng.boot(boots)
+    u_b, q_b, _ = eng.boot(boots[:, ::-1])
+    np.testing.assert_allclose(u_all.cpu().numpy(), u_b.cpu().numpy(), rtol=1e-9, atol=1e-11)
+    # relabelling the rows of X and Y together changes nothing
+    order = rs.permutation(S)
+    eng2 = _engine()
+    eng2.set_data(X[order], Y[order], rsmp.cell_of_row([S], 1), 1, 1, 0)
+    np.testing.assert_allclose(eng2.decompose()[1], sv, rtol=1e-10)

@@ -129,6 +129,15 @@ int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate,
                     double* d_out_sv, void* stream);
 
 /*
+ * Same with pre-permuted behaviour matrices instead of index vectors
+ * (`permindices=False`: surrogate / spatially-constrained null models,
+ * pyls/base.py:636-639, 691-692; pyls/structures.py:115-120).
+ *   d_ystack (n, S, T) fp64: the Y matrix of every permutation
+ */
+int plsx_perm_batch_y(plsx_ctx* ctx, const double* d_ystack, int n, int rotate,
+                      double* d_out_sv, void* stream);
+
+/*
  * Bootstrap -- BasePLS.bootstrap / _single_boot (pyls/base.py:439-576).
  *   d_boot_idx (n, S) int32  one bootstrap sample per ROW
  *   d_usum, d_usq (B, L)  accumulated IN PLACE: += sum_r U_r, += sum_r U_r**2
@@ -156,6 +165,19 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np,
                           const uint8_t* d_masks, int ns,
                           double* d_ucorr, double* d_vcorr, void* stream);
+
+/*
+ * Cross-validation -- BehavioralPLS.crossval / _single_crossval
+ * (pyls/types/behavioral.py:82-170) with compute.rescale_test
+ * (pyls/compute.py:129-151): for each of m train/test splits decompose the
+ * training rows on the device, z-map the test rows with the training feature
+ * mean / std of their cell, predict Y and score the prediction.
+ *   d_masks (m, S) uint8, 1 = training row (gen_splits(..., test_size))
+ *   d_r, d_r2 (m, T) out: Pearson r (efficient_corr) and r^2
+ *                  (sklearn r2_score, multioutput='raw_values') per behaviour
+ */
+int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2,
+                        void* stream);
 
 /*
  * SIMPLS regression (pyls/types/regression.py:56-186, 248-373), solved per

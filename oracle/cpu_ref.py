@@ -324,6 +324,47 @@ def single_boot(spec, X, Y, inds, x_weights, d_orig=None):
     return distrib, U_boot
 
 
+def rescale_test(X_train, X_test, Y_train, U, V):
+    """compute.rescale_test, pyls/compute.py:129-151: z-map the test rows with
+    the training mean / std (ddof=1), project, add the training mean of Y."""
+    mu = X_train.mean(axis=0)
+    sd = X_train.std(axis=0, ddof=1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        X_resc = (X_test - mu) / sd
+    return (X_resc @ U @ V.T) + Y_train.mean(axis=0, keepdims=True)
+
+
+def r2_score_raw(y_true, y_pred):
+    """sklearn.metrics.r2_score(..., multioutput='raw_values') for the
+    non-degenerate case: 1 - SS_res / SS_tot per column."""
+    ss_res = np.sum((y_true - y_pred) ** 2, axis=0)
+    ss_tot = np.sum((y_true - y_true.mean(axis=0)) ** 2, axis=0)
+    return 1.0 - ss_res / ss_tot
+
+
+def single_crossval(spec, X, Y, inds):
+    """BehavioralPLS._single_crossval, pyls/types/behavioral.py:126-170.
+    ``inds`` True = training row."""
+    inds = np.asarray(inds, dtype=bool)
+    dummy = spec.dummy
+    Xtr, Ytr, dtr = X[inds], Y[inds], dummy[inds]
+    Xte, Yte, dte = X[~inds], Y[~inds], dummy[~inds]
+    U, d, V = decompose(spec, Xtr, Ytr, dtr)
+    pred = []
+    for n, V_spl in enumerate(np.split(V, dummy.shape[-1])):
+        tr, te = dtr[:, n].astype(bool), dte[:, n].astype(bool)
+        pred.append(rescale_test(Xtr[tr], Xte[te], Ytr[tr], U, V_spl))
+    pred = np.vstack(pred)
+    return efficient_corr(Yte, pred), r2_score_raw(Yte, pred)
+
+
+def crossval(spec, X, Y, splits):
+    """BehavioralPLS.crossval (behavioral.py:82-124) with the (S, n) train
+    masks supplied.  Returns pearson_r, r_squared of shape (T, n)."""
+    out = [single_crossval(spec, X, Y, splits[:, i]) for i in range(splits.shape[1])]
+    return np.stack([o[0] for o in out], -1), np.stack([o[1] for o in out], -1)
+
+
 # --------------------------------------------------------------------------
 # full drivers (what BasePLS.run_pls + the subclass run_pls assemble)
 # --------------------------------------------------------------------------

@@ -38,6 +38,8 @@ struct plsx_ctx {
     Buf Afrag, R, Gm, Pm, part, Mfrag, U0T, V0, d0, tmpW;
     Buf Rfull, Vp, dp, Mvd, Cm, srcx, srcy, part2;     // split-half scratch
     Buf Kmat, swork, spct, sc;                          // SIMPLS: K = Xc Xc^T, dual-solver scratch
+    Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
+    double* mom_out_arg = nullptr;                      // set while a launch should export feature moments
     int ncomp = 0;
     // timing of the cross-product kernel
     int timing = 0;
@@ -186,7 +188,7 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
-                       std::max(ctx->nmom_pad, 0), groups, ncolblk);
+                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg);
     LAUNCHCHK();
     if (ctx->timing) {
         HIPCHK(hipEventRecord(e1, st));
@@ -226,7 +228,7 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 // afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
 // [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
 int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
-              bool prebuilt = false)
+              bool prebuilt = false, const double* ystack = nullptr)
 {
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
@@ -240,7 +242,8 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
     } else if (ctx->method == PLSX_BEHAVIORAL) {
         dim3 grid(nres, ctx->J), block(256);
         const size_t lds = (size_t)2 * ctx->T * 8;
-        hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ptr<double>(ctx->Y), ctx->T, ctx->S,
+        hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ystack ? ystack : ptr<double>(ctx->Y),
+                           ystack ? (long long)ctx->S * ctx->T : 0LL, ctx->T, ctx->S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay,
                            ctx->cov, ctx->scaled, ptr<double>(ctx->Afrag), ctx->group_stride,
                            ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16));
@@ -430,7 +433,8 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->out_row, &ctx->mom_idx, &ctx->mom_n, &ctx->Afrag, &ctx->R, &ctx->Gm, &ctx->Pm,
                    &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW,
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
-                   &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc})
+                   &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
+                   &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -632,21 +636,44 @@ int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv, con
     return PLSX_OK;
 }
 
+namespace {
+int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int n, int rotate,
+                    double* d_out_sv, void* stream);
+}
+
 int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate, double* d_out_sv,
                     void* stream)
 {
     NEED_ORIG();
     if (!d_perm_idx || !d_out_sv || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch: bad arguments");
+    return perm_batch_impl(ctx, d_perm_idx, nullptr, n, rotate, d_out_sv, stream);
+}
+
+int plsx_perm_batch_y(plsx_ctx* ctx, const double* d_ystack, int n, int rotate, double* d_out_sv,
+                      void* stream)
+{
+    NEED_ORIG();
+    if (ctx->method != PLSX_BEHAVIORAL)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch_y: pre-permuted Y stacks need behavioral PLS");
+    if (!d_ystack || !d_out_sv || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch_y: bad arguments");
+    return perm_batch_impl(ctx, nullptr, d_ystack, n, rotate, d_out_sv, stream);
+}
+
+namespace {
+int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int n, int rotate,
+                    double* d_out_sv, void* stream)
+{
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     const int nb = ctx->Gcap * ctx->npg;
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
-        const int* idx = d_perm_idx + (size_t)off * ctx->S;
+        const int* idx = d_perm_idx ? d_perm_idx + (size_t)off * ctx->S : nullptr;
         // behavioral permutes Y (base.py:599), mean-centred permutes X (meancentered.py:125)
         const int* xs = (ctx->method == PLSX_BEHAVIORAL) ? nullptr : idx;
         const int* ys = (ctx->method == PLSX_BEHAVIORAL) ? idx : nullptr;
-        if (int e = run_xprod(ctx, xs, ys, m, st)) return e;
+        const double* yst = d_ystack ? d_ystack + (size_t)off * ctx->S * ctx->T : nullptr;
+        if (int e = run_xprod(ctx, xs, ys, m, st, false, yst)) return e;
         if (int e = run_gram(ctx, m, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_PERM);
         a.rotate = rotate ? 1 : 0;
@@ -655,6 +682,8 @@ int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate,
     }
     return PLSX_OK;
 }
+
+}  // namespace
 
 int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
                     double* d_distrib, void* stream)
@@ -745,6 +774,63 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
                                d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
             LAUNCHCHK();
         }
+    }
+    return PLSX_OK;
+}
+
+int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2, void* stream)
+{
+    NEED_DATA();
+    if (ctx->method != PLSX_BEHAVIORAL)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: cross-validation is defined for behavioral PLS");
+    if (ctx->cov)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_crossval_batch: covariance=True is not supported");
+    if (!d_masks || !d_r || !d_r2 || m < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int S = ctx->S, T = ctx->T, J = ctx->J, Tp = ctx->Tp, L = ctx->L;
+    // splits per pass: bounded by the super-batch and by the J rescaled copies kept in R2
+    int nb = std::max(1, std::min(ctx->Gcap * ctx->npg, 256 / std::max(J, 1)));
+    nb = (nb / ctx->npg) * ctx->npg;
+    if (nb < ctx->npg) nb = ctx->npg;
+    for (int off = 0; off < m; off += nb) {
+        const int mm = std::min(nb, m - off);
+        const int groups = ceil_div(mm, ctx->npg);
+        const uint8_t* mk = d_masks + (size_t)off * S;
+        if (int e = ensure(ctx, ctx->srcx, (size_t)mm * S * sizeof(int))) return e;
+        hipLaunchKernelGGL(k_cv_src, dim3(ceil_div(S, 256), mm), dim3(256), 0, st, mk, S, ptr<int>(ctx->srcx));
+        LAUNCHCHK();
+        if (int e = ensure(ctx, ctx->momout, (size_t)groups * ctx->nmom_pad * 2 * ctx->Bpad * 8)) return e;
+        ctx->mom_out_arg = ptr<double>(ctx->momout);
+        int e = run_xprod(ctx, ptr<int>(ctx->srcx), nullptr, mm, st);
+        ctx->mom_out_arg = nullptr;
+        if (e) return e;
+        // train decompositions
+        if (int e2 = run_gram(ctx, mm, false, st)) return e2;
+        if (int e2 = ensure(ctx, ctx->Vs, (size_t)mm * Tp * L * 8)) return e2;
+        if (int e2 = ensure(ctx, ctx->ds, (size_t)mm * L * 8)) return e2;
+        SmallArgs a = small_args(ctx, SMALL_DECOMP);
+        a.out_V = ptr<double>(ctx->Vs); a.out_d = ptr<double>(ctx->ds);
+        if (int e2 = run_small(ctx, a, mm, st)) return e2;
+        // rescaled copies and offsets, then Q = Rs . Xc^T
+        if (int e2 = ensure(ctx, ctx->R2, (size_t)mm * J * ctx->strideR * 8)) return e2;
+        if (int e2 = ensure(ctx, ctx->cvc, (size_t)mm * J * Tp * 8)) return e2;
+        hipLaunchKernelGGL(k_cv_rescale, dim3(Tp, mm * J), dim3(256), 0, st, ptr<double>(ctx->R), ctx->strideR,
+                           ctx->Bpad, ctx->B, J, ctx->npg, ctx->nmom_pad, ptr<double>(ctx->momout),
+                           ptr<double>(ctx->R2), ptr<double>(ctx->cvc), Tp);
+        LAUNCHCHK();
+        if (int e2 = ensure(ctx, ctx->Qm, (size_t)mm * J * Tp * S * 8)) return e2;
+        if (int e2 = run_nt(ctx, ptr<double>(ctx->R2), ctx->strideR, ctx->Bpad, Tp, ptr<double>(ctx->Xc), 0,
+                            ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, mm * J, ptr<double>(ctx->Qm),
+                            (long long)Tp * S, S, nullptr, 0, 0, st))
+            return e2;
+        if (int e2 = ensure(ctx, ctx->ybar, (size_t)mm * J * T * 8)) return e2;
+        if (int e2 = ensure(ctx, ctx->pred, (size_t)mm * S * T * 8)) return e2;
+        hipLaunchKernelGGL(k_cv_final, dim3(mm), dim3(256), 0, st, ptr<double>(ctx->Qm), ptr<double>(ctx->cvc),
+                           ptr<double>(ctx->Vs), ptr<double>(ctx->ds), ptr<double>(ctx->Y), mk,
+                           ptr<int>(ctx->cell_of_row), S, T, J, Tp, L, ptr<double>(ctx->ybar),
+                           ptr<double>(ctx->pred), d_r + (size_t)off * T, d_r2 + (size_t)off * T);
+        LAUNCHCHK();
     }
     return PLSX_OK;
 }

@@ -83,7 +83,7 @@ struct GroupLayout {
 // z-scoring is over the positions of cell j that the resample keeps
 // (pyls/compute.py:83-87 applied per cell, behavioral.py:49-52).
 // grid (n_resamples, J), block 256.  dynamic LDS: 2*Tn doubles.
-__global__ void k_build_A_behav(const double* __restrict__ Y, int T, int S,
+__global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_stride, int T, int S,
                                 const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                                 const int* __restrict__ xsrc, const int* __restrict__ ysrc,
                                 GroupLayout lay, int covariance, int scaled,
@@ -93,6 +93,9 @@ __global__ void k_build_A_behav(const double* __restrict__ Y, int T, int S,
     extern __shared__ double sm_b[];
     const int r = blockIdx.x, j = blockIdx.y;
     const int g = r / lay.n, rr = r % lay.n;
+    // y_stride != 0: every resample brings its own (S, T) behaviour matrix
+    // (pre-permuted Y stacks, pyls/base.py:636-639, 691-692)
+    const double* Y = Y0 + (size_t)r * y_stride;
     const int start = cell_start[j], len = cell_len[j];
     const int* xs = xsrc ? xsrc + (size_t)r * S : nullptr;
     const int* ys = ysrc ? ysrc + (size_t)r * S : nullptr;
@@ -245,7 +248,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              double* __restrict__ R, int ldr, int rows_per_group,
              const int* __restrict__ out_row, const int* __restrict__ mom_idx,
              const double* __restrict__ mom_n, int nmom_pad,
-             int n_groups, int ncolblk)
+             int n_groups, int ncolblk, double* __restrict__ mom_out)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = NW * 64;                      // threads
@@ -345,7 +348,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             const double m1 = sS[o], m2 = sQ[o];
             const double nn = mom_n[(size_t)grp * nmom_pad + mr];
             const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);
-            sS[o] = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+            const double sc = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+            sS[o] = sc;
+            if (mom_out) {       // training mean / inverse std of the features (cross-validation)
+                double* mo = mom_out + ((size_t)grp * nmom_pad + mr) * 2 * ldr + col;
+                mo[0] = m1 / nn;
+                mo[ldr] = sc;
+            }
         }
         __syncthreads();
     }
@@ -1060,6 +1069,103 @@ __global__ void k_split_final(const double* __restrict__ part, int nchunk, int n
         const double w1 = f11 - f1s * f1s / nn, w2 = f22 - f2s * f2s / nn;
         rr = cv / sqrt(w1 * w2);
         vcorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cross-validation (BehavioralPLS.crossval, pyls/types/behavioral.py:82-170)
+// ---------------------------------------------------------------------------
+
+// Training masks -> source tables (train rows keep their position, test rows -1).
+__global__ void k_cv_src(const uint8_t* __restrict__ masks, int S, int* __restrict__ xsrc)
+{
+    const int slot = blockIdx.y;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < S; p += gridDim.x * blockDim.x)
+        xsrc[(size_t)slot * S + p] = masks[(size_t)slot * S + p] ? p : -1;
+}
+
+// Rs[(i*J + j)][t][b] = invstd_{i,j}[b] * R_i[t][b]  and  c[(i*J+j)][t] = sum_b mean_{i,j}[b] * Rs[..][t][b]
+// so that zmap(X_test; X_train_cell_j) @ R_i^T = X_test @ Rs^T - c   (compute.rescale_test,
+// pyls/compute.py:148-149).  grid (T', m*J), one block per output row.
+__global__ __launch_bounds__(256)
+void k_cv_rescale(const double* __restrict__ R, long long strideR, int ldr, int B, int J, int npg,
+                  int nmom_pad, const double* __restrict__ mom_out,
+                  double* __restrict__ R2, double* __restrict__ cvec, int Tp)
+{
+    __shared__ double red[4];
+    const int t = blockIdx.x, slot = blockIdx.y;
+    const int i = slot / J, j = slot % J;
+    const int g = i / npg, rr = i % npg;
+    const double* mo = mom_out + ((size_t)g * nmom_pad + rr * J + j) * 2 * ldr;
+    const double* src = R + (size_t)i * strideR + (size_t)t * ldr;
+    double* dst = R2 + (size_t)slot * strideR + (size_t)t * ldr;
+    double part = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double v = src[b] * mo[ldr + b];
+        dst[b] = v;
+        part += mo[b] * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) cvec[(size_t)slot * Tp + t] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Predictions and scores of one train/test split (block = split).
+//   q = Q[(i*J+j)][:, p] - c ;  z = q^T V / d ;  y_pred = z V_j^T + mean_train_j(Y)
+//   pearson r and r^2 (sklearn r2_score, raw values) per behaviour over the test rows.
+__global__ __launch_bounds__(256)
+void k_cv_final(const double* __restrict__ Q /* [m*J][Tp][S] */, const double* __restrict__ cvec,
+                const double* __restrict__ V /* [m][Tp][L] */, const double* __restrict__ d /* [m][L] */,
+                const double* __restrict__ Y, const uint8_t* __restrict__ masks,
+                const int* __restrict__ cell_of_pos, int S, int T, int J, int Tp, int L,
+                double* __restrict__ ybar /* scratch [m][J][T] */, double* __restrict__ pred /* [m][S][T] */,
+                double* __restrict__ out_r, double* __restrict__ out_r2)
+{
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* mk = masks + (size_t)i * S;
+    double* yb = ybar + (size_t)i * J * T;
+    double* pr = pred + (size_t)i * S * T;
+    const double* Vi = V + (size_t)i * Tp * L;
+    const double* di = d + (size_t)i * L;
+    // training means of Y per cell
+    for (int idx = tid; idx < J * T; idx += blockDim.x) {
+        const int j = idx / T, t = idx % T;
+        double s = 0.0; int n = 0;
+        for (int p = 0; p < S; ++p)
+            if (mk[p] && cell_of_pos[p] == j) { s += Y[(size_t)p * T + t]; ++n; }
+        yb[idx] = s / (double)n;
+    }
+    __syncthreads();
+    const double dmax = di[0];
+    for (int p = tid; p < S; p += blockDim.x) {
+        if (mk[p]) continue;
+        const int j = cell_of_pos[p];
+        const double* Qs = Q + (size_t)(i * J + j) * Tp * S;
+        const double* cs = cvec + (size_t)(i * J + j) * Tp;
+        for (int t = 0; t < T; ++t) pr[(size_t)p * T + t] = yb[j * T + t];
+        for (int l = 0; l < L; ++l) {
+            if (!(di[l] > PLSX_RANK_RTOL * dmax)) continue;
+            double z = 0.0;
+            for (int u = 0; u < Tp; ++u) z += (Qs[(size_t)u * S + p] - cs[u]) * Vi[(size_t)u * L + l];
+            z /= di[l];
+            for (int t = 0; t < T; ++t) pr[(size_t)p * T + t] += z * Vi[(size_t)(j * T + t) * L + l];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += blockDim.x) {
+        double sy = 0, sp = 0, syy = 0, spp = 0, syp = 0, sres = 0; int n = 0;
+        for (int p = 0; p < S; ++p) {
+            if (mk[p]) continue;
+            const double y = Y[(size_t)p * T + t], q = pr[(size_t)p * T + t];
+            sy += y; sp += q; syy += y * y; spp += q * q; syp += y * q; sres += (y - q) * (y - q); ++n;
+        }
+        const double nn = (double)n;
+        const double cov = syp - sy * sp / nn, vy = syy - sy * sy / nn, vp = spp - sp * sp / nn;
+        double r = cov / sqrt(vy * vp);
+        out_r[(size_t)i * T + t] = (r > 1.0) ? 1.0 : ((r < -1.0) ? -1.0 : r);
+        out_r2[(size_t)i * T + t] = 1.0 - sres / vy;
     }
 }
 

@@ -56,6 +56,8 @@ def _load():
         'plsx_project': ([vp, vp, i32, vp, vp], i32),
         'plsx_colmean': ([vp, vp, vp], i32),
         'plsx_perm_batch': ([vp, vp, i32, i32, vp, vp], i32),
+        'plsx_perm_batch_y': ([vp, vp, i32, i32, vp, vp], i32),
+        'plsx_crossval_batch': ([vp, vp, i32, vp, vp, vp], i32),
         'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
         'plsx_split_half_batch': ([vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
@@ -81,7 +83,7 @@ def exported_symbols():
     names = ['plsx_version', 'plsx_max_tprime', 'plsx_ctx_create', 'plsx_ctx_destroy',
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
-             'plsx_colmean', 'plsx_perm_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
+             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak',
              'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch']
@@ -235,6 +237,19 @@ class Engine(object):
         self.sync()
         return out.cpu().numpy().T.copy()
 
+    def perm_ystack(self, ystack, rotate=True):
+        """ystack (n, S, T): pre-permuted Y matrices -> permuted singular values (L, n)."""
+        ystack = np.asarray(ystack, dtype=np.float64)
+        if ystack.ndim != 3 or ystack.shape[1] != self.S or ystack.shape[2] != self.T:
+            raise ValueError('pre-permuted Y stack must have shape (n, {}, {}); got {}'
+                             .format(self.S, self.T, ystack.shape))
+        d = self._dev(ystack, np.float64)
+        out = self._empty((ystack.shape[0], self.L))
+        self._check(self.lib.plsx_perm_batch_y(self.ctx, d.data_ptr(), ystack.shape[0],
+                                               1 if rotate else 0, out.data_ptr(), self._stream()))
+        self.sync()
+        return out.cpu().numpy().T.copy()
+
     def boot(self, bootsamples, usum=None, usq=None):
         """bootsamples (S, R) -> (usum, usq) device tensors (B, L), accumulated in
         place when given, and distrib (T', L, R) numpy."""
@@ -272,6 +287,20 @@ class Engine(object):
         self.sync()
         return (np.ascontiguousarray(uc.cpu().numpy().transpose(0, 2, 1)),
                 np.ascontiguousarray(vc.cpu().numpy().transpose(0, 2, 1)))
+
+    def crossval(self, splits):
+        """splits (S, m) bool, True = training row -> pearson_r, r_squared (T, m)."""
+        torch = _torch()
+        splits = np.asarray(splits)
+        if splits.ndim != 2 or splits.shape[0] != self.S:
+            raise ValueError('split masks must have shape (S, m) with S = {}'.format(self.S))
+        dm = torch.from_numpy(np.ascontiguousarray(splits.T, dtype=np.uint8)).to(self.device)
+        m = dm.shape[0]
+        r, r2 = self._empty((m, self.T)), self._empty((m, self.T))
+        self._check(self.lib.plsx_crossval_batch(self.ctx, dm.data_ptr(), m, r.data_ptr(), r2.data_ptr(),
+                                                 self._stream()))
+        self.sync()
+        return r.cpu().numpy().T.copy(), r2.cpu().numpy().T.copy()
 
     # -- SIMPLS regression ---------------------------------------------------
     def set_data_regression(self, Xc, Yc, n_components):

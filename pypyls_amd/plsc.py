@@ -95,18 +95,23 @@ class _PLSCRun(object):
         # ---- ONE collective (parallel.collect) ----------------------------
         n_perm = inp.get('n_perm') or 0
         n_boot = inp.get('n_boot') or 0
-        permsamp = bootsamp = local_perm = local_dist = usum = usq = None
+        permsamp = bootsamp = local_perm = local_dist = usum = usq = ystack = None
         if n_perm > 0:
             # BasePLS.permutation, base.py:601-652
             permsamp = inp.get('permsamples')
             if permsamp is None:
                 permsamp = resampling.gen_permsamp(inp.groups, inp.n_cond, n_perm, seed=self.rs,
                                                    verbose=inp.get('verbose'))
-            elif not inp.get('permindices'):
-                raise NotImplementedError(
-                    'pre-permuted Y stacks (permindices=False, pyls/base.py:636-639) are not '
-                    'supported by the device path yet')
             permsamp = np.asarray(permsamp)
+            if not inp.get('permindices'):
+                # pre-permuted Y matrices, (n_perm, S, T) (base.py:636-639)
+                if self.method != 'behavioral' or permsamp.ndim != 3:
+                    raise ValueError('permindices=False expects `permsamples` of shape '
+                                     '(n_perm, S, T) and behavioral PLS')
+                if inp.get('n_split') is not None:
+                    raise NotImplementedError('split-half with pre-permuted Y stacks is not '
+                                              'supported by the device path')
+                ystack, permsamp = permsamp, None
         n_split = inp.get('n_split')
         orig_splits = None
         if permsamp is not None and n_split is not None:
@@ -126,6 +131,12 @@ class _PLSCRun(object):
                 bootsamp = resampling.gen_bootsamp(inp.groups, inp.n_cond, n_boot, seed=self.rs,
                                                    verbose=inp.get('verbose'))
             bootsamp = np.asarray(bootsamp)
+        n_perm_tot = 0 if permsamp is None else permsamp.shape[1]
+        if ystack is not None:
+            n_perm_tot = ystack.shape[0]
+            lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
+            local_perm = eng.perm_ystack(ystack[lo:hi], rotate=bool(inp.get('rotate', True))) \
+                if hi > lo else np.zeros((L, 0))
         if permsamp is not None:
             lo, hi = parallel.shard_bounds(permsamp.shape[1], rank, world)
             local_perm = eng.perm(permsamp[:, lo:hi], rotate=bool(inp.get('rotate', True))) \
@@ -155,7 +166,7 @@ class _PLSCRun(object):
             # ride along with the permutation block of the single collective
             local_perm = np.vstack([local_perm, local_uc, local_vc])
         d_perm, distrib, usum, usq = parallel.collect(
-            local_perm, permsamp.shape[1] if permsamp is not None else 0,
+            local_perm, n_perm_tot,
             local_dist, bootsamp.shape[1] if bootsamp is not None else 0, usum, usq)
         if orig_splits is not None:
             d_perm, ucorrs, vcorrs = d_perm[:L], d_perm[L:2 * L], d_perm[2 * L:]
@@ -170,9 +181,10 @@ class _PLSCRun(object):
                 vcorr_pvals=hostmath.perm_sig(orig_vc, vcorrs),
                 ucorr_lolim=ull, vcorr_lolim=vll, ucorr_uplim=uul, vcorr_uplim=vul))
             self.split_null = (ucorrs, vcorrs)
-        if permsamp is not None:
+        if d_perm is not None:
             res['permres']['pvals'] = hostmath.perm_sig(sv, d_perm)
-            res['permres']['permsamples'] = permsamp
+            res['permres']['permsamples'] = permsamp if ystack is None else \
+                np.transpose(ystack, (1, 2, 0))                   # base.py:638-639 layout
             res['permres']['perm_singval'] = d_perm
 
         # ---- scores / loadings (subclass run_pls) --------------------------
@@ -212,11 +224,26 @@ class _PLSCRun(object):
                     contrast=contrast, contrast_boot=distrib,
                     contrast_ci=np.stack(hostmath.boot_ci(distrib, ci=inp.get('ci', 95)), -1)))
 
+        # ---- cross-validation (behavioral.py:219-221, 82-170) ----------------
         if (self.method == 'behavioral' and inp.get('test_split') is not None
                 and (inp.get('test_size') or 0) > 0):
-            warnings.warn('cross-validation (test_split / test_size, pyls/types/behavioral.py:'
-                          '82-170) is not part of the accelerated path in this build and is '
-                          'skipped; pass test_split=0 to silence this warning.')
+            splits = inp.get('_cvsplits')
+            if splits is None:
+                splits = resampling.gen_splits(inp.groups, inp.n_cond, inp.test_split, seed=self.rs,
+                                               test_size=inp.test_size)
+            if inp.get('covariance'):
+                warnings.warn('cross-validation with covariance=True is not supported by the '
+                              'device path; cvres is left empty.')
+            else:
+                lo, hi = parallel.shard_bounds(splits.shape[1], rank, world)
+                if hi > lo:
+                    r, r2 = eng.crossval(splits[:, lo:hi])
+                    local_cv = np.vstack([r, r2])
+                else:
+                    local_cv = np.zeros((2 * Y.shape[1], 0))
+                cv, _, _, _ = parallel.collect(local_cv, splits.shape[1], None, 0, None, None)
+                Tn = Y.shape[1]
+                res['cvres'].update(dict(pearson_r=cv[:Tn], r_squared=cv[Tn:]))
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv

@@ -92,7 +92,7 @@ class PLSInputs(KeyedRecord):
         'ci', 'seed', 'verbose', 'n_proc', 'bootsamples', 'permsamples',
         'method', 'n_components', 'aggfunc', 'permindices',
         # build-only knobs (filtered like any other key): pre-drawn split masks, engine
-        '_splitsamples', '_perm_splitsamples', '_engine',
+        '_splitsamples', '_perm_splitsamples', '_cvsplits', '_engine',
     )
 
     def __init__(self, **kwargs):

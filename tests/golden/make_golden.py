@@ -55,6 +55,8 @@ def _logging_gen_splits(*args, **kwargs):
 
 
 pbase.gen_splits = _logging_gen_splits
+import pyls.types.behavioral as _pbehav                        # noqa: E402
+_pbehav.gen_splits = _logging_gen_splits      # crossval imports the name directly
 
 
 def flat(res, prefix='ref_'):
@@ -64,7 +66,7 @@ def flat(res, prefix='ref_'):
                 'y_loadings', 'singvals', 'varexp'):
         if res.get(key) is not None:
             out[prefix + key] = np.asarray(res[key])
-    for sub in ('permres', 'bootres', 'splitres'):
+    for sub in ('permres', 'bootres', 'splitres', 'cvres'):
         for key, val in res[sub].items():
             if val is not None:
                 out['{}{}__{}'.format(prefix, sub, key)] = np.asarray(val)
@@ -93,6 +95,10 @@ def run_plsc(name, fcn, X, Y=None, **kw):
         v = kw.get(k)
         if v is not None:
             out[k] = np.asarray(v)
+    if kw.get('test_split'):
+        # the cross-validation masks are the LAST gen_splits call (behavioral.py:220)
+        out['cv_splits'] = _SPLIT_LOG[-1]
+        out['test_size'] = np.asarray(kw.get('test_size', 0.25))
     n_perm = kw.get('n_perm', 0)
     if kw.get('n_split') and n_perm:
         # order of gen_splits calls: permutation i = 0..P-1 (seed=i,
@@ -252,5 +258,29 @@ def main():
         print('wrote simpls_' + tag)
 
 
+def main_cv():
+    """Cross-validation cases (own RandomState so the fixtures above stay
+    byte-stable when cases are added)."""
+    rs = np.random.RandomState(424242)
+
+    def synth(S, B, T, signal=0.8):
+        Xs = rs.randn(S, B)
+        Ys = rs.randn(S, T)
+        Ys[:, :T] += signal * Xs[:, :T]
+        return Xs, Ys
+
+    # default ON in behavioral_pls: test_split=100, test_size=.25 (behavioral.py:231-235)
+    Xs, Ys = synth(60, 150, 4)
+    run_plsc('bpls_cv', pyls.behavioral_pls, Xs, Ys, n_perm=0, n_boot=0, test_split=8,
+             test_size=0.25, seed=1234)
+    Xs, Ys = synth(64, 90, 3)
+    run_plsc('bpls_2g2c_cv', pyls.behavioral_pls, Xs, Ys, groups=[14, 18], n_cond=2,
+             n_perm=5, n_boot=5, test_split=6, test_size=0.3, seed=77)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'cv':
+        main_cv()
+    else:
+        main()
+        main_cv()

@@ -31,8 +31,13 @@ def _run(g, method, with_samples=True, **extra):
             kw['_perm_splitsamples'] = g['perm_splitsamples']
     kw.update(extra)
     if method == 'behavioral':
-        return pls.behavioral_pls(g['X'], g['Y'], covariance=bool(g.get('covariance', False)),
-                                  test_split=0, **kw)
+        if 'cv_splits' in g:
+            kw.update(test_split=g['cv_splits'].shape[1], test_size=float(g['test_size']))
+            if with_samples:
+                kw['_cvsplits'] = g['cv_splits']
+        else:
+            kw['test_split'] = 0
+        return pls.behavioral_pls(g['X'], g['Y'], covariance=bool(g.get('covariance', False)), **kw)
     return pls.meancentered_pls(g['X'], mean_centering=int(g.get('mean_centering', 0)), **kw)
 
 
@@ -118,6 +123,13 @@ def test_behavioral_vs_reference_and_oracle(name):
     _compare(res, g, _oracle(g, 'behavioral'), keep, boot_tight=True)
     _compare_split(res, _oracle(g, 'behavioral'), keep)
     _compare_split(res, _ref_as_dict(g), keep)
+    if 'cv_splits' in g:
+        spec = ref.Spec('behavioral', list(g['groups']), int(g['n_cond']))
+        r, r2 = ref.crossval(spec, g['X'], g['Y'], g['cv_splits'])
+        for got, want_o, want_r, what in ((res['cvres']['pearson_r'], r, g['ref_cvres__pearson_r'], 'pearson_r'),
+                                          (res['cvres']['r_squared'], r2, g['ref_cvres__r_squared'], 'r_squared')):
+            assert_close(got, want_o, RTOL, what='oracle ' + what)
+            assert_close(got, want_r, RTOL, what='reference ' + what)
     # (a) the reference's own numbers; rank-deficient bootstrap rotations of the
     # reference are noise-defined (oracle.procrustes_live) -> functional check
     _compare(res, g, _ref_as_dict(g), keep, boot_tight=_boots_full_rank(g) and bool(np.all(keep)))
@@ -146,6 +158,34 @@ def test_seed_reproduces_reference_index_arrays(name):
     keep = live_lvs(g['ref_singvals'])
     assert_close(res['permres']['perm_singval'][keep], g['ref_permres__perm_singval'][keep],
                  RTOL, what='perm_singval')
+
+
+def test_cv_seed_reproduces_reference_splits():
+    """seed only: the cross-validation masks are drawn from the same stream
+    position as the reference's (after the bootstrap arrays)."""
+    g = load_golden('bpls_2g2c_cv')
+    res = _run(g, 'behavioral', with_samples=False)
+    np.testing.assert_array_equal(res['bootres']['bootsamples'], g['ref_bootres__bootsamples'])
+    assert_close(res['cvres']['pearson_r'], g['ref_cvres__pearson_r'], RTOL, what='pearson_r')
+    assert_close(res['cvres']['r_squared'], g['ref_cvres__r_squared'], RTOL, what='r_squared')
+
+
+def test_prepermuted_y_stack_equals_index_permutations():
+    """permindices=False (pyls/base.py:636-639): a (n_perm, S, T) stack of
+    already-permuted Y matrices gives the same null as the index arrays."""
+    import pypyls_amd as pls
+    g = load_golden('bpls_2g2c')
+    perms = g['ref_permres__permsamples']
+    ystack = np.stack([g['Y'][perms[:, i]] for i in range(perms.shape[1])])
+    kw = dict(groups=list(g['groups']), n_cond=int(g['n_cond']), n_perm=perms.shape[1], n_boot=0,
+              test_split=0, verbose=False)
+    a = pls.behavioral_pls(g['X'], g['Y'], permsamples=ystack, permindices=False, **kw)
+    b = pls.behavioral_pls(g['X'], g['Y'], permsamples=perms, **kw)
+    np.testing.assert_allclose(a.permres.perm_singval, b.permres.perm_singval, rtol=1e-12)
+    np.testing.assert_array_equal(a.permres.pvals, b.permres.pvals)
+    assert a.permres.permsamples.shape == (g['Y'].shape[0], g['Y'].shape[1], perms.shape[1])
+    keep = live_lvs(g['ref_singvals'])
+    assert_close(a.permres.perm_singval[keep], g['ref_permres__perm_singval'][keep], RTOL, what='vs reference')
 
 
 def test_linnerud_known_answers():

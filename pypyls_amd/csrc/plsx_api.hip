@@ -31,6 +31,9 @@ struct plsx_ctx {
     int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, Gcap = 0, Galloc = 0;
     int nks_t = 0, LT = 0;
     size_t group_stride = 0;
+    // fixed-X fast path (behavioral permutations): pre-scaled features, no moment tiles
+    int fix = 0, MTf = 25, npgf = 0;
+    size_t group_stride_f = 0;
     long long strideR = 0;
     std::vector<int> h_cell_start, h_cell_len;
     // device buffers
@@ -39,6 +42,7 @@ struct plsx_ctx {
     Buf Rfull, Vp, dp, Mvd, Cm, srcx, srcy, part2;     // split-half scratch
     Buf Kmat, swork, spct, sc;                          // SIMPLS: K = Xc Xc^T, dual-solver scratch
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
+    Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     double* mom_out_arg = nullptr;                      // set while a launch should export feature moments
     int ncomp = 0;
     // timing of the cross-product kernel
@@ -152,8 +156,10 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
 {
     groups = std::min(std::max(groups, 1), ctx->Gcap);
     if (groups <= ctx->Galloc) return 0;
-    const size_t nb = (size_t)groups * ctx->npg;
-    if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * ctx->group_stride * 8)) return e;
+    // resamples held at once: the fixed-X path packs more resamples per group
+    const size_t nb = (size_t)groups * std::max(ctx->npg, ctx->npgf);
+    const size_t astride = std::max(ctx->group_stride, ctx->group_stride_f);
+    if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * astride * 8 + 4096)) return e;
     // R: rows t >= Tp of every resample stay zero forever (memset on alloc)
     if (int e = ensure(ctx, ctx->R, nb * ctx->Tpp * (size_t)ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->mom_n, (size_t)groups * std::max(ctx->nmom_pad, 16) * 8, true)) return e;
@@ -167,7 +173,7 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
 template <int MT, int NW, int KT, int NSQ, int DBG = 0>
 int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 {
-    const size_t stage = (size_t)2 * KT * MT * 64 * 8;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
     const size_t epi = (size_t)NW * 2 * NSQ * 16 * 16 * 8 + (size_t)2 * MT * 16 * 4;
     const size_t lds = std::max(stage, epi);
     static size_t configured = 0;
@@ -222,6 +228,55 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
         case 17: return launch_xprod_t<24, 4, 1, 1, 7>(ctx, groups, st);
         default: return launch_xprod_nsq<4, 1>(ctx, groups, st);
     }
+}
+
+// Fixed-X fast path: A = z-scored (permuted) Y only, X pre-scaled per cell, no
+// moment tiles, 25 M-tiles = 8 resamples of T' = 50 with no padding.
+int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, const double* ystack)
+{
+    const int groups = ceil_div(nres, ctx->npgf);
+    if (int e = ensure_scratch(ctx, groups)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride_f * 8, st));
+    GroupLayout lay;
+    lay.n = ctx->npgf; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MTf;
+    lay.w0 = ctx->MTf; lay.sq0 = ctx->MTf; lay.Tpp = ctx->Tpp;
+    {
+        dim3 grid(nres, ctx->J), block(256);
+        const size_t lds = (size_t)2 * ctx->T * 8;
+        hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ystack ? ystack : ptr<double>(ctx->Y),
+                           ystack ? (long long)ctx->S * ctx->T : 0LL, ctx->T, ctx->S,
+                           ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), (const int*)nullptr, ysrc, lay,
+                           0, 0, ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->mom_n), 16);
+        LAUNCHCHK();
+    }
+    constexpr int MT = 25, NW = 4, KT = 1;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
+    const size_t lds = std::max(stage, (size_t)2 * MT * 16 * 4);
+    static bool configured = false;
+    if (!configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, 0, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    dim3 grid(ncolblk * round_up(groups, 8)), block(NW * 64);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 0>), grid, block, lds, st,
+                       ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->Xn), ctx->Bpad,
+                       ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npgf * ctx->Tpp,
+                       ptr<int>(ctx->out_row_f), ptr<int>(ctx->mom_idx_f), ptr<double>(ctx->mom_n), 0,
+                       groups, ncolblk, (double*)nullptr);
+    LAUNCHCHK();
+    if (ctx->timing) {
+        HIPCHK(hipEventRecord(e1, st));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return 0;
 }
 
 // Build the A operands of `nres` resamples and run the cross-product kernel:
@@ -434,7 +489,8 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW,
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
-                   &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred})
+                   &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -538,6 +594,32 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     }
     plan_groups(ctx);
     if (int e = upload_rowmaps(ctx)) return e;
+    ctx->fix = 0; ctx->npgf = 0; ctx->group_stride_f = 0;
+    {
+        const char* nf = getenv("PLSX_NO_FIXED_X");
+        if (method == PLSX_BEHAVIORAL && !ctx->cov && !(nf && atoi(nf))) {
+            // fixed-X fast path for permutations
+            ctx->npgf = (ctx->MTf * 16) / ctx->Tp;
+            if (ctx->npgf >= 1) {
+                ctx->group_stride_f = (size_t)ctx->nks * ctx->MTf * 64;
+                const int rows = ctx->MTf * 16;
+                std::vector<int> orow(rows, -1), none(rows, -1);
+                for (int rr = 0; rr < ctx->npgf; ++rr)
+                    for (int t = 0; t < ctx->Tp; ++t) orow[rr * ctx->Tp + t] = rr * ctx->Tpp + t;
+                if (int e = ensure(ctx, ctx->out_row_f, rows * sizeof(int))) return e;
+                if (int e = ensure(ctx, ctx->mom_idx_f, rows * sizeof(int))) return e;
+                HIPCHK(hipMemcpy(ctx->out_row_f.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(ctx->mom_idx_f.p, none.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+                if (int e = ensure(ctx, ctx->Xn, xbytes)) return e;
+                HIPCHK(hipMemsetAsync(ctx->Xn.p, 0, xbytes, st));
+                hipLaunchKernelGGL(k_cell_scale, dim3(ceil_div(B, 256)), dim3(256), 0, st, ptr<double>(ctx->Xc),
+                                   ctx->Bpad, B, J, ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len),
+                                   ptr<double>(ctx->Xn));
+                LAUNCHCHK();
+                ctx->fix = 1;
+            }
+        }
+    }
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
     if (int e = ensure(ctx, ctx->d0, (size_t)ctx->L * 8)) return e;
@@ -665,7 +747,7 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int nb = ctx->Gcap * ctx->npg;
+    const int nb = ctx->Gcap * (ctx->fix ? ctx->npgf : ctx->npg);
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_perm_idx ? d_perm_idx + (size_t)off * ctx->S : nullptr;
@@ -673,7 +755,9 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
         const int* xs = (ctx->method == PLSX_BEHAVIORAL) ? nullptr : idx;
         const int* ys = (ctx->method == PLSX_BEHAVIORAL) ? idx : nullptr;
         const double* yst = d_ystack ? d_ystack + (size_t)off * ctx->S * ctx->T : nullptr;
-        if (int e = run_xprod(ctx, xs, ys, m, st, false, yst)) return e;
+        if (ctx->fix) {
+            if (int e = run_xprod_fixed(ctx, ys, m, st, yst)) return e;
+        } else if (int e = run_xprod(ctx, xs, ys, m, st, false, yst)) return e;
         if (int e = run_gram(ctx, m, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_PERM);
         a.rotate = rotate ? 1 : 0;

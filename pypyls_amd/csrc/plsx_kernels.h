@@ -59,6 +59,29 @@ __global__ void k_center_pad(const double* __restrict__ X, const double* __restr
     Xc[(size_t)i * ldx + b] = X[(size_t)i * B + b] - mean[b];
 }
 
+// Xn[i][b] = Xc[i][b] / std_{cell(i)}(Xc[:, b])  (ddof = 1): the features as the
+// un-resampled X enters every per-cell z-score.  Permutations leave X fixed
+// (pyls/base.py:599), so their cross-products can use Xn and skip the moment
+// tiles.  One thread per column, rows visited in order.
+__global__ void k_cell_scale(const double* __restrict__ Xc, int ldx, int B, int J,
+                             const int* __restrict__ cell_start, const int* __restrict__ cell_len,
+                             double* __restrict__ Xn)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int j = 0; j < J; ++j) {
+        const int r0 = cell_start[j], n = cell_len[j];
+        double s = 0.0;
+        for (int i = r0; i < r0 + n; ++i) s += Xc[(size_t)i * ldx + b];
+        const double mean = s / (double)n;
+        double q = 0.0;
+        for (int i = r0; i < r0 + n; ++i) { const double d = Xc[(size_t)i * ldx + b] - mean; q += d * d; }
+        const double var = q / (double)(n - 1);
+        const double sc = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+        for (int i = r0; i < r0 + n; ++i) Xn[(size_t)i * ldx + b] = Xc[(size_t)i * ldx + b] * sc;
+    }
+}
+
 // Offset (in doubles) of element (row, k) inside one group's fragment-ordered
 // A operand: [kstep][mtile][lane], lane = (k & 3) * 16 + (row & 15).
 __device__ __forceinline__ size_t afrag_off(int row, int k, int MT)
@@ -252,7 +275,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = NW * 64;                      // threads
-    constexpr int STAGE = KT * MT * 64;              // doubles per stage
+    constexpr int STAGE = KT * MT * 64;              // doubles per stage (global pitch)
+    constexpr int STAGE_LDS = ((STAGE + 127) / 128) * 128;   // LDS pitch: whole wave-DMA pieces
     constexpr int PASSES = (STAGE + NT * 2 - 1) / (NT * 2);   // NT threads x double2
     constexpr bool EVEN = (STAGE % (NT * 2)) == 0;
     const int tid = threadIdx.x;
@@ -299,11 +323,11 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             // A stage kn: global -> LDS DMA (global_load_lds_dwordx4: no staging
             // VGPRs, no ds_write pass), into the buffer every wave finished
             // reading before the barrier that ended the previous pass.
-            stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE, tid);
+            stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid);
 #pragma unroll
             for (int s = 0; s < KT; ++s) xn[s] = Xp[(size_t)((kn * KT + s) * 4) * ldx];
         }
-        const double* sA = smem + cur * STAGE + lane;
+        const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
             const double b = xb[s];
@@ -485,9 +509,9 @@ void k_nt_gemm(NtArgs a)
 //
 // The contraction index (feature column) may be assigned to MFMA k-slots in
 // any order as long as A and B operands agree, so lane (m = l & 15, q = l >> 4)
-// loads FOUR consecutive columns c0 + 4q .. 4q+3 of row m (two dwordx4; the
-// four q-groups together cover one full 128-byte line of the row) and element
-// s of that quad feeds k-step s.  Wave w owns output column tile w of G and of
+// loads two 16-byte pieces of row m per 16-column step, placed so that the four
+// q-lanes of a row read 64 contiguous bytes per load instruction (column
+// c0 + 8 j + 2 q + e feeds k-step 2 j + e).  Wave w owns output column tile w of G and of
 // P; it reads all four row tiles of R (shared with the other waves through
 // L1) plus row tile w of R / of U0^T as its B operands.  (Computing only the
 // upper triangle of G tiles was measured SLOWER: 36.7 vs 29.2 ms per 560
@@ -507,64 +531,76 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
     const int cbeg = chunk * cols_per_chunk;
     const int cend = min(B, cbeg + cols_per_chunk);
     const double* Rr = R + (size_t)r * strideR;
-    // rows beyond T' are clamped: they only feed output rows / columns >= T',
-    // which the reduction never reads
+    // Column <-> k-slot mapping of one 16-column step: load j (0/1), element e
+    // (0/1) of lane q holds column c0 + 8 j + 2 q + e and feeds k-step 2 j + e.
+    // Per load instruction the four q-lanes of a row read 64 contiguous bytes.
+    // Rows beyond T' are clamped: they only feed output rows / columns >= T',
+    // which the reduction never reads.
     const double* pa[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) pa[a] = Rr + (size_t)min(16 * a + m, Tp - 1) * ldr + 4 * q;
-    const double* pb = Rr + (size_t)min(16 * w + m, Tp - 1) * ldr + 4 * q;
-    const double* pu = WITH_P ? U0T + (size_t)min(16 * w + m, L - 1) * ldu + 4 * q : nullptr;
+    for (int a = 0; a < 4; ++a) pa[a] = Rr + (size_t)min(16 * a + m, Tp - 1) * ldr + 2 * q;
+    const double* pb = Rr + (size_t)min(16 * w + m, Tp - 1) * ldr + 2 * q;
+    const double* pu = WITH_P ? U0T + (size_t)min(16 * w + m, L - 1) * ldu + 2 * q : nullptr;
     d4 accG[4], accP[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
 
     int c0 = cbeg;
     const int cfull = cbeg + ((cend - cbeg) / 16) * 16;
-    d4 xa[4], xb, ub = (d4){0, 0, 0, 0};
+    d2 xa[4][2], xb[2], ub[2];
+    ub[0] = ub[1] = (d2){0, 0};
+    xb[0] = xb[1] = (d2){0, 0};
     if (c0 < cfull) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xa[a] = *reinterpret_cast<const d4*>(pa[a] + c0);
-        xb = *reinterpret_cast<const d4*>(pb + c0);
-        if (WITH_P) ub = *reinterpret_cast<const d4*>(pu + c0);
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xa[a][j] = *reinterpret_cast<const d2*>(pa[a] + c0 + 8 * j);
+            if (WITH_G) xb[j] = *reinterpret_cast<const d2*>(pb + c0 + 8 * j);
+            if (WITH_P) ub[j] = *reinterpret_cast<const d2*>(pu + c0 + 8 * j);
+        }
     }
     for (; c0 < cfull; c0 += 16) {
-        d4 na[4], nb, nu = (d4){0, 0, 0, 0};
+        d2 na[4][2], nb[2], nu[2];
         const int cn = min(c0 + 16, cfull - 16);          // clamped prefetch (re-load on the last pass)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) na[a] = *reinterpret_cast<const d4*>(pa[a] + cn);
-        nb = *reinterpret_cast<const d4*>(pb + cn);
-        if (WITH_P) nu = *reinterpret_cast<const d4*>(pu + cn);
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (WITH_G) accG[a] = mfma_f64(xa[a][s], xb[s], accG[a]);
-                if (WITH_P) accP[a] = mfma_f64(xa[a][s], ub[s], accP[a]);
-            }
+            for (int a = 0; a < 4; ++a) na[a][j] = *reinterpret_cast<const d2*>(pa[a] + cn + 8 * j);
+            if (WITH_G) nb[j] = *reinterpret_cast<const d2*>(pb + cn + 8 * j);
+            if (WITH_P) nu[j] = *reinterpret_cast<const d2*>(pu + cn + 8 * j);
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) xa[a] = na[a];
-        xb = nb;
-        ub = nu;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    if (WITH_G) accG[a] = mfma_f64(xa[a][j][e], xb[j][e], accG[a]);
+                    if (WITH_P) accP[a] = mfma_f64(xa[a][j][e], ub[j][e], accP[a]);
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) xa[a][j] = na[a][j];
+            if (WITH_G) xb[j] = nb[j];
+            if (WITH_P) ub[j] = nu[j];
+        }
     }
     if (cfull < cend) {                                    // ragged tail: mask columns >= cend
-        const int cc = cfull + 4 * q;
-        d4 ta[4], tb, tu = (d4){0, 0, 0, 0};
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) ta[a][s] = (cc + s < cend) ? pa[a][cfull + s] : 0.0;
+            for (int e = 0; e < 2; ++e) {
+                const int cc = cfull + 8 * j + 2 * q + e;
+                const bool ok = cc < cend;
+                const double vb = (WITH_G && ok) ? pb[cfull + 8 * j + e] : 0.0;
+                const double vu = (WITH_P && ok) ? pu[cfull + 8 * j + e] : 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            tb[s] = (cc + s < cend) ? pb[cfull + s] : 0.0;
-            if (WITH_P) tu[s] = (cc + s < cend) ? pu[cfull + s] : 0.0;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (WITH_G) accG[a] = mfma_f64(ta[a][s], tb[s], accG[a]);
-                if (WITH_P) accP[a] = mfma_f64(ta[a][s], tu[s], accP[a]);
+                for (int a = 0; a < 4; ++a) {
+                    const double va = ok ? pa[a][cfull + 8 * j + e] : 0.0;
+                    if (WITH_G) accG[a] = mfma_f64(va, vb, accG[a]);
+                    if (WITH_P) accP[a] = mfma_f64(va, vu, accP[a]);
+                }
             }
     }
     // partial tiles: [chunk][resample][which][64 x 64]

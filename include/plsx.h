@@ -193,14 +193,24 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
  *                           d_perm_idx (n, S) permutes Y; d_out (n, k) pctvar of Y
  *   plsx_simpls_boot_batch  PLSRegression._single_boot (regression.py:279-327):
  *                           d_usum/d_usq (B, k) += sign-aligned x_weights (and
- *                           squares); d_yload (n, T, k) = Yi^T (Xi W)
+ *                           squares); d_yload (n, T, k) = Yi^T (Xi W).
+ *                           d_ystack (n, S, T) or NULL: a Y matrix per bootstrap
+ *                           (3-D Y aggregated over its resampled third axis,
+ *                           regression.py:308-310); rows are still gathered with
+ *                           d_boot_idx.
+ *   plsx_simpls_set_row_masks  d_okx / d_oky (S,) uint8, 1 = the row of X / of Y
+ *                           is usable; positions whose source row is an all-NaN
+ *                           row are dropped per resample (get_mask,
+ *                           regression.py:48-53).  NULL = all rows usable.  The
+ *                           bound X / Y must hold zeros in the masked rows.
  */
 int plsx_simpls_decompose(plsx_ctx* ctx, double* d_xwT, double* d_pctvar, double* d_cvec,
                           double* d_yload, void* stream);
 int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream);
 int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, double* d_out, void* stream);
-int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum,
-                           double* d_usq, double* d_yload, void* stream);
+int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const double* d_ystack, int n,
+                           double* d_usum, double* d_usq, double* d_yload, void* stream);
+int plsx_simpls_set_row_masks(plsx_ctx* ctx, const uint8_t* d_okx, const uint8_t* d_oky, void* stream);
 
 /* Bootstrap ratios -- compute.boot_rel (pyls/compute.py:212-237), elementwise
  * on (B, L) arrays: se = sqrt(|usq - usum^2/n| / (n-1)), bsr = orig / se.

@@ -549,50 +549,77 @@ def simpls(X, Y, n_components=None):
                 x_scores=x_sc, y_scores=y_sc, pctvar=pctvar)
 
 
-def regression_single_boot(X, Y, inds, k, original):
-    """PLSRegression._single_boot for 2-D Y, regression.py:279-327."""
-    Xi, Yi = X[inds], Y[inds]
-    w = simpls(Xi, Yi, k)['x_weights']
+def get_mask(X, Y):
+    """Rows where neither X nor Y is entirely NaN (regression.py:48-53)."""
+    return np.logical_not(np.logical_or(np.all(np.isnan(X), axis=1),
+                                        np.all(np.isnan(Y), axis=1)))
+
+
+_AGG = dict(mean=np.mean, median=np.median, sum=np.sum)
+
+
+def regression_single_boot(X, Y, inds, k, original, aggfunc=None):
+    """PLSRegression._single_boot, regression.py:279-327.  For 3-D Y ``inds``
+    is the pair (subject resample, third-axis resample) and Y is aggregated
+    over the resampled third axis (:308-310); NaN rows of the resample are
+    masked (:313, :324-325)."""
+    if Y.ndim == 3:
+        sboot, cboot = inds
+        Xi, Yi = X[sboot], aggfunc(Y[..., cboot], axis=-1)[sboot]
+    else:
+        Xi, Yi = X[inds], Y[inds]
+    mask = get_mask(Xi, Yi)
+    w = simpls(Xi[mask], Yi[mask], k)['x_weights']
     w = w * np.sign(efficient_corr(w, original))
-    return Yi.T @ (Xi @ w), w
+    return Yi[mask].T @ (Xi @ w)[mask], w
 
 
 def regression_single_perm(X, Y, inds, k):
     """PLSRegression._single_perm with original=None (the only reachable
     branch), regression.py:329-373."""
-    return simpls(X, Y[inds], k)['pctvar'][1]
+    Yp = Y[inds]
+    mask = get_mask(X, Yp)
+    return simpls(X[mask], Yp[mask], k)['pctvar'][1]
 
 
 def run_regression(X, Y, n_components, permsamples=None, bootsamples=None,
-                   ci=95):
-    """PLSRegression.run_pls for 2-D, NaN-free input, regression.py:375-428.
-    The reference mean-centres the caller's X in place (:395); here a copy is
-    centred."""
+                   ci=95, aggfunc='mean'):
+    """PLSRegression.run_pls, regression.py:375-428, incl. 3-D Y (aggregated
+    with ``aggfunc``) and all-NaN rows.  The reference mean-centres the
+    caller's X in place (:395); here a copy is centred."""
     X = np.array(X, dtype=float)
     Y = np.array(Y, dtype=float)
-    X -= X.mean(axis=0, keepdims=True)
-    Y -= Y.mean(axis=0, keepdims=True)
+    agg = _AGG.get(aggfunc, aggfunc)
+    Y_agg = agg(Y, axis=-1) if Y.ndim == 3 else Y.copy()
+    X -= np.nanmean(X, axis=0, keepdims=True)
+    Y_agg = Y_agg - np.nanmean(Y_agg, axis=0, keepdims=True)
+    mask = get_mask(X, Y_agg)
     k = int(n_components)
-    out = simpls(X, Y, k)
+    out = simpls(X[mask], Y_agg[mask], k)
     res = dict(permres={}, bootres={})
     W = out['x_weights']
     res['x_weights'] = W
     res['x_scores'] = X @ W
     res['varexp'] = out['pctvar'][1]
-    res['y_loadings'] = Y.T @ res['x_scores']
-    res['y_scores'] = resid_yscores(res['x_scores'], Y @ res['y_loadings'])
+    res['y_loadings'] = Y_agg[mask].T @ res['x_scores'][mask]
+    res['y_scores'] = np.full((len(Y_agg), k), np.nan)
+    res['y_scores'][mask] = resid_yscores(res['x_scores'][mask],
+                                          Y_agg[mask] @ res['y_loadings'])
     if permsamples is not None:
-        d_perm = np.stack([regression_single_perm(X, Y, permsamples[:, i], k)
+        d_perm = np.stack([regression_single_perm(X, Y_agg, permsamples[:, i], k)
                            for i in range(permsamples.shape[1])], axis=-1)
         res['permres'] = dict(
             pvals=perm_sig(np.diag(res['varexp']), d_perm),
             perm_singval=d_perm, permsamples=permsamples)
     if bootsamples is not None:
-        R = bootsamples.shape[1]
+        R = bootsamples.shape[-1]
         u_sum, u_square = np.zeros_like(W), np.zeros_like(W)
         distrib = []
+        # the reference bootstraps the ORIGINAL (un-centred, un-aggregated) Y
+        # for 3-D input and the centred Y for 2-D input (regression.py:408, 395-397)
+        Yb = Y if Y.ndim == 3 else Y_agg
         for i in range(R):
-            yl, w = regression_single_boot(X, Y, bootsamples[:, i], k, W)
+            yl, w = regression_single_boot(X, Yb, bootsamples[..., i], k, W, agg)
             u_sum += w
             u_square += w ** 2
             distrib.append(yl)

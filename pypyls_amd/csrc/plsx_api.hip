@@ -43,6 +43,8 @@ struct plsx_ctx {
     Buf Kmat, swork, spct, sc;                          // SIMPLS: K = Xc Xc^T, dual-solver scratch
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
+    Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
+    bool has_okx = false, has_oky = false;
     double* mom_out_arg = nullptr;                      // set while a launch should export feature moments
     int ncomp = 0;
     // timing of the cross-product kernel
@@ -490,7 +492,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->okx, &ctx->oky})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -543,6 +545,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
     ctx->has_data = ctx->has_orig = false;
+    ctx->has_okx = ctx->has_oky = false;
     ctx->Galloc = 0;
     ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_MEANCENTERED) ? 0 : T;
     ctx->ncomp = ncomp;
@@ -922,7 +925,8 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
 // ---- SIMPLS regression (pyls/types/regression.py) ---------------------------
 namespace {
 int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, bool scatter,
-                    double* pctvar, double* yload, double* cvec, hipStream_t st)
+                    double* pctvar, double* yload, double* cvec, hipStream_t st,
+                    const double* ystack = nullptr)
 {
     const int S = ctx->S, T = ctx->T, k = ctx->ncomp;
     const int groups = ceil_div(nres, ctx->npg);
@@ -930,7 +934,11 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     SimplsArgs a;
     memset(&a, 0, sizeof(a));
     a.S = S; a.T = T; a.k = k;
-    a.K = ptr<double>(ctx->Kmat); a.Yc = ptr<double>(ctx->Y);
+    a.K = ptr<double>(ctx->Kmat);
+    a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
+    a.y_stride = ystack ? (long long)S * T : 0;
+    a.okx = ctx->has_okx ? ptr<uint8_t>(ctx->okx) : nullptr;
+    a.oky = (ctx->has_oky && !ystack) ? ptr<uint8_t>(ctx->oky) : nullptr;
     a.xsrc = xsrc; a.ysrc = ysrc;
     a.work_stride = (size_t)S * (3 * T + 4 * k + 4);
     if (int e = ensure(ctx, ctx->swork, (size_t)nres * a.work_stride * 8)) return e;
@@ -943,7 +951,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         a.lay.w0 = ctx->w0; a.lay.sq0 = ctx->sq0; a.lay.Tpp = ctx->Tpp;
     }
     const int ldh = T | 1;
-    const size_t lds = ((size_t)S + 3 * (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)2 * S * 4 + 64;
+    const size_t lds = ((size_t)S + 3 * (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)3 * S * 4 + 64;
     if (lds > 160 * 1024) return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS: S / T too large for the on-chip solver");
     static size_t configured = 0;
     if (lds > configured) {
@@ -1008,8 +1016,29 @@ int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, doub
     return PLSX_OK;
 }
 
-int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
-                           double* d_yload, void* stream)
+int plsx_simpls_set_row_masks(plsx_ctx* ctx, const uint8_t* d_okx, const uint8_t* d_oky, void* stream)
+{
+    NEED_DATA();
+    if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->has_okx = ctx->has_oky = false;
+    if (d_okx) {
+        if (int e = ensure(ctx, ctx->okx, ctx->S)) return e;
+        HIPCHK(hipMemcpyAsync(ctx->okx.p, d_okx, ctx->S, hipMemcpyDeviceToDevice, st));
+        ctx->has_okx = true;
+    }
+    if (d_oky) {
+        if (int e = ensure(ctx, ctx->oky, ctx->S)) return e;
+        HIPCHK(hipMemcpyAsync(ctx->oky.p, d_oky, ctx->S, hipMemcpyDeviceToDevice, st));
+        ctx->has_oky = true;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return PLSX_OK;
+}
+
+int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const double* d_ystack, int n,
+                           double* d_usum, double* d_usq, double* d_yload, void* stream)
 {
     NEED_ORIG();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
@@ -1025,7 +1054,8 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, doub
         const int m = std::min(nb, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
         double* yl = d_yload + (size_t)off * T * k;
-        if (int e = run_simpls_dual(ctx, idx, idx, m, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st))
+        const double* yst = d_ystack ? d_ystack + (size_t)off * ctx->S * T : nullptr;
+        if (int e = run_simpls_dual(ctx, idx, idx, m, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st, yst))
             return e;
         if (int e = run_xprod(ctx, idx, idx, m, st, true)) return e;          // R_r = W_r^T (k x B)
         // sign alignment against the (centred) original weights

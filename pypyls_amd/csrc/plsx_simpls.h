@@ -21,7 +21,10 @@
 struct SimplsArgs {
     int S, T, k;
     const double* K;        // S x S
-    const double* Yc;       // S x T, globally centred Y
+    const double* Yc;       // S x T, globally centred Y (or per-resample stack, y_stride != 0)
+    long long y_stride;     // doubles between the Y matrices of consecutive resamples (0: shared)
+    const uint8_t* okx;     // [S] 1 = X row usable (not an all-NaN row), or nullptr
+    const uint8_t* oky;     // [S] 1 = Y row usable, or nullptr
     const int* xsrc;        // [nres][S] or nullptr (identity)
     const int* ysrc;        // [nres][S] or nullptr
     double* work;           // per-resample scratch
@@ -48,28 +51,32 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return s;
 }
 
-// z = Jc . K[xs, xs] . Jc . v ; optionally also returns the value before the
-// final centring (zu).  v, z, zu: S-long global arrays; vc: S doubles of LDS.
-__device__ void kop(const double* __restrict__ K, int S, const int* xs, const double* v,
-                    double* z, double* zu, double* vc, double* red)
+// z = Jc . K[xs, xs] . Jc . v over the INCLUDED positions (inc[p] != 0; ninc of
+// them; excluded positions -- all-NaN rows, regression.py:48-53 -- read and
+// produce zeros); optionally also returns the value before the final centring
+// (zu).  v, z, zu: S-long global arrays; vc: S doubles of LDS.
+__device__ void kop(const double* __restrict__ K, int S, const int* xs, const int* inc, double ninc,
+                    const double* v, double* z, double* zu, double* vc, double* red)
 {
     const int tid = threadIdx.x, NT = blockDim.x;
     double part = 0.0;
-    for (int p = tid; p < S; p += NT) part += v[p];
-    const double mean = block_sum(part, red) / (double)S;
-    for (int p = tid; p < S; p += NT) vc[p] = v[p] - mean;
+    for (int p = tid; p < S; p += NT) if (inc[p]) part += v[p];
+    const double mean = block_sum(part, red) / ninc;
+    for (int p = tid; p < S; p += NT) vc[p] = inc[p] ? v[p] - mean : 0.0;
     __syncthreads();
     double zpart = 0.0;
     for (int p = tid; p < S; p += NT) {
-        const int col = xs[p];
         double acc = 0.0;
-        for (int q = 0; q < S; ++q) acc += K[(size_t)xs[q] * S + col] * vc[q];
+        if (inc[p]) {
+            const int col = xs[p];
+            for (int q = 0; q < S; ++q) acc += K[(size_t)xs[q] * S + col] * vc[q];
+        }
         if (zu) zu[p] = acc;
         z[p] = acc;
         zpart += acc;
     }
-    const double zmean = block_sum(zpart, red) / (double)S;
-    for (int p = tid; p < S; p += NT) z[p] -= zmean;
+    const double zmean = block_sum(zpart, red) / ninc;
+    for (int p = tid; p < S; p += NT) if (inc[p]) z[p] -= zmean;
     __syncthreads();
 }
 
@@ -91,6 +98,7 @@ void k_simpls_dual(SimplsArgs a)
     double* red = cv + T;                    // [16]
     int* xs = reinterpret_cast<int*>(red + 16);   // [S]
     int* ys = xs + S;                             // [S]
+    int* inc = ys + S;                            // [S] position included
     __shared__ int s_flag;
 
     // global scratch carve
@@ -107,19 +115,25 @@ void k_simpls_dual(SimplsArgs a)
     double* vu = vz + S;                     // [S]
     double* vb = vu + S;                     // [S]
 
+    const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
+    double cnt = 0.0;
     for (int p = tid; p < S; p += NT) {
-        xs[p] = a.xsrc ? a.xsrc[(size_t)r * S + p] : p;
-        ys[p] = a.ysrc ? a.ysrc[(size_t)r * S + p] : p;
+        const int x = a.xsrc ? a.xsrc[(size_t)r * S + p] : p;
+        const int y = a.ysrc ? a.ysrc[(size_t)r * S + p] : p;
+        xs[p] = x; ys[p] = y;
+        const int ok = (!a.okx || a.okx[x]) && (!a.oky || a.oky[y]);
+        inc[p] = ok;
+        cnt += ok;
     }
-    __syncthreads();
-    // Y0 = Jc Y[ys]
+    const double ninc = block_sum(cnt, red);
+    // Y0 = Jc Y[ys] over the included rows
     double ssy_part = 0.0;
     for (int t = 0; t < T; ++t) {
         double part = 0.0;
-        for (int p = tid; p < S; p += NT) part += a.Yc[(size_t)ys[p] * T + t];
-        const double mean = block_sum(part, red) / (double)S;
+        for (int p = tid; p < S; p += NT) if (inc[p]) part += Ysrc[(size_t)ys[p] * T + t];
+        const double mean = block_sum(part, red) / ninc;
         for (int p = tid; p < S; p += NT) {
-            const double y = a.Yc[(size_t)ys[p] * T + t] - mean;
+            const double y = inc[p] ? Ysrc[(size_t)ys[p] * T + t] - mean : 0.0;
             Y0[(size_t)p * T + t] = y;
             Yd[(size_t)p * T + t] = y;
             ssy_part += y * y;
@@ -130,7 +144,7 @@ void k_simpls_dual(SimplsArgs a)
     for (int t = 0; t < T; ++t) {
         for (int p = tid; p < S; p += NT) va[p] = Yd[(size_t)p * T + t];
         __syncthreads();
-        kop(a.K, S, xs, va, vz, nullptr, vc, red);
+        kop(a.K, S, xs, inc, ninc, va, vz, nullptr, vc, red);
         for (int p = tid; p < S; p += NT) Z[(size_t)p * T + t] = vz[p];
         __syncthreads();
     }
@@ -176,17 +190,17 @@ void k_simpls_dual(SimplsArgs a)
             va[p] = s / si;
         }
         __syncthreads();
-        kop(a.K, S, xs, va, vz, vu, vc, red);          // vz = t (unnormalised), vu = X[xs] r
+        kop(a.K, S, xs, inc, ninc, va, vz, vu, vc, red);   // vz = t (unnormalised), vu = X[xs] r
         double np = 0.0;
         for (int p = tid; p < S; p += NT) np += vz[p] * vz[p];
         const double normt = sqrt(block_sum(np, red));
         // dual weights (centred, as scattered), scores, X[xs] W
         {
             double mpart = 0.0;
-            for (int p = tid; p < S; p += NT) mpart += va[p];
-            const double amean = block_sum(mpart, red) / (double)S;
+            for (int p = tid; p < S; p += NT) if (inc[p]) mpart += va[p];
+            const double amean = block_sum(mpart, red) / ninc;
             for (int p = tid; p < S; p += NT) {
-                WD[(size_t)c * S + p] = (va[p] - amean) / normt;
+                WD[(size_t)c * S + p] = inc[p] ? (va[p] - amean) / normt : 0.0;
                 XW[(size_t)c * S + p] = vu[p] / normt;
                 vz[p] /= normt;                        // t_c
             }
@@ -212,17 +226,17 @@ void k_simpls_dual(SimplsArgs a)
                 for (int p = tid; p < S; p += NT) vb[p] -= coef * BT[(size_t)j * S + p];
                 __syncthreads();
             }
-        kop(a.K, S, xs, vb, vz, nullptr, vc, red);     // vz = K_r beta
+        kop(a.K, S, xs, inc, ninc, vb, vz, nullptr, vc, red);   // vz = K_r beta
         // note: kop centres its input; beta enters only through K_r, so use the centred beta
         {
             double mpart = 0.0;
-            for (int p = tid; p < S; p += NT) mpart += vb[p];
-            const double bmean = block_sum(mpart, red) / (double)S;
+            for (int p = tid; p < S; p += NT) if (inc[p]) mpart += vb[p];
+            const double bmean = block_sum(mpart, red) / ninc;
             double part = 0.0;
-            for (int p = tid; p < S; p += NT) part += (vb[p] - bmean) * vz[p];
+            for (int p = tid; p < S; p += NT) if (inc[p]) part += (vb[p] - bmean) * vz[p];
             const double nrm = sqrt(block_sum(part, red));
             for (int p = tid; p < S; p += NT) {
-                BT[(size_t)c * S + p] = (vb[p] - bmean) / nrm;
+                BT[(size_t)c * S + p] = inc[p] ? (vb[p] - bmean) / nrm : 0.0;
                 KB[(size_t)c * S + p] = vz[p] / nrm;
             }
         }
@@ -255,7 +269,7 @@ void k_simpls_dual(SimplsArgs a)
     for (int idx = tid; idx < T * k; idx += NT) {
         const int t = idx / k, c = idx % k;
         double s = 0.0;
-        for (int p = 0; p < S; ++p) s += a.Yc[(size_t)ys[p] * T + t] * XW[(size_t)c * S + p];
+        for (int p = 0; p < S; ++p) if (inc[p]) s += Ysrc[(size_t)ys[p] * T + t] * XW[(size_t)c * S + p];
         a.yload[((size_t)r * T + t) * k + c] = s;
     }
     if (a.Afrag) {
@@ -263,7 +277,7 @@ void k_simpls_dual(SimplsArgs a)
         double* A = a.Afrag + (size_t)g * a.group_stride;
         for (int idx = tid; idx < S * k; idx += NT) {
             const int c = idx / S, p = idx % S;
-            atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
+            if (inc[p]) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
         }
     }
 }

@@ -67,7 +67,8 @@ def _load():
         'plsx_simpls_decompose': ([vp, vp, vp, vp, vp, vp], i32),
         'plsx_simpls_set_original': ([vp, vp, vp], i32),
         'plsx_simpls_perm_batch': ([vp, vp, i32, vp, vp], i32),
-        'plsx_simpls_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
+        'plsx_simpls_boot_batch': ([vp, vp, vp, i32, vp, vp, vp, vp], i32),
+        'plsx_simpls_set_row_masks': ([vp, vp, vp, vp], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -86,7 +87,7 @@ def exported_symbols():
              'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak',
              'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
-             'plsx_simpls_boot_batch']
+             'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -333,14 +334,32 @@ class Engine(object):
         self.sync()
         return out.cpu().numpy().T.copy()
 
-    def simpls_boot(self, bootsamples):
-        """-> usum, usq device tensors (B, k) and y_loadings_boot (T, k, R)."""
+    def simpls_set_row_masks(self, okx=None, oky=None):
+        """okx / oky (S,) bool: usable rows of X / Y (all-NaN rows are False)."""
+        torch = _torch()
+        dx = None if okx is None else torch.from_numpy(np.ascontiguousarray(okx, dtype=np.uint8)).to(self.device)
+        dy = None if oky is None else torch.from_numpy(np.ascontiguousarray(oky, dtype=np.uint8)).to(self.device)
+        self._check(self.lib.plsx_simpls_set_row_masks(
+            self.ctx, None if dx is None else dx.data_ptr(), None if dy is None else dy.data_ptr(),
+            self._stream()))
+        self.sync()
+
+    def simpls_boot(self, bootsamples, usum=None, usq=None, ystack=None):
+        """-> usum, usq device tensors (B, k) (accumulated in place when given)
+        and y_loadings_boot (T, k, R).  ystack (R, S, T): one Y per bootstrap."""
         idx = self._index_rows(bootsamples)
         n = idx.shape[0]
-        usum, usq = self._zeros((self.B, self.k)), self._zeros((self.B, self.k))
+        if usum is None:
+            usum, usq = self._zeros((self.B, self.k)), self._zeros((self.B, self.k))
+        dys = None
+        if ystack is not None:
+            dys = self._dev(ystack, np.float64)
+            if tuple(dys.shape) != (n, self.S, self.T):
+                raise ValueError('ystack must have shape ({}, {}, {})'.format(n, self.S, self.T))
         yl = self._empty((n, self.T, self.k))
-        self._check(self.lib.plsx_simpls_boot_batch(self.ctx, idx.data_ptr(), n, usum.data_ptr(),
-                                                    usq.data_ptr(), yl.data_ptr(), self._stream()))
+        self._check(self.lib.plsx_simpls_boot_batch(
+            self.ctx, idx.data_ptr(), None if dys is None else dys.data_ptr(), n, usum.data_ptr(),
+            usq.data_ptr(), yl.data_ptr(), self._stream()))
         self.sync()
         return usum, usq, np.ascontiguousarray(yl.cpu().numpy().transpose(1, 2, 0))
 

@@ -16,7 +16,10 @@ Differences from the reference at this commit, on purpose:
   * the leading singular triplet per component is exact, the reference's
     rank-1 randomized SVD is approximate when Y has more than 11 columns
     (SURVEY.md section 0.3).
-  * 3-D Y (``aggfunc``) and NaN rows are not supported on the device path:
+  * 3-D Y: the reference builds its (2, n_boot) resampling array with
+    ``np.array(list(zip(s.T, c.T))).T`` (regression.py:216), which numpy >= 1.24
+    rejects; here the equivalent object array is built explicitly.  The
+    combination of NaN rows and 3-D Y, and rows that are only partly NaN, raise
     NotImplementedError.
 """
 import numpy as np
@@ -40,10 +43,24 @@ def resid_yscores(x_scores, y_scores):
     return y_scores
 
 
+_AGGFUNCS = dict(mean=np.mean, median=np.median, sum=np.sum)
+
+
+def _row_ok(A):
+    """False for all-NaN rows (get_mask, regression.py:48-53); rows that are
+    only partly NaN cannot be handled (they poison the reference as well)."""
+    nan = np.isnan(A)
+    allnan, anynan = nan.all(axis=1), nan.any(axis=1)
+    if np.any(anynan & ~allnan):
+        raise NotImplementedError('rows with some (not all) NaN entries are not supported')
+    return ~allnan
+
+
 def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=True, ci=95,
                    aggfunc='mean', permsamples=None, bootsamples=None, seed=None, verbose=True,
                    n_proc=None, **kwargs):
-    """PLS regression of Y (S, T) on X (S, B) with SIMPLS; see pyls.pls_regression."""
+    """PLS regression of Y (S, T) or (S, T, C) on X (S, B) with SIMPLS; see
+    pyls.pls_regression."""
     from .engine import Engine
     X, Y = np.asarray(X), np.asarray(Y)
     if X.ndim != 2:
@@ -56,33 +73,69 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         if n_components > max_components:
             raise ValueError('Provided `n_components` cannot be greater than {}'
                              .format(max_components))
-    if Y.ndim == 3:
-        if not callable(aggfunc) and aggfunc not in ('mean', 'median', 'sum'):
-            raise ValueError("Provided `aggfunc` must either be callable or one of "
-                             "['mean', 'median', 'sum']")
-        raise NotImplementedError('3-D Y (aggfunc bootstrap, pyls/types/regression.py:208-235) '
-                                  'is not supported by the device path yet')
-    if Y.ndim != 2 or len(X) != len(Y):
+    if Y.ndim not in (2, 3) or len(X) != len(Y):
         raise ValueError('Provided `X` and `Y` matrices must have the same number of samples. '
                          'Provided matrices differed: X: {}, Y: {}'.format(len(X), len(Y)))
-    if np.isnan(X).any() or np.isnan(Y).any():
-        raise NotImplementedError('NaN rows (get_mask, pyls/types/regression.py:48-53) are not '
-                                  'supported by the device path yet')
+    S = len(X)
+    agg = None
+    third = None                                   # (C, n_boot) third-axis resamples for 3-D Y
+    if Y.ndim == 3:
+        # regression.py:208-235
+        if not callable(aggfunc) and aggfunc not in _AGGFUNCS:
+            raise ValueError('Provided `aggfunc` must either be callable or one of {}'
+                             .format(sorted(_AGGFUNCS)))
+        agg = _AGGFUNCS.get(aggfunc, aggfunc)
+        C = Y.shape[-1]
+        if n_boot > 0:
+            if bootsamples is None:
+                # both draws restart from `seed`, as the reference's do (:212-215)
+                subj = resampling.gen_bootsamp([S], 1, n_boot, seed=seed, verbose=verbose)
+                third = resampling.gen_bootsamp([C], 1, n_boot, seed=seed, verbose=verbose)
+            else:
+                bs = np.asarray(bootsamples, dtype=object) if not isinstance(bootsamples, np.ndarray) \
+                    else bootsamples
+                ok = bs.shape[0] == 2 and bs.shape[-1] == n_boot
+                if ok:
+                    subj = np.stack([np.asarray(bs[0][i]) for i in range(n_boot)], axis=-1)
+                    third = np.stack([np.asarray(bs[1][i]) for i in range(n_boot)], axis=-1)
+                    ok = subj.shape[0] == S and third.shape[0] == C
+                if not ok:
+                    raise ValueError('Provided bootsamples arrays does not match size of provided '
+                                     'input arrays or number of bootstraps requested via `nboot`.')
+            packed = np.empty((2, n_boot), dtype=object)
+            for i in range(n_boot):
+                packed[0, i], packed[1, i] = subj[:, i], third[:, i]
+            bootsamples_out, bootsamples = packed, subj
+        try:
+            Y_agg = agg(Y, axis=-1)
+        except TypeError:
+            raise TypeError('Provided callable `aggfun` must accept `axis` keyword argument to '
+                            'condense an array along the specified axis.')
+        if np.isnan(Y).any() or np.isnan(X).any():
+            raise NotImplementedError('NaN rows together with a 3-D Y are not supported')
+    else:
+        Y_agg = Y
+        bootsamples_out = None
     kwargs.update(n_split=0, test_split=0)         # regression.py:238
     kwargs.setdefault('permindices', True)
-    S = len(X)
     inputs = PLSInputs(X=X, Y=Y, groups=[S], n_cond=1, n_components=n_components, n_perm=n_perm,
                        n_boot=n_boot, rotate=rotate, ci=ci, aggfunc=aggfunc,
-                       permsamples=permsamples, bootsamples=bootsamples, seed=seed,
-                       verbose=verbose, n_proc=n_proc, **kwargs)
+                       permsamples=permsamples, bootsamples=bootsamples_out if Y.ndim == 3 else bootsamples,
+                       seed=seed, verbose=verbose, n_proc=n_proc, **kwargs)
     rs = resampling.check_random_state(seed)
     k = n_components
 
-    Xc = X.astype(np.float64) - X.mean(axis=0, keepdims=True)     # regression.py:395-396
-    Yc = Y.astype(np.float64) - Y.mean(axis=0, keepdims=True)
+    # regression.py:395-397 (on copies: the reference centres the caller's X in place)
+    Xc = X.astype(np.float64) - np.nanmean(X, axis=0, keepdims=True)
+    Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
+    okx, oky = _row_ok(Xc), _row_ok(Yc)
+    mask = okx & oky
+    masked = not mask.all()
     B, T = Xc.shape[1], Yc.shape[1]
     eng = kwargs.get('_engine') or Engine()
-    eng.set_data_regression(Xc, Yc, k)
+    eng.set_data_regression(np.nan_to_num(Xc), np.nan_to_num(Yc), k)
+    if masked:
+        eng.simpls_set_row_masks(okx, oky)
     res = PLSResults(inputs=inputs)
 
     # the reference's rank-1 randomized SVD draws normal((min(B, T), 11)) per
@@ -99,7 +152,9 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     W = W * signs
     eng.simpls_set_original(W)
     res['x_weights'] = W
-    res['x_scores'] = eng.project(W)                               # X already centred
+    x_scores = eng.project(W)                                      # X already centred
+    x_scores[~okx] = np.nan                                        # NaN rows stay NaN (X @ W)
+    res['x_scores'] = x_scores
     rank, world = parallel.rank_world()
 
     permsamp = bootsamp = local_perm = local_dist = usum = usq = None
@@ -118,11 +173,19 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         local_perm = eng.simpls_perm(permsamp[:, lo:hi]) if hi > lo else np.zeros((k, 0))
     if bootsamp is not None:
         lo, hi = parallel.shard_bounds(bootsamp.shape[1], rank, world)
-        if hi > lo:
-            usum, usq, local_dist = eng.simpls_boot(bootsamp[:, lo:hi])
-        else:
-            usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
-            local_dist = np.zeros((T, k, 0))
+        usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
+        parts = []
+        step = 256 if third is not None else max(hi - lo, 1)
+        for a0 in range(lo, hi, step):
+            a1 = min(hi, a0 + step)
+            ystack = None
+            if third is not None:
+                # Y aggregated over the resampled third axis, NOT centred
+                # (the reference bootstraps the original Y, regression.py:308-310, 408)
+                ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a0, a1)])
+            usum, usq, d = eng.simpls_boot(bootsamp[:, a0:a1], usum, usq, ystack=ystack)
+            parts.append(d)
+        local_dist = np.concatenate(parts, axis=-1) if parts else np.zeros((T, k, 0))
     d_perm, distrib, usum, usq = parallel.collect(
         local_perm, permsamp.shape[1] if permsamp is not None else 0,
         local_dist, bootsamp.shape[1] if bootsamp is not None else 0, usum, usq)
@@ -131,14 +194,17 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         res['permres']['permsamples'] = permsamp
         res['permres']['perm_singval'] = d_perm
 
-    res['y_loadings'] = Yc.T @ res['x_scores']                     # regression.py:401
-    res['y_scores'] = resid_yscores(res['x_scores'], Yc @ res['y_loadings'])
+    res['y_loadings'] = Yc[mask].T @ x_scores[mask]                # regression.py:401
+    y_scores = np.full((S, k), np.nan)
+    y_scores[mask] = resid_yscores(x_scores[mask], Yc[mask] @ res['y_loadings'])
+    res['y_scores'] = y_scores
     if bootsamp is not None:
         # add the original back, n_boot + 1 (regression.py:409-415)
         bsr, se = eng.boot_rel(W, usum, usq, bootsamp.shape[1] + 1, add_orig=True)
         res['bootres'].update(dict(
             x_weights_normed=bsr, x_weights_stderr=se, y_loadings=res['y_loadings'],
             y_loadings_boot=distrib,
-            y_loadings_ci=np.stack(hostmath.boot_ci(distrib, ci=ci), -1), bootsamples=bootsamp))
+            y_loadings_ci=np.stack(hostmath.boot_ci(distrib, ci=ci), -1),
+            bootsamples=bootsamples_out if third is not None else bootsamp))
     res['varexp'] = pctvar                                          # regression.py:425-426
     return res

@@ -278,9 +278,59 @@ def main_cv():
              n_perm=5, n_boot=5, test_split=6, test_size=0.3, seed=77)
 
 
+def main_reg_extra():
+    """pls_regression with 3-D Y (aggfunc) and with all-NaN rows
+    (pyls/tests/types/test_regression.py:69-90)."""
+    rs = np.random.RandomState(777)
+    S, B, T, C, k = 34, 60, 5, 7, 3
+    X = rs.randn(S, B)
+    Y3 = rs.randn(S, T, C) + 0.8 * X[:, :T, None]
+    # the reference builds its own (2, n_boot) resampling array with
+    # np.array(list(zip(s.T, c.T))).T (regression.py:216), which numpy >= 1.24
+    # rejects (inhomogeneous shape); supply the equivalent object array.
+    sb = pbase.gen_bootsamp([S], 1, 9, seed=1234, verbose=False)
+    cb = pbase.gen_bootsamp([C], 1, 9, seed=1234, verbose=False)
+    boots = np.empty((2, 9), dtype=object)
+    for i in range(9):
+        boots[0, i], boots[1, i] = sb[:, i], cb[:, i]
+    for agg in ('mean', 'median'):
+        res = pyls.pls_regression(X.copy(), Y3.copy(), n_components=k, n_perm=0, n_boot=9,
+                                  aggfunc=agg, bootsamples=boots, seed=1234, verbose=False)
+        out = flat(res)
+        bs = res['bootres']['bootsamples']
+        out['boot_subjects'] = np.stack([np.asarray(b) for b in bs[0]], axis=-1)
+        out['boot_third'] = np.stack([np.asarray(b) for b in bs[1]], axis=-1)
+        del out['ref_bootres__bootsamples']
+        out['X'], out['Y'], out['n_components'] = X, Y3, np.asarray(k)
+        np.savez_compressed(os.path.join(HERE, 'simpls_3d_{}.npz'.format(agg)), **out)
+        print('wrote simpls_3d_' + agg)
+    Xn = rs.randn(40, 70)
+    Yn = rs.randn(40, 4) + 0.8 * Xn[:, :4]
+    Xn[[5, 17]] = np.nan
+    Yn[11] = np.nan
+    res = pyls.pls_regression(Xn.copy(), Yn.copy(), n_components=3, n_perm=0, n_boot=10,
+                              seed=1234, verbose=False)
+    out = flat(res)
+    obj = PLSRegression(Xn.copy(), Yn.copy(), n_components=3, n_perm=0, n_boot=0, seed=1234,
+                        verbose=False)
+    Xc = Xn - np.nanmean(Xn, axis=0, keepdims=True)
+    Yc = Yn - np.nanmean(Yn, axis=0, keepdims=True)
+    permsamp = pbase.gen_permsamp([40], 1, 8, seed=77, verbose=False)
+    out['permsamples'] = permsamp
+    out['ref_perm_varexp'] = np.stack([
+        obj._single_perm(Xc, Yc, inds=permsamp[:, i], original=None, seed=i)[0]
+        for i in range(permsamp.shape[1])], -1)
+    out['X'], out['Y'], out['n_components'] = Xn, Yn, np.asarray(3)
+    np.savez_compressed(os.path.join(HERE, 'simpls_nan.npz'), **out)
+    print('wrote simpls_nan')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cv':
         main_cv()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'reg':
+        main_reg_extra()
     else:
         main()
         main_cv()
+        main_reg_extra()

@@ -50,18 +50,67 @@ def test_seed_gives_reference_bootsamples():
     np.testing.assert_array_equal(res['bootres']['bootsamples'], g['ref_bootres__bootsamples'])
 
 
+@pytest.mark.parametrize('agg', ['mean', 'median'])
+def test_pls_regression_3d_y(agg):
+    """3-D Y bootstrap (regression.py:208-235, 308-310) vs the reference."""
+    import pypyls_amd as pls
+    g = load_golden('simpls_3d_' + agg)
+    n = g['boot_subjects'].shape[1]
+    bs = np.empty((2, n), dtype=object)
+    for i in range(n):
+        bs[0, i], bs[1, i] = g['boot_subjects'][:, i], g['boot_third'][:, i]
+    k = int(g['n_components'])
+    res = pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, aggfunc=agg,
+                             bootsamples=bs, seed=1234, verbose=False)
+    for key in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        assert_close(res[key], g['ref_' + key], RTOL, what=key)
+    for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(res['bootres'][key], g['ref_bootres__' + key], RTOL, what=key)
+    # generated resampling arrays: both draws restart from the seed (regression.py:212-215)
+    res2 = pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, aggfunc=agg,
+                              seed=1234, verbose=False)
+    got = res2['bootres']['bootsamples']
+    np.testing.assert_array_equal(np.stack(list(got[0]), -1), g['boot_subjects'])
+    np.testing.assert_array_equal(np.stack(list(got[1]), -1), g['boot_third'])
+    assert_close(res2['bootres']['x_weights_normed'], g['ref_bootres__x_weights_normed'], RTOL,
+                 what='bsr (generated bootsamples)')
+    with pytest.raises(ValueError):
+        pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, aggfunc='notafunc')
+    with pytest.raises(TypeError):
+        pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, aggfunc=lambda x: x)
+    with pytest.raises(ValueError):
+        pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, bootsamples=[[10], [10]])
+
+
+def test_pls_regression_nan_rows():
+    """All-NaN rows are masked per resample (get_mask, regression.py:48-53)."""
+    import pypyls_amd as pls
+    g = load_golden('simpls_nan')
+    res = pls.pls_regression(g['X'], g['Y'], n_components=3, n_perm=g['permsamples'].shape[1],
+                             n_boot=g['ref_bootres__bootsamples'].shape[1],
+                             permsamples=g['permsamples'],
+                             bootsamples=g['ref_bootres__bootsamples'], seed=1234, verbose=False)
+    for key in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        a, b = res[key], g['ref_' + key]
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        assert_close(np.nan_to_num(a), np.nan_to_num(b), RTOL, what=key)
+    assert_close(res['permres']['perm_singval'], g['ref_perm_varexp'], RTOL, what='perm')
+    for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(res['bootres'][key], g['ref_bootres__' + key], RTOL, what=key)
+    X = g['X'].copy()
+    X[3, 2] = np.nan                                  # partly-NaN row
+    with pytest.raises(NotImplementedError):
+        pls.pls_regression(X, g['Y'], n_components=2, n_perm=0, n_boot=0)
+
+
 def test_regression_errors():
     import pypyls_amd as pls
     rs = np.random.RandomState(0)
     X, Y = rs.rand(20, 30), rs.rand(20, 3)
     with pytest.raises(ValueError):
         pls.pls_regression(X, Y, n_components=25, n_perm=0, n_boot=0)
-    with pytest.raises(NotImplementedError):
-        pls.pls_regression(X, rs.rand(20, 3, 4), n_components=2, n_perm=0, n_boot=0)
-    Xn = X.copy()
-    Xn[3] = np.nan
-    with pytest.raises(NotImplementedError):
-        pls.pls_regression(Xn, Y, n_components=2, n_perm=0, n_boot=0)
+    with pytest.raises(ValueError):
+        pls.pls_regression(X, Y[:-1], n_components=2, n_perm=0, n_boot=0)
     res = pls.pls_regression(X, Y, n_components=2, n_perm=4, n_boot=4, seed=1, verbose=False)
     assert res.x_weights.shape == (30, 2) and res.varexp.shape == (2,)
     assert 'singvals' not in res or res.get('singvals') is None

@@ -190,6 +190,32 @@ def test_simpls_vs_reference(tag):
         assert_close(out['bootres'][k], g['ref_bootres__' + k], TOL, what=k)
 
 
+@pytest.mark.parametrize('agg', ['mean', 'median'])
+def test_simpls_3d_vs_reference(agg):
+    g = load_golden('simpls_3d_' + agg)
+    n = g['boot_subjects'].shape[1]
+    bs = np.empty((2, n), dtype=object)
+    for i in range(n):
+        bs[0, i], bs[1, i] = g['boot_subjects'][:, i], g['boot_third'][:, i]
+    out = ref.run_regression(g['X'], g['Y'], int(g['n_components']), bootsamples=bs, aggfunc=agg)
+    for k in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        assert_close(out[k], g['ref_' + k], 1e-9, what=k)
+    for k in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(out['bootres'][k], g['ref_bootres__' + k], 1e-9, what=k)
+
+
+def test_simpls_nan_rows_vs_reference():
+    g = load_golden('simpls_nan')
+    out = ref.run_regression(g['X'], g['Y'], 3, permsamples=g['permsamples'],
+                             bootsamples=g['ref_bootres__bootsamples'])
+    for k in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        np.testing.assert_array_equal(np.isnan(out[k]), np.isnan(g['ref_' + k]))
+        assert_close(np.nan_to_num(out[k]), np.nan_to_num(g['ref_' + k]), 1e-9, what=k)
+    assert_close(out['permres']['perm_singval'], g['ref_perm_varexp'], 1e-9, what='perm')
+    for k in ('x_weights_normed', 'y_loadings_boot'):
+        assert_close(out['bootres'][k], g['ref_bootres__' + k], 1e-9, what=k)
+
+
 def test_simpls_wide_is_unpinned_but_close():
     """T = 16 > 11: the reference's top singular vector is approximate and
     seed dependent; the exact restatement must still be close."""

@@ -338,6 +338,12 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 acc[m] = mfma_f64(a, (m < MT - NSQ) ? b : bsq, acc[m]);
             }
         }
+        if (DBG & 64) {                   // tuning probe: 12 extra VALU ops per k-step
+            int dummy = tid;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dummy));
+            asm volatile("" :: "v"(dummy));
+        }
         if (!(DBG & 2)) {
 #pragma unroll
             for (int s = 0; s < KT; ++s) xb[s] = xn[s];

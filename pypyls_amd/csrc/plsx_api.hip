@@ -223,6 +223,7 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
         case 3: return launch_xprod_nsq<4, 2>(ctx, groups, st);
         case 2: return launch_xprod_nsq<8, 1>(ctx, groups, st);
         case 10: return launch_xprod_t<24, 4, 1, 1, 64>(ctx, groups, st);  // +12 VALU per k-step (cost probe)
+        case 7: return launch_xprod_t<24, 4, 1, 1, 128>(ctx, groups, st);  // flat-addressed loads (pre-buffer-resource)
         case 11: return launch_xprod_t<24, 4, 1, 1, 1>(ctx, groups, st);   // tuning probes (wrong results)
         case 12: return launch_xprod_t<24, 4, 1, 1, 2>(ctx, groups, st);
         case 13: return launch_xprod_t<24, 4, 1, 1, 3>(ctx, groups, st);

@@ -261,6 +261,34 @@ __device__ __forceinline__ void stage_copy(const double* __restrict__ src, doubl
     }
 }
 
+// Same copy through a buffer resource: the per-lane offset (tid * 16) never
+// changes and the per-pass offset is an SGPR, so the copy costs no VALU
+// instruction at all (VALU issue between fp64 MFMAs costs matrix-pipe slots;
+// flat addressing needs 64-bit VALU adds per load).
+#define PLSX_RSRC_FLAGS 0x00020000
+template <int NT, int PASSES, bool EVEN, int STAGE>
+__device__ __forceinline__ void stage_copy_buf(const double* src, double* dst, int tid, int wave)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, (short)0, 0x7fffffff,
+                                                                   PLSX_RSRC_FLAGS);
+    const int voff = tid * 16;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        if (EVEN || p * NT + wave * 64 < STAGE / 2) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs, (__attribute__((address_space(3))) void*)(dst + (size_t)(p * NT + wave * 64) * 2),
+                16, voff, p * NT * 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowbase, (short)0, 0x7fffffff,
+                                                                   PLSX_RSRC_FLAGS);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+}
+
 // NSQ = number of second-moment tiles; they are the LAST NSQ tiles of the block
 // (static split: no per-tile operand select in the MFMA loop -- VALU work between
 // fp64 MFMAs costs matrix-pipe issue slots on gfx950, measured 8 %).
@@ -295,6 +323,9 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     const double* Ag = Afrag + (size_t)grp * group_stride;
     const double* Xp = X + (size_t)kq * ldx + col;
+    constexpr bool FLAT = (DBG & 128) != 0;           // old flat-addressed loads (A/B probe)
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int xvoff = (kq * ldx + col) * 8;            // per-lane byte offset inside a 4-row k-step
 
     d4 acc[MT];
 #pragma unroll
@@ -302,10 +333,12 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     const int nkt = nks / KT;
     // prologue: stage 0 of A, first X fragments
-    stage_copy<NT, PASSES, EVEN, STAGE>(Ag, smem, tid);
+    if (FLAT) stage_copy<NT, PASSES, EVEN, STAGE>(Ag, smem, tid);
+    else stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
     double xb[KT];
 #pragma unroll
-    for (int s = 0; s < KT; ++s) xb[s] = Xp[(size_t)(s * 4) * ldx];
+    for (int s = 0; s < KT; ++s)
+        xb[s] = FLAT ? Xp[(size_t)(s * 4) * ldx] : load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
     // Force the first X fragments to be resident before the loop: a load still
     // pending at the loop header makes hipcc place a near-draining
     // s_waitcnt vmcnt(1) right after the next stage's loads are issued.
@@ -323,9 +356,15 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             // A stage kn: global -> LDS DMA (global_load_lds_dwordx4: no staging
             // VGPRs, no ds_write pass), into the buffer every wave finished
             // reading before the barrier that ended the previous pass.
-            stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid);
+            if (FLAT)
+                stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid);
+            else
+                stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS,
+                                                        tid, swave);
 #pragma unroll
-            for (int s = 0; s < KT; ++s) xn[s] = Xp[(size_t)((kn * KT + s) * 4) * ldx];
+            for (int s = 0; s < KT; ++s)
+                xn[s] = FLAT ? Xp[(size_t)((kn * KT + s) * 4) * ldx]
+                             : load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
         }
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll

@@ -5,6 +5,7 @@
 #include "../../include/plsx.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,7 @@ struct plsx_ctx {
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
+    Buf psum, psq;                                      // k_urot resample-split partials
     bool has_okx = false, has_oky = false;
     double* mom_out_arg = nullptr;                      // set while a launch should export feature moments
     int ncomp = 0;
@@ -316,6 +318,36 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
     return launch_xprod(ctx, groups, st);
 }
 
+// Resident blocks of `kernel` (256-thread blocks) on the whole chip.
+int chip_slots(const void* kernel)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return per_cu * cus;
+}
+
+// Number of parts (lo..hi) to cut each of `units` work items into so that
+// units * parts fills whole rounds of `slots` resident blocks as exactly as
+// possible (a grid that ends in a nearly empty last round wastes up to a round).
+int pick_parts(long long units, int slots, int lo, int hi)
+{
+    int best = lo;
+    double best_waste = 2.0;
+    for (int p = lo; p <= hi; ++p) {
+        const double rounds = (double)units * p / slots;
+        const double waste = (rounds < 1.0) ? 0.0 : (std::ceil(rounds) - rounds) / std::ceil(rounds);
+        if (waste < best_waste - 1e-9) { best_waste = waste; best = p; }
+        if (waste < 0.03) break;
+    }
+    return best;
+}
+
 // C1 = A.B1^T (and C2 = A.B2^T), batched, contraction over K columns.
 int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
            const double* B1, long long strideB1, int ldb1, int N1,
@@ -377,8 +409,14 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
                       mode == 1 ? E : nullptr, 0, ctx->Bpad, Erows, ctx->B, nres,
                       Gm, sG, ctx->Tp, mode == 1 ? Pout : nullptr, sP, Erows, st);
     }
+    const void* kfn = (mode == 0) ? reinterpret_cast<const void*>(k_gram<0>)
+                    : (mode == 1) ? reinterpret_cast<const void*>(k_gram<1>)
+                                  : reinterpret_cast<const void*>(k_gram<2>);
+    const int maxchunk = std::max(1, ctx->B / 512);
     int nchunk = std::max(1, ceil_div(4096, nres));
-    nchunk = std::min(nchunk, std::max(1, ctx->B / 512));
+    if (nchunk < maxchunk)
+        nchunk = pick_parts(nres, chip_slots(kfn), nchunk, std::min(maxchunk, 4 * nchunk));
+    nchunk = std::min(nchunk, maxchunk);
     const int cols = round_up(ceil_div(ctx->B, nchunk), 16);
     nchunk = ceil_div(ctx->B, cols);
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
@@ -426,22 +464,48 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     return 0;
 }
 
+template <int LT>
+int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
+{
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
+    int nsplit = 1;
+    if (!out && nres >= 64) {
+        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<LT>)), 1, 8);
+        nsplit = std::min(nsplit, nres / 32);
+    }
+    const int rps = ceil_div(nres, std::max(nsplit, 1));
+    nsplit = ceil_div(nres, rps);
+    double *ps = nullptr, *pq = nullptr;
+    if (nsplit > 1) {
+        const size_t bytes = (size_t)nsplit * ctx->B * ctx->L * 8;
+        if (int e = ensure(ctx, ctx->psum, bytes)) return e;
+        if (int e = ensure(ctx, ctx->psq, bytes)) return e;
+        ps = ptr<double>(ctx->psum);
+        pq = ptr<double>(ctx->psq);
+    }
+    hipLaunchKernelGGL(k_urot<LT>, dim3(nblk, nsplit), dim3(256), 0, st, ptr<double>(ctx->R), ctx->strideR,
+                       ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), nres, ctx->B, ctx->L, usum, usq, out,
+                       rps, ps, pq);
+    LAUNCHCHK();
+    if (nsplit > 1) {
+        const long long count = (long long)ctx->B * ctx->L;
+        hipLaunchKernelGGL(k_add_splits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ps, pq, nsplit,
+                           count, usum, usq);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
 int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
 {
-    dim3 grid(ceil_div(ceil_div(ctx->B, 16), 4)), block(256);
-#define URARGS ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), \
-               nres, ctx->B, ctx->L, usum, usq, out
     switch (ctx->LT) {
-        case 1: hipLaunchKernelGGL(k_urot<1>, grid, block, 0, st, URARGS); break;
-        case 2: hipLaunchKernelGGL(k_urot<2>, grid, block, 0, st, URARGS); break;
-        case 3: hipLaunchKernelGGL(k_urot<3>, grid, block, 0, st, URARGS); break;
-        case 4: hipLaunchKernelGGL(k_urot<4>, grid, block, 0, st, URARGS); break;
-        case 5: hipLaunchKernelGGL(k_urot<5>, grid, block, 0, st, URARGS); break;
-        default: hipLaunchKernelGGL(k_urot<6>, grid, block, 0, st, URARGS); break;
+        case 1: return launch_urot<1>(ctx, nres, usum, usq, out, st);
+        case 2: return launch_urot<2>(ctx, nres, usum, usq, out, st);
+        case 3: return launch_urot<3>(ctx, nres, usum, usq, out, st);
+        case 4: return launch_urot<4>(ctx, nres, usum, usq, out, st);
+        case 5: return launch_urot<5>(ctx, nres, usum, usq, out, st);
+        default: return launch_urot<6>(ctx, nres, usum, usq, out, st);
     }
-#undef URARGS
-    LAUNCHCHK();
-    return 0;
 }
 
 SmallArgs small_args(plsx_ctx* ctx, int mode)
@@ -494,7 +558,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->okx, &ctx->oky})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;

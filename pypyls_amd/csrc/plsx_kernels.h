@@ -918,38 +918,60 @@ template <int LT>
 __global__ __launch_bounds__(256)
 void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             const double* __restrict__ Mfrag, int nres, int B, int L,
-            double* __restrict__ usum, double* __restrict__ usq, double* __restrict__ out)
+            double* __restrict__ usum, double* __restrict__ usq, double* __restrict__ out,
+            int res_per_split, double* __restrict__ psum, double* __restrict__ psq)
 {
+    // blockIdx.y = resample split: with more than one split the block writes
+    // its partial (sum, sum of squares) to psum / psq [split][B][L]; k_add_splits
+    // adds them in split order (deterministic).  Splitting shortens the work
+    // unit so the grid does not end in a nearly empty last round of blocks.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b0 = (blockIdx.x * 4 + wave) * 16;
     if (b0 >= B) return;
+    const int r_beg = blockIdx.y * res_per_split;
+    const int r_end = min(nres, r_beg + res_per_split);
     d4 sum[LT], sq[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) { sum[l] = (d4){0, 0, 0, 0}; sq[l] = (d4){0, 0, 0, 0}; }
     const size_t mstride = (size_t)nks_t * LT * 64;
-    for (int r = 0; r < nres; ++r) {
+    // buffer-resource addressing: per-lane offsets are loop invariant, the k-step
+    // offsets are SGPRs (no VALU address arithmetic next to the MFMAs)
+    const int rvoff = ((lane >> 4) * ldr + b0 + (lane & 15)) * 8;
+    const int mvoff = lane * 8;
+    const int rstep = 4 * ldr * 8;
+    for (int r = r_beg; r < r_end; ++r) {
         d4 acc[LT];
 #pragma unroll
         for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
-        const double* Rp = R + (size_t)r * strideR + (size_t)(lane >> 4) * ldr + b0 + (lane & 15);
-        const double* Mp = Mfrag + (size_t)r * mstride + lane;
+        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(Mfrag + (size_t)r * mstride), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
         // issue the R-fragment loads of several k-steps ahead of their MFMAs
         // (HBM-latency bound otherwise: one 512-byte request per wave in flight)
         int ks = 0;
         for (; ks + 4 <= nks_t; ks += 4) {
             double a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = Rp[(size_t)(ks + u) * 4 * ldr];
+            for (int u = 0; u < 4; ++u)
+                a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks + u) * rstep, 0));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int l = 0; l < LT; ++l)
-                    acc[l] = mfma_f64(a[u], Mp[((ks + u) * LT + l) * 64], acc[l]);
+                for (int l = 0; l < LT; ++l) {
+                    const double mv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                        rsM, mvoff, ((ks + u) * LT + l) * 512, 0));
+                    acc[l] = mfma_f64(a[u], mv, acc[l]);
+                }
         }
         for (; ks < nks_t; ++ks) {
-            const double a = Rp[(size_t)ks * 4 * ldr];
+            const double a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
 #pragma unroll
-            for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a, Mp[(ks * LT + l) * 64], acc[l]);
+            for (int l = 0; l < LT; ++l) {
+                const double mv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                    rsM, mvoff, (ks * LT + l) * 512, 0));
+                acc[l] = mfma_f64(a, mv, acc[l]);
+            }
         }
 #pragma unroll
         for (int l = 0; l < LT; ++l) {
@@ -965,9 +987,25 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             if (b < B && k < L) {
                 const size_t o = (size_t)b * L + k;
                 if (out) out[o] = sum[l][i];
-                else { usum[o] += sum[l][i]; usq[o] += sq[l][i]; }
+                else if (psum) {
+                    const size_t po = (size_t)blockIdx.y * B * L + o;
+                    psum[po] = sum[l][i];
+                    psq[po] = sq[l][i];
+                } else { usum[o] += sum[l][i]; usq[o] += sq[l][i]; }
             }
         }
+}
+
+// usum += sum_s psum[s], usq += sum_s psq[s] in split order.
+__global__ void k_add_splits(const double* __restrict__ psum, const double* __restrict__ psq, int nsplit,
+                             long long count, double* __restrict__ usum, double* __restrict__ usq)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double a = usum[i], q = usq[i];
+    for (int s = 0; s < nsplit; ++s) { a += psum[(size_t)s * count + i]; q += psq[(size_t)s * count + i]; }
+    usum[i] = a;
+    usq[i] = q;
 }
 
 // ---------------------------------------------------------------------------

@@ -604,6 +604,8 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
     if (method == PLSX_REGRESSION && T > 64)
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS on the device supports at most 64 Y columns");
+    if ((long long)B + Tp > 2000000LL)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
     if (Tp > PLSX_MAX_TP) {
         char msg[160];
         snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the on-chip solver limit %d", Tp,

@@ -221,6 +221,14 @@ int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum,
                   const double* d_usq, int n, int add_orig, long long count,
                   double* d_bsr, double* d_se, void* stream);
 
+/* Percentile interval of many series -- compute.boot_ci (pyls/compute.py:184-209,
+ * numpy.percentile, default 'linear' interpolation).  d_data (nseries, n)
+ * contiguous series; the two quantiles are given by their virtual index
+ * (i, g) = (floor((n-1) q), fractional part) as numpy computes them.
+ * d_lo, d_hi (nseries,) out.  n <= 16384. */
+int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, int n, int i_lo, double g_lo,
+                       int i_hi, double g_hi, double* d_lo, double* d_hi, void* stream);
+
 /* On-box fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64, 8
  * independent accumulators per wave): measured TFLOP/s -> *tflops. */
 int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops);

@@ -1175,6 +1175,29 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops)
     return PLSX_OK;
 }
 
+int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, int n, int i_lo, double g_lo,
+                       int i_hi, double g_hi, double* d_lo, double* d_hi, void* stream)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_data || !d_lo || !d_hi || nseries < 1 || n < 1 || i_lo < 0 || i_hi < 0 || i_lo >= n || i_hi >= n)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_percentile_ci: bad arguments");
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    if (p2 > 16384) return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_percentile_ci: more than 16384 values per series");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t lds = (size_t)p2 * 8;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_percentile2),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_percentile2, dim3((unsigned)nseries), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       d_data, n, p2, i_lo, g_lo, i_hi, g_hi, d_lo, d_hi);
+    LAUNCHCHK();
+    return PLSX_OK;
+}
+
 int plsx_set_timing(plsx_ctx* ctx, int enable)
 {
     if (!ctx) return PLSX_ERR_ARG;

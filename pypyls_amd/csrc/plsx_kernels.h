@@ -1288,6 +1288,60 @@ void k_cv_final(const double* __restrict__ Q /* [m*J][Tp][S] */, const double* _
     }
 }
 
+// ---------------------------------------------------------------------------
+// percentile confidence intervals (compute.boot_ci, pyls/compute.py:184-209)
+// ---------------------------------------------------------------------------
+// One block per series (n values, contiguous): bitonic sort in LDS, then
+// numpy's default 'linear' percentile: value = lerp(a[i], a[i+1], g) with
+// lerp = a + (b - a) g for g < 0.5 and b - (b - a)(1 - g) otherwise (numpy
+// lib/_function_base_impl._lerp).  The virtual indices (i, g) of the two
+// quantiles are computed on the host exactly as numpy does.
+__global__ __launch_bounds__(256)
+void k_percentile2(const double* __restrict__ data, int n, int npow2,
+                   int i_lo, double g_lo, int i_hi, double g_hi,
+                   double* __restrict__ out_lo, double* __restrict__ out_hi)
+{
+    extern __shared__ double sv[];
+    __shared__ int s_nan;
+    const int tid = threadIdx.x;
+    const double* src = data + (size_t)blockIdx.x * n;
+    if (tid == 0) s_nan = 0;
+    __syncthreads();
+    int has_nan = 0;
+    for (int i = tid; i < npow2; i += blockDim.x) {
+        double v = (i < n) ? src[i] : __builtin_inf();
+        if (v != v) { has_nan = 1; v = __builtin_inf(); }
+        sv[i] = v;
+    }
+    if (has_nan) s_nan = 1;
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += blockDim.x) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const double a = sv[i], b = sv[p];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { sv[i] = b; sv[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid < 2) {
+        const int i0 = tid ? i_hi : i_lo;
+        const double g = tid ? g_hi : g_lo;
+        const double a = sv[i0], b = sv[min(i0 + 1, n - 1)];
+        double diff = b - a;
+        // numpy rounds the product and the sum separately: keep hipcc from
+        // contracting them into one fma
+        double prod = (g >= 0.5) ? diff * (1.0 - g) : diff * g;
+        asm volatile("" : "+v"(prod));
+        double r = (g >= 0.5) ? b - prod : a + prod;
+        if (s_nan) r = __builtin_nan("");
+        (tid ? out_hi : out_lo)[blockIdx.x] = r;
+    }
+}
+
 // fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave,
 // 4 waves per block; used to confirm the fp64 matrix peak on the box.
 __global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ out, int iters)

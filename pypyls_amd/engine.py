@@ -64,6 +64,7 @@ def _load():
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
         'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
+        'plsx_percentile_ci': ([vp, vp, ctypes.c_longlong, i32, i32, c_d, i32, c_d, vp, vp, vp], i32),
         'plsx_simpls_decompose': ([vp, vp, vp, vp, vp, vp], i32),
         'plsx_simpls_set_original': ([vp, vp, vp], i32),
         'plsx_simpls_perm_batch': ([vp, vp, i32, vp, vp], i32),
@@ -86,7 +87,7 @@ def exported_symbols():
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
              'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak',
-             'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
+             'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks']
     return [n for n in names if hasattr(lib, n)]
 
@@ -393,6 +394,29 @@ class Engine(object):
                                            self._stream()))
         self.sync()
         return bsr.cpu().numpy(), se.cpu().numpy()
+
+    def percentile_ci(self, boot, ci=95):
+        """compute.boot_ci on the device: boot (..., n) -> lower, upper (...)."""
+        boot = np.ascontiguousarray(boot, dtype=np.float64)
+        n = boot.shape[-1]
+        if n > 16384:                                   # longer series: numpy on the host
+            low = (100 - ci) / 2
+            lo, hi = np.percentile(boot, [low, 100 - low], axis=-1)
+            return lo, hi
+        low = (100 - ci) / 2
+        idx = []
+        for q in (low, 100 - low):                      # numpy's virtual index of the quantile
+            vi = (n - 1) * np.true_divide(q, 100)
+            prev = np.floor(vi)
+            idx.append((int(prev), float(vi - prev)))
+        d = self._dev(boot.reshape(-1, n), np.float64)
+        lo, hi = self._empty((d.shape[0],)), self._empty((d.shape[0],))
+        self._check(self.lib.plsx_percentile_ci(self.ctx, d.data_ptr(), d.shape[0], n, idx[0][0], idx[0][1],
+                                                idx[1][0], idx[1][1], lo.data_ptr(), hi.data_ptr(),
+                                                self._stream()))
+        self.sync()
+        shp = boot.shape[:-1]
+        return lo.cpu().numpy().reshape(shp), hi.cpu().numpy().reshape(shp)
 
     # -- measurement --------------------------------------------------------
     def mfma_f64_peak(self):

@@ -32,10 +32,12 @@ def _as_float_array(A, name):
     A = np.asarray(A)
     if A.ndim != 2:
         raise ValueError('Expected 2D array for `{}`, got {}D array instead'.format(name, A.ndim))
-    A = A.astype(np.float64, copy=False)
+    return A.astype(np.float64, copy=False)
+
+
+def _check_finite(A, name):
     if not np.all(np.isfinite(A)):
         raise ValueError('Input `{}` contains NaN, infinity or a value too large'.format(name))
-    return A
 
 
 class _PLSCRun(object):
@@ -78,6 +80,14 @@ class _PLSCRun(object):
                      covariance=bool(inp.get('covariance')))
         L = eng.L
         res = PLSResults(inputs=inp)
+        # finite-input check (sklearn check_X_y in compute.xcorr, compute.py:78):
+        # a NaN / inf anywhere in a column of X makes the device column mean
+        # non-finite, which avoids a host pass over the (S, B) matrix
+        xmean = eng.colmean()
+        if not np.all(np.isfinite(xmean)):
+            raise ValueError('Input `X` contains NaN, infinity or a value too large')
+        if Y is not None:
+            _check_finite(Y, 'Y')
 
         # ---- original decomposition (BasePLS.svd, base.py:362-364) -------
         # the reference's randomized_svd consumes normal((L, L + 10)) from
@@ -86,7 +96,6 @@ class _PLSCRun(object):
         xw, sv, yw = eng.decompose()
         xw, yw = hostmath.sign_convention(xw, yw)
         eng.set_original(xw, sv, yw)
-        xmean = eng.colmean()
         res['x_weights'], res['y_weights'] = xw, yw
         res['x_scores'] = eng.project(xw) + (xmean @ xw)[None, :]
         rank, world = parallel.rank_world()
@@ -214,7 +223,7 @@ class _PLSCRun(object):
                 res['bootres'].update(dict(
                     x_weights_normed=bsr, x_weights_stderr=se,
                     y_loadings=res['y_loadings'].copy(), y_loadings_boot=distrib,
-                    y_loadings_ci=np.stack(hostmath.boot_ci(distrib, ci=inp.get('ci', 95)), -1),
+                    y_loadings_ci=np.stack(eng.percentile_ci(distrib, ci=inp.get('ci', 95)), -1),
                     bootsamples=bootsamp))
             else:
                 # no add-back, n_boot (meancentered.py:162-164)
@@ -222,7 +231,7 @@ class _PLSCRun(object):
                 res['bootres'].update(dict(
                     x_weights_normed=bsr, x_weights_stderr=se, bootsamples=bootsamp,
                     contrast=contrast, contrast_boot=distrib,
-                    contrast_ci=np.stack(hostmath.boot_ci(distrib, ci=inp.get('ci', 95)), -1)))
+                    contrast_ci=np.stack(eng.percentile_ci(distrib, ci=inp.get('ci', 95)), -1)))
 
         # ---- cross-validation (behavioral.py:219-221, 82-170) ----------------
         if (self.method == 'behavioral' and inp.get('test_split') is not None

@@ -204,7 +204,7 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         res['bootres'].update(dict(
             x_weights_normed=bsr, x_weights_stderr=se, y_loadings=res['y_loadings'],
             y_loadings_boot=distrib,
-            y_loadings_ci=np.stack(hostmath.boot_ci(distrib, ci=ci), -1),
+            y_loadings_ci=np.stack(eng.percentile_ci(distrib, ci=ci), -1),
             bootsamples=bootsamples_out if third is not None else bootsamp))
     res['varexp'] = pctvar                                          # regression.py:425-426
     return res

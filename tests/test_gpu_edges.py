@@ -139,3 +139,40 @@ def test_full_size_properties():
     eng2 = _engine()
     eng2.set_data(X[order], Y[order], rsmp.cell_of_row([S], 1), 1, 1, 0)
     np.testing.assert_allclose(eng2.decompose()[1], sv, rtol=1e-10)
+
+
+@pytest.mark.parametrize('n', [1, 2, 7, 100, 1000, 5000, 16384])
+def test_percentile_ci_matches_numpy(n):
+    """Device bitonic-sort percentile == numpy.percentile (linear), bit for bit."""
+    rs = np.random.RandomState(n)
+    boot = rs.randn(3, 5, n)
+    if n >= 7:
+        boot[1, 2, :3] = boot[1, 2, 3]                      # ties
+    eng = _engine()
+    for ci in (95, 90, 50):
+        lo, hi = eng.percentile_ci(boot, ci=ci)
+        wlo, whi = ref.boot_ci(boot, ci=ci)
+        np.testing.assert_array_equal(lo, wlo)
+        np.testing.assert_array_equal(hi, whi)
+    boot[0, 0, 0] = np.nan
+    lo, hi = eng.percentile_ci(boot)
+    assert np.isnan(lo[0, 0]) and np.isnan(hi[0, 0]) and np.isfinite(lo[1, 1])
+
+
+def test_nonfinite_input_rejected():
+    import pypyls_amd as pls
+    rs = np.random.RandomState(0)
+    X, Y = rs.rand(30, 40), rs.rand(30, 3)
+    Xb = X.copy()
+    Xb[4, 7] = np.nan
+    with pytest.raises(ValueError):
+        pls.behavioral_pls(Xb, Y, n_perm=0, n_boot=0, test_split=0)
+    Xb[4, 7] = np.inf
+    with pytest.raises(ValueError):
+        pls.behavioral_pls(Xb, Y, n_perm=0, n_boot=0, test_split=0)
+    Yb = Y.copy()
+    Yb[2, 1] = np.nan
+    with pytest.raises(ValueError):
+        pls.behavioral_pls(X, Yb, n_perm=0, n_boot=0, test_split=0)
+    with pytest.raises(ValueError):
+        pls.meancentered_pls(Xb, groups=[15, 15], n_perm=0, n_boot=0)

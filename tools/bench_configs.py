@@ -74,6 +74,19 @@ def c5():
                 resamples_per_s=10000 / dt, note='front-end call; SIMPLS in the dual space')
 
 
+def c4():
+    """End-to-end front-end call at the headline shape (includes index generation,
+    H2D of X, original decomposition, D2H of the (B, L) results, percentile CIs)."""
+    import pypyls_amd as pls
+    X, Y = synth(500, 200000, 50)
+    pls.behavioral_pls(X, Y, n_perm=56, n_boot=56, test_split=0, seed=1, verbose=False)
+    t0 = time.perf_counter()
+    res, dt = timed(lambda: pls.behavioral_pls(X, Y, n_perm=5000, n_boot=5000, test_split=0, seed=1234,
+                                               verbose=False))
+    return dict(config='c4 behavioral X(500x200000) Y(500x50) 5000+5000, seed only (front-end wall time)',
+                seconds=dt, resamples_per_s=10000 / dt, pval0=float(res.permres.pvals[0]))
+
+
 def _c4_engine():
     from pypyls_amd import resampling, hostmath
     from pypyls_amd.engine import Engine

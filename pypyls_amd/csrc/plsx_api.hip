@@ -602,8 +602,9 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: mean_centering must be 0, 1 or 2");
     const int J = n_groups * n_cond;
     const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
-    if (method == PLSX_REGRESSION && T > 64)
-        return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS on the device supports at most 64 Y columns");
+    if (method == PLSX_REGRESSION && (size_t)T * (T | 1) * 8 + 20 * (size_t)S + 16 * T + 256 > 160 * 1024)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED,
+                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
     if ((long long)B + Tp > 2000000LL)
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
     if (Tp > PLSX_MAX_TP) {
@@ -1008,7 +1009,8 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.okx = ctx->has_okx ? ptr<uint8_t>(ctx->okx) : nullptr;
     a.oky = (ctx->has_oky && !ystack) ? ptr<uint8_t>(ctx->oky) : nullptr;
     a.xsrc = xsrc; a.ysrc = ysrc;
-    a.work_stride = (size_t)S * (3 * T + 4 * k + 4);
+    const int ldh = T | 1;
+    a.work_stride = (size_t)S * (3 * T + 4 * k + 4) + (size_t)T * ldh;
     if (int e = ensure(ctx, ctx->swork, (size_t)nres * a.work_stride * 8)) return e;
     a.work = ptr<double>(ctx->swork);
     a.pctvar = pctvar; a.yload = yload; a.cvec = cvec;
@@ -1018,9 +1020,10 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         a.lay.n = ctx->npg; a.lay.Tp = ctx->Tp; a.lay.J = 1; a.lay.T = T; a.lay.MT = ctx->MT;
         a.lay.w0 = ctx->w0; a.lay.sq0 = ctx->sq0; a.lay.Tpp = ctx->Tpp;
     }
-    const int ldh = T | 1;
-    const size_t lds = ((size_t)S + 3 * (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)3 * S * 4 + 64;
-    if (lds > 160 * 1024) return fail(ctx, PLSX_ERR_UNSUPPORTED, "SIMPLS: S / T too large for the on-chip solver");
+    const size_t lds = ((size_t)S + (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)3 * S * 4 + 64;
+    if (lds > 160 * 1024)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED,
+                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
     static size_t configured = 0;
     if (lds > configured) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_simpls_dual),

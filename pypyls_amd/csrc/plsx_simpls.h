@@ -90,9 +90,7 @@ void k_simpls_dual(SimplsArgs a)
     const int ldh = T | 1;
     // LDS carve
     double* vc = sm_p;                       // [S]
-    double* H = vc + S;                      // T x ldh
-    double* Vj = H + (size_t)T * ldh;        // T x ldh
-    double* Hw = Vj + (size_t)T * ldh;       // T x ldh (Jacobi working copy)
+    double* Hw = vc + S;                     // T x ldh (Jacobi working copy of H)
     double* gv = Hw + (size_t)T * ldh;       // [T]
     double* cv = gv + T;                     // [T]
     double* red = cv + T;                    // [16]
@@ -114,6 +112,7 @@ void k_simpls_dual(SimplsArgs a)
     double* vz = va + S;                     // [S]
     double* vu = vz + S;                     // [S]
     double* vb = vu + S;                     // [S]
+    double* H = vb + S;                      // T x ldh  = Yd^T K_r Yd (kept in L2; only Hw is on chip)
 
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
     double cnt = 0.0;
@@ -158,15 +157,13 @@ void k_simpls_dual(SimplsArgs a)
     __syncthreads();
 
     for (int c = 0; c < k; ++c) {
-        // ---- leading eigenpair of H (T x T, symmetric PSD) by one-sided Jacobi
-        for (int idx = tid; idx < T * ldh; idx += NT) {
-            const int col = idx / ldh, row = idx % ldh;
-            Vj[idx] = (row == col) ? 1.0 : 0.0;
-        }
-        // Jacobi overwrites its input: work on a copy of H
+        // ---- leading eigenpair of H (T x T, symmetric PSD) by one-sided Jacobi on a
+        // copy.  The rotations need not be accumulated: at convergence column j
+        // of the copy is H v_j = lambda_j v_j, so the eigenvector is that column
+        // normalised (same sign as v_j, lambda_j > 0).
         for (int idx = tid; idx < T * ldh; idx += NT) Hw[idx] = H[idx];
         __syncthreads();
-        jacobi_cols(Hw, T, Vj, T, T, ldh, &s_flag);
+        jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag);
         // eigenvalues = column norms of (H V); pick the largest
         for (int col = tid; col < T; col += NT) {
             double s = 0.0;
@@ -179,7 +176,7 @@ void k_simpls_dual(SimplsArgs a)
         const double lam = gv[best];
         const double si = sqrt(lam);
         for (int t = tid; t < T; t += NT) {
-            cv[t] = Vj[best * ldh + t];
+            cv[t] = Hw[best * ldh + t] / lam;
             a.cvec[((size_t)r * T + t) * k + c] = cv[t];
         }
         __syncthreads();

@@ -96,7 +96,8 @@ def main():
 
     S, B, T = args.S, args.B, args.T
     X, Y = synth(S, B, T)
-    eng = Engine()
+    # long-lived engine: fixed 48 GB super-batch scratch, mapped during warm-up
+    eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
     eng.set_data(X, Y, resampling.cell_of_row([S], 1), 1, 1, 0)
     xw, sv, yw = eng.decompose()
     xw, yw = hostmath.sign_convention(xw, yw)
@@ -117,9 +118,19 @@ def main():
     usum = torch.zeros((B, L), dtype=torch.float64, device=dev)
     usq = torch.zeros((B, L), dtype=torch.float64, device=dev)
 
-    def step(i):
+    leg_events = []
+
+    def step(i, timed=False):
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         eng.perm_into(perm_idx[i], out_sv, rotate=True)
+        if timed:
+            ev[1].record()
         eng.boot_into(boot_idx[i], usum, usq, dist_out)
+        if timed:
+            ev[2].record()
+            leg_events.append(ev)
 
     for i in range(args.warmup):
         step(i)
@@ -130,7 +141,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
-        step(i)
+        step(i, timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -153,7 +164,10 @@ def main():
         # processes `launch_units` resamples.
         launches = max(int(timing.get('xprod_launches', 0)), 1)
         avg_ms = timing.get('xprod_ms', 0.0) / launches
-        units_per_launch = per_step * args.steps / launches
+        dual = bool(timing.get('dual_perm', 0))
+        # resamples the timed k_xprod launches covered (bootstraps only when the
+        # permutations take the dual S x S path and launch no k_xprod at all)
+        units_per_launch = timing.get('xprod_resamples', per_step * args.steps) / launches
         flops_launch = 2.0 * S * Tp * B * units_per_launch
         achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
@@ -164,13 +178,23 @@ def main():
                 traffic = tj.get('hbm_bytes_per_launch') * units_per_launch / tj.get('resamples_per_launch')
             except Exception:
                 traffic = None
-        # whole-pipeline fractions: perm and boot flops / bytes per resample
-        wf_perm = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B
-        wf_boot = wf_perm + 4.0 * Tp * L * B
-        wb = 8.0 * S * (B + Tp)
-        rate_gpu = value / world
-        frac_mfma = rate_gpu * 0.5 * (wf_perm + wf_boot) / (PEAK_FP64_MFMA_TFLOPS * 1e12)
-        frac_hbm = rate_gpu * wb / (PEAK_HBM_TBS * 1e12)
+        # whole-pipeline fractions: algorithmic flops / bytes of THIS formulation
+        # (DESIGN.md section 5).  Bootstrap: cross-product + Gram + R.U0 + U
+        # rotation, all O(B).  Permutation: O(B) only without the dual path;
+        # with it, the S x S kernel once per call plus O(T' S^2) per permutation.
+        wf_boot = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
+        wb_boot = 8.0 * S * (B + Tp)
+        if dual:
+            wf_perm = 2.0 * Tp * S * S + 2.0 * Tp * Tp * S + 2.0 * S * S * B / max(args.perms, 1)
+            wb_perm = 8.0 * (S * B / max(args.perms, 1) + 3.0 * Tp * S)
+        else:
+            wf_perm = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B
+            wb_perm = wb_boot
+        steps_per_s = args.steps / elapsed
+        frac_mfma = steps_per_s * (args.perms * wf_perm + args.boots * wf_boot) / (PEAK_FP64_MFMA_TFLOPS * 1e12)
+        frac_hbm = steps_per_s * (args.perms * wb_perm + args.boots * wb_boot) / (PEAK_HBM_TBS * 1e12)
+        perm_ms = sum(e[0].elapsed_time(e[1]) for e in leg_events) / max(len(leg_events), 1)
+        boot_ms = sum(e[1].elapsed_time(e[2]) for e in leg_events) / max(len(leg_events), 1)
         out = {
             'metric': 'resamples/sec (perm+boot), behavioral_pls X({}x{})/Y({}x{}) fp64'
                       .format(S, B, S, T),
@@ -182,6 +206,8 @@ def main():
                                    'shape on {} GPU(s)), n_split=0, test_split=0'
                                    .format(S, B, S, T, world),
                        'perms_per_step_per_gpu': args.perms, 'boots_per_step_per_gpu': args.boots,
+                       'perm_path': 'dual (S x S kernel)' if dual else 'feature pass',
+                       'perm_ms_per_step': perm_ms, 'boot_ms_per_step': boot_ms,
                        'parallelism': 'resample-sharded x{}'.format(world)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_xprod<{}>'.format(int(timing.get('m_tiles', 0))),
                          'achieved': achieved, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -236,8 +236,22 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops);
 /* Performance counters of the last perm/boot call: fills up to `cap` doubles:
  * [0] kernel ms of the cross-product kernel (HIP events on the launch stream),
  * [1] its launch count, [2] resamples per launch group, [3] M tiles per block,
- * [4] super-batch size. Returns the number written. */
+ * [4] super-batch size, [5] resamples those launches covered, [6] 1 if
+ * permutations take the dual (S x S kernel) path and launch no cross-product
+ * kernel. Returns the number written. */
 int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
+/* Scratch budget of the resampling super-batches (default 48 GB; the R block
+ * of one bootstrap is 8 T' B bytes).  fixed = 1: every launch uses budget-sized
+ * super-batches -- the steady-state setting for a long-lived context (what
+ * bench.py measures).  fixed = 0 (default): the super-batch of a call is sized
+ * by a cost model that weighs mapping fresh device memory (the driver clears
+ * recycled VRAM, 30-70 ms per GB) against the per-launch overhead, so a
+ * one-shot run of a few thousand resamples maps a few GB instead of 48.
+ * Must precede plsx_set_data.  The environment variable PLSX_SCRATCH_GB=<gb>
+ * is equivalent to plsx_set_scratch(ctx, gb, 1).  No reference counterpart
+ * (joblib workers size themselves, pyls/base.py:490-507). */
+int plsx_set_scratch(plsx_ctx* ctx, double max_gb, int fixed);
+
 /* Enable (1) / disable (0) event timing of the cross-product kernel. */
 int plsx_set_timing(plsx_ctx* ctx, int enable);
 

@@ -2,6 +2,7 @@
 // C ABI declared in include/plsx.h.  gfx950 only.
 #include "plsx_kernels.h"
 #include "plsx_simpls.h"
+#include <chrono>
 #include "../../include/plsx.h"
 
 #include <algorithm>
@@ -44,6 +45,8 @@ struct plsx_ctx {
     Buf Kmat, swork, spct, sc;                          // SIMPLS: K = Xc Xc^T, dual-solver scratch
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
+    Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
+    int dual = 0;
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
     bool has_okx = false, has_oky = false;
@@ -53,6 +56,10 @@ struct plsx_ctx {
     int timing = 0;
     int variant = 0;        // cross-product kernel variant (PLSX_XPROD_VARIANT, tuning only)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    long long timed_units = 0;
+    double scratch_gb = 48.0;                           // super-batch scratch budget
+    int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
+                          // resamples covered by the timed launches
     double last_ms = 0.0;
     int last_launches = 0;
 };
@@ -82,12 +89,23 @@ int fail(plsx_ctx* c, int code, const std::string& msg)
 int ensure(plsx_ctx* ctx, Buf& b, size_t bytes, bool zero = false)
 {
     if (b.bytes < bytes) {
+        static const bool trace = getenv("PLSX_TRACE_ALLOC") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
         if (b.p) HIPCHK(hipFree(b.p));
+        auto t1 = std::chrono::steady_clock::now();
         b.p = nullptr;
         b.bytes = 0;
         HIPCHK(hipMalloc(&b.p, bytes));
+        auto t2 = std::chrono::steady_clock::now();
         b.bytes = bytes;
         if (zero) HIPCHK(hipMemset(b.p, 0, bytes));
+        if (trace) {
+            HIPCHK(hipDeviceSynchronize());
+            auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
+            fprintf(stderr, "[plsx alloc] %.3f GB: free %.1f ms, malloc %.1f ms, zero %.1f ms\n",
+                    bytes / 1073741824.0, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+        }
     }
     return 0;
 }
@@ -130,8 +148,7 @@ void plan_groups(plsx_ctx* c)
     int g = round_up(std::max(1, ceil_div(2048, ncolblk)), 8);
     g = std::max(g, round_up(ceil_div(512, std::max(best, 1)), 8));
     g = std::min(std::max(g, 8), 128);
-    const char* env = getenv("PLSX_SCRATCH_GB");
-    const double budget = (env ? atof(env) : 48.0) * 1073741824.0;
+    const double budget = c->scratch_gb * 1073741824.0;
     while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);
     c->Gcap = g;
 }
@@ -172,6 +189,31 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
     if (int e = ensure(ctx, ctx->Mfrag, nb * ctx->nks_t * ctx->LT * 64 * 8)) return e;
     ctx->Galloc = groups;
     return 0;
+}
+
+// Groups per launch for a call that processes `units` resamples packed
+// `per_group` to a group.  A fixed budget (plsx_set_scratch / PLSX_SCRATCH_GB)
+// always launches budget-sized super-batches: best steady-state throughput for
+// a long-lived context.  Otherwise the size weighs the cost of mapping device
+// memory against the fixed cost per launch (~2.5 ms: one wave of the
+// latency-bound small solver plus fills).  Mapping is not free on a shared
+// MI355X: the driver clears recycled VRAM lazily, and a request that outgrows
+// the pool of already-clean pages (a few tens of GB) stalls for ~25 ms per GB
+// of dirty memory on the device -- seconds, measured 2-6 s -- which a one-shot
+// call of a few thousand resamples should not pay to compute for one second.
+// The model prices that at 40 ms per GB requested.  Scratch that is already
+// mapped is always used in full.
+int launch_groups(plsx_ctx* ctx, long long units, int per_group)
+{
+    const long long need = (units + per_group - 1) / std::max(per_group, 1);
+    const int cap = (int)std::max<long long>(1, std::min<long long>(ctx->Gcap, need));
+    if (ctx->scratch_fixed) return cap;
+    const double gb_per_group = (double)std::max(ctx->npg, ctx->npgf) * ctx->Tpp * (double)ctx->Bpad * 8.0 /
+                                1073741824.0;
+    const double c_group = 40.0 * gb_per_group, c_launch = 2.5;
+    int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
+    g = std::max(g, ctx->Galloc);
+    return std::max(1, std::min(g, cap));
 }
 
 template <int MT, int NW, int KT, int NSQ, int DBG = 0>
@@ -242,6 +284,7 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
 {
     const int groups = ceil_div(nres, ctx->npgf);
     if (int e = ensure_scratch(ctx, groups)) return e;
+    if (ctx->timing) ctx->timed_units += nres;
     HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride_f * 8, st));
     GroupLayout lay;
     lay.n = ctx->npgf; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MTf;
@@ -293,6 +336,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
 {
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
+    if (ctx->timing) ctx->timed_units += nres;
     if (prebuilt) return launch_xprod(ctx, groups, st);       // A already scattered by the caller
     HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
     GroupLayout lay;
@@ -543,6 +587,9 @@ int plsx_ctx_create(int device, plsx_ctx** out)
     plsx_ctx* c = new (std::nothrow) plsx_ctx();
     if (!c) return PLSX_ERR_HIP;
     c->device = device;
+    if (const char* env = getenv("PLSX_SCRATCH_GB")) {
+        if (atof(env) > 0.0) { c->scratch_gb = atof(env); c->scratch_fixed = 1; }
+    }
     *out = c;
     return PLSX_OK;
 }
@@ -558,7 +605,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -692,6 +739,12 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
             }
         }
     }
+    {
+        // dual permutation path: needs a resample-independent feature matrix
+        const char* nd = getenv("PLSX_NO_DUAL_PERM");
+        ctx->dual = (!(nd && atoi(nd)) &&
+                     (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->fix || ctx->cov)))) ? 1 : 0;
+    }
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
     if (int e = ensure(ctx, ctx->d0, (size_t)ctx->L * 8)) return e;
@@ -723,7 +776,7 @@ int plsx_crosscov_batch(plsx_ctx* ctx, const int32_t* d_xsrc, const int32_t* d_y
     if (n < 1 || !d_R) return fail(ctx, PLSX_ERR_ARG, "plsx_crosscov_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int nb = ctx->Gcap * ctx->npg;
+    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* xs = d_xsrc ? d_xsrc + (size_t)off * ctx->S : nullptr;
@@ -814,12 +867,76 @@ int plsx_perm_batch_y(plsx_ctx* ctx, const double* d_ystack, int n, int rotate, 
 }
 
 namespace {
+// Dual permutation path.  A permutation leaves the feature side untouched
+// (behavioral PLS permutes Y, base.py:599; mean-centred PLS permutes the rows
+// of X but applies no per-feature scaling, meancentered.py:125), so its
+// cross-covariance is R_p = A_p . Xf with ONE fixed feature matrix Xf (the
+// cell-z-scored X, or the centred X for covariance / mean-centred PLS) and the
+// permutation statistic -- singular values of R_p, optionally Procrustes-rotated
+// on the T' side (base.py:683-712) -- needs only the Gram matrix
+//     G_p = R_p R_p^T = A_p (Xf Xf^T) A_p^T = A_p K A_p^T,   K = Xf Xf^T  (S x S).
+// K is formed once per call (one pass over X); every permutation then costs
+// O(T' S^2) instead of O(T' S B).
+int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int n, int rotate,
+              double* d_out_sv, hipStream_t st)
+{
+    const int S = ctx->S, Tp = ctx->Tp, Sd = round_up(S, 8);
+    if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
+    const double* Xf = ctx->fix ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
+    if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
+                       ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
+        return e;
+    // resamples per pass: 2 GB operands, grid.y / grid.z limits of the tiled GEMM
+    long long nb = std::min<long long>(32768, (2LL << 30) / ((long long)Tp * Sd * 8));
+    nb = std::min<long long>(nb, 60000LL * 64 / ((long long)Tp * ceil_div(S, 64)));
+    nb = std::max<long long>(nb, 1);
+    GroupLayout lay;
+    memset(&lay, 0, sizeof(lay));
+    lay.n = 1; lay.Tp = Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT; lay.Tpp = ctx->Tpp;
+    for (int off = 0; off < n; off += (int)nb) {
+        const int m = std::min<int>((int)nb, n - off);
+        const size_t abytes = (size_t)m * Tp * Sd * 8;
+        if (int e = ensure(ctx, ctx->Ad, abytes)) return e;
+        if (int e = ensure(ctx, ctx->Wd, abytes)) return e;
+        if (int e = ensure(ctx, ctx->Gm, (size_t)m * Tp * Tp * 8)) return e;
+        HIPCHK(hipMemsetAsync(ctx->Ad.p, 0, abytes, st));
+        const int* idx = d_perm_idx ? d_perm_idx + (size_t)off * S : nullptr;
+        if (ctx->method == PLSX_BEHAVIORAL) {
+            const double* yst = d_ystack ? d_ystack + (size_t)off * S * ctx->T : nullptr;
+            hipLaunchKernelGGL(k_build_A_behav, dim3(m, ctx->J), dim3(256), (size_t)2 * ctx->T * 8, st,
+                               yst ? yst : ptr<double>(ctx->Y), yst ? (long long)S * ctx->T : 0LL, ctx->T, S,
+                               ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), (const int*)nullptr, idx,
+                               lay, ctx->cov, 0, ptr<double>(ctx->Ad), (size_t)0, (double*)nullptr, 0, Sd);
+        } else {
+            hipLaunchKernelGGL(k_build_A_mc, dim3(m), dim3(256), 0, st, S, ctx->J, ctx->n_cond, ctx->mc,
+                               ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd);
+        }
+        LAUNCHCHK();
+        // W = A K  (all permutations stacked: (m T') x S)
+        if (int e = run_nt(ctx, ptr<double>(ctx->Ad), 0, Sd, m * Tp, ptr<double>(ctx->Kd), 0, Sd, S,
+                           nullptr, 0, 0, 0, S, 1, ptr<double>(ctx->Wd), 0, Sd, nullptr, 0, 0, st))
+            return e;
+        // G_p = W_p A_p^T
+        if (int e = run_nt(ctx, ptr<double>(ctx->Wd), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->Ad),
+                           (long long)Tp * Sd, Sd, Tp, nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Gm),
+                           (long long)Tp * Tp, Tp, nullptr, 0, 0, st))
+            return e;
+        SmallArgs a = small_args(ctx, SMALL_PERM);
+        a.rotate = rotate ? 1 : 0;
+        a.out_sv = d_out_sv + (size_t)off * ctx->L;
+        if (int e = run_small(ctx, a, m, st)) return e;
+    }
+    return PLSX_OK;
+}
+
 int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int n, int rotate,
                     double* d_out_sv, void* stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int nb = ctx->Gcap * (ctx->fix ? ctx->npgf : ctx->npg);
+    if (ctx->dual) return perm_dual(ctx, d_perm_idx, d_ystack, n, rotate, d_out_sv, st);
+    const int pg = ctx->fix ? ctx->npgf : ctx->npg;
+    const int nb = launch_groups(ctx, n, pg) * pg;
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_perm_idx ? d_perm_idx + (size_t)off * ctx->S : nullptr;
@@ -849,7 +966,7 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int nb = ctx->Gcap * ctx->npg;
+    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
@@ -876,7 +993,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     const int S = ctx->S, Tp = ctx->Tp, L = ctx->L;
-    const int nb = ((ctx->Gcap * ctx->npg) / 2) * 2;          // slots per super-batch (pairs of halves)
+    const int nb = ((launch_groups(ctx, 2LL * np * ns, ctx->npg) * ctx->npg) / 2) * 2;   // slots per super-batch (pairs of halves)
     if (nb < 2) return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_split_half_batch: scratch too small");
     if (int e = ensure(ctx, ctx->Rfull, (size_t)ctx->strideR * 8)) return e;
     if (int e = ensure(ctx, ctx->Vp, (size_t)Tp * L * 8)) return e;
@@ -946,7 +1063,7 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
     HIPCHK(hipSetDevice(ctx->device));
     const int S = ctx->S, T = ctx->T, J = ctx->J, Tp = ctx->Tp, L = ctx->L;
     // splits per pass: bounded by the super-batch and by the J rescaled copies kept in R2
-    int nb = std::max(1, std::min(ctx->Gcap * ctx->npg, 256 / std::max(J, 1)));
+    int nb = std::max(1, std::min(launch_groups(ctx, m, ctx->npg) * ctx->npg, 256 / std::max(J, 1)));
     nb = (nb / ctx->npg) * ctx->npg;
     if (nb < ctx->npg) nb = ctx->npg;
     for (int off = 0; off < m; off += nb) {
@@ -1118,7 +1235,7 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const doubl
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     const int k = ctx->ncomp, T = ctx->T;
-    const int nb = ctx->Gcap * ctx->npg;
+    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
     if (int e = ensure(ctx, ctx->spct, (size_t)nb * k * 8)) return e;
     if (int e = ensure(ctx, ctx->sc, (size_t)nb * T * k * 8)) return e;
     for (int off = 0; off < n; off += nb) {
@@ -1201,12 +1318,23 @@ int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, i
     return PLSX_OK;
 }
 
+int plsx_set_scratch(plsx_ctx* ctx, double max_gb, int fixed)
+{
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!(max_gb > 0.0)) return fail(ctx, PLSX_ERR_ARG, "plsx_set_scratch: budget must be positive");
+    if (ctx->has_data) return fail(ctx, PLSX_ERR_STATE, "plsx_set_scratch must precede plsx_set_data");
+    ctx->scratch_gb = max_gb;
+    ctx->scratch_fixed = fixed ? 1 : 0;
+    return PLSX_OK;
+}
+
 int plsx_set_timing(plsx_ctx* ctx, int enable)
 {
     if (!ctx) return PLSX_ERR_ARG;
     ctx->timing = enable ? 1 : 0;
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     ctx->events.clear();
+    ctx->timed_units = 0;
     return PLSX_OK;
 }
 
@@ -1220,9 +1348,9 @@ int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
         if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess)
             ms += t;
     }
-    double vals[5] = {ms, (double)ctx->events.size(), (double)ctx->npg, (double)ctx->MT,
-                      (double)ctx->Gcap * ctx->npg};
-    int n = std::min(cap, 5);
+    double vals[7] = {ms, (double)ctx->events.size(), (double)ctx->npg, (double)ctx->MT,
+                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual};
+    int n = std::min(cap, 7);
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
 }

@@ -111,8 +111,10 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
                                 const int* __restrict__ xsrc, const int* __restrict__ ysrc,
                                 GroupLayout lay, int covariance, int scaled,
                                 double* __restrict__ Afrag, size_t group_stride,
-                                double* __restrict__ mom_n, int nmom_pad)
+                                double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0)
 {
+    // dense_ld != 0: write plain row-major (T' x dense_ld) matrices, one per
+    // resample, instead of k_xprod's fragment order (dual permutation path)
     extern __shared__ double sm_b[];
     const int r = blockIdx.x, j = blockIdx.y;
     const int g = r / lay.n, rr = r % lay.n;
@@ -167,7 +169,8 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
         int yi = ys ? ys[p] : p;
         double v = (Y[(size_t)yi * T + t] - mean[t]) * rstd[t] * inv_nm1;
         int row = rr * lay.Tp + j * T + t;
-        atomicAdd(A + afrag_off(row, xi, lay.MT), v);
+        if (dense_ld) atomicAdd(Afrag + ((size_t)r * lay.Tp + j * T + t) * dense_ld + xi, v);
+        else atomicAdd(A + afrag_off(row, xi, lay.MT), v);
     }
     if (scaled) {
         for (int pl = tid; pl < len; pl += blockDim.x) {
@@ -188,7 +191,7 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
 __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
                              const int* __restrict__ cell_of_pos,
                              const int* __restrict__ xsrc, GroupLayout lay,
-                             double* __restrict__ Afrag, size_t group_stride)
+                             double* __restrict__ Afrag, size_t group_stride, int dense_ld = 0)
 {
     __shared__ int cnt[PLSX_MAX_TP];
     const int r = blockIdx.x;
@@ -221,7 +224,9 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
             } else {
                 coef -= 1.0 / (double)ntot;
             }
-            if (coef != 0.0) atomicAdd(A + afrag_off(rr * lay.Tp + j2, xi, lay.MT), coef);
+            if (coef == 0.0) continue;
+            if (dense_ld) atomicAdd(Afrag + ((size_t)r * lay.Tp + j2) * dense_ld + xi, coef);
+            else atomicAdd(A + afrag_off(rr * lay.Tp + j2, xi, lay.MT), coef);
         }
     }
 }
@@ -1342,17 +1347,24 @@ void k_percentile2(const double* __restrict__ data, int n, int npow2,
     }
 }
 
-// fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave,
+// fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave
+// with distinct operands (identical chains would be merged by the compiler),
 // 4 waves per block; used to confirm the fp64 matrix peak on the box.
 __global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ out, int iters)
 {
     d4 acc[8];
+    double a[8], b[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double a = 1e-3 * (double)(threadIdx.x & 63), b = 1.0 + 1e-6 * (double)blockIdx.x;
-    for (int it = 0; it < iters; ++it) {
+    for (int j = 0; j < 8; ++j) {
+        acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+        a[j] = 1e-3 * (double)((threadIdx.x & 63) + 1) + 0.125 * j;
+        b[j] = 1.0 + 1e-6 * (double)(blockIdx.x + 1) - 0.0625 * j;
+    }
+    for (int it = 0; it < iters; it += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = mfma_f64(a, b, acc[j]);
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = mfma_f64(a[j], b[(j + r) & 7], acc[j]);
     }
     double s = 0.0;
 #pragma unroll

@@ -63,6 +63,7 @@ def _load():
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
+        'plsx_set_scratch': ([vp, c_d, i32], i32),
         'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
         'plsx_percentile_ci': ([vp, vp, ctypes.c_longlong, i32, i32, c_d, i32, c_d, vp, vp, vp], i32),
         'plsx_simpls_decompose': ([vp, vp, vp, vp, vp, vp], i32),
@@ -86,7 +87,7 @@ def exported_symbols():
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
              'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
-             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_mfma_f64_peak',
+             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks']
     return [n for n in names if hasattr(lib, n)]
@@ -101,7 +102,10 @@ class Engine(object):
     """One device context.  All ndarray arguments / results are host numpy
     arrays unless a method says it returns a device tensor."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, scratch_gb=None):
+        """``scratch_gb``: fixed super-batch scratch budget for a long-lived
+        engine (steady-state throughput); None sizes the scratch per call
+        (include/plsx.h, plsx_set_scratch)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise PlsxError('no AMD GPU visible to PyTorch-ROCm: the PLS resampling engine has '
@@ -117,6 +121,8 @@ class Engine(object):
             raise PlsxError('plsx_ctx_create failed with status {}'.format(rc))
         self.ctx = ctx
         self.S = self.B = self.L = self.Tp = 0
+        if scratch_gb is not None:
+            self._check(self.lib.plsx_set_scratch(self.ctx, float(scratch_gb), 1))
 
     # -- plumbing ---------------------------------------------------------
     def close(self):
@@ -431,5 +437,6 @@ class Engine(object):
     def last_timing(self):
         buf = (ctypes.c_double * 8)()
         n = self.lib.plsx_last_timing(self.ctx, buf, 8)
-        keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch']
+        keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch',
+                'xprod_resamples', 'dual_perm']
         return {k: buf[i] for i, k in enumerate(keys[:max(n, 0)])}

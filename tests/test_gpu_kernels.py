@@ -191,3 +191,41 @@ def test_split_half_meancentered():
             u, v = ref.split_half(spec, Xp, Yp, ud, vd, pm[p][:, [i]])
             assert_close(uc[p][live, i], u, 1e-7, what='ucorr')
             assert_close(vc[p][live, i], v, 1e-7, what='vcorr')
+
+
+@pytest.mark.parametrize('case', [
+    dict(S=40, B=300, T=6, groups=[40], n_cond=1),
+    dict(S=46, B=130, T=4, groups=[11, 12], n_cond=2),
+    dict(S=36, B=70, T=5, groups=[12], n_cond=3, covariance=True),
+    dict(S=30, B=7, T=5, groups=[15, 15], n_cond=1),
+    dict(S=48, B=500, groups=[8, 8], n_cond=3, method='meancentered', mc=0),
+    dict(S=48, B=500, groups=[8, 8], n_cond=3, method='meancentered', mc=1),
+    dict(S=48, B=500, groups=[8, 8], n_cond=3, method='meancentered', mc=2),
+])
+@pytest.mark.parametrize('rotate', [True, False])
+def test_dual_perm_path_equals_feature_pass(case, rotate, monkeypatch):
+    """The S x S kernel formulation of the permutation test (G_p = A_p K A_p^T)
+    against the O(B) pass over the features (PLSX_NO_DUAL_PERM=1), and against
+    the oracle's single_perm."""
+    from pypyls_amd import resampling as rsmp, hostmath
+    case = dict(case)
+    method = case.pop('method', 'behavioral')
+    cov, mc = case.pop('covariance', False), case.pop('mc', 0)
+    X, Y, rs = _data(case['S'], case['B'], case.get('T', 3), seed=5)
+    perms = rsmp.gen_permsamp(case['groups'], case['n_cond'], 9, seed=3)
+    got = {}
+    Yo = Y if method == 'behavioral' else None
+    for flag in ('0', '1'):
+        monkeypatch.setenv('PLSX_NO_DUAL_PERM', flag)
+        eng = _engine()
+        spec = _setup(eng, X, Yo, case['groups'], case['n_cond'], method=method, covariance=cov, mc=mc)
+        U, d, V = ref.decompose(spec, X, Yo if Yo is not None else spec.dummy)
+        eng.set_original(U, np.diag(d), V)
+        assert bool(eng.last_timing()['dual_perm']) == (flag == '0')
+        got[flag] = eng.perm(perms, rotate=rotate)
+    live = ref.live_lvs(np.diag(d))
+    assert_close(got['0'][live], got['1'][live], 1e-9, what='dual vs feature pass')
+    spec.rotate = rotate
+    want = np.stack([ref.single_perm(spec, X, Yo if Yo is not None else spec.dummy, perms[:, i], V)[0]
+                     for i in range(perms.shape[1])], -1)
+    assert_close(got['0'][live], want[live], 1e-7, what='dual vs oracle')

@@ -665,6 +665,184 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
         }
 }
 
+// ---------------------------------------------------------------------------
+// K_G4: the same Gram products on v_mfma_f64_4x4x4_4b_f64 (four independent
+// 4x4x4 products per instruction, 16 cycles: the same 32 flop/cycle/SIMD as the
+// 16x16x4 shape -- 74.9 TF/s measured, tools/mfma_4x4_probe.hip).  With 4-row
+// granularity T' = 50 pads to 52 instead of 64, and only the blocks q <= q' of
+// the symmetric G are formed: 260 block products per 4 feature columns and
+// resample (91 of G + 169 of P) = 1040 matrix cycles instead of 32 x 64 = 2048.
+//
+// The four blocks of an instruction are four RESAMPLES (r0 .. r0+3): lane
+// l = 16 k + 4 blk + i holds R[r0+blk][4 q + i][c + k] -- which is at the same
+// time the A operand of row block q and the B operand of column block q
+// (operand layouts, measured: A[blk][i][k] at lane 16k+4blk+i, B[blk][k][j] at
+// lane 16k+4blk+j, D[blk][i][j] at lane 16i+4blk+j).  One register per row
+// block therefore feeds every product it takes part in; U0^T blocks (shared by
+// the four resamples) are the B operands of P.  Each lane loads 16 bytes (the
+// columns of two k-steps, order c+2k+e: any assignment of columns to k-slots
+// is valid as long as both operands agree), so the four k-lanes of a row read
+// 64 contiguous bytes.  The pieces of 8 columns are copied global -> LDS once per
+// block with the LDS-DMA path (buffer_load ... lds: row offsets in VGPRs, the
+// column offset in an SGPR, no staging registers), laid out in operand order so
+// every ds_read_b128 is lane-linear; the U0^T pieces are stored once and
+// broadcast to the four lane groups.  (Loading the operands straight from
+// global memory in every wave was measured SLOWER than the 16x16x4 kernel,
+// 31.0 vs 28.4 ms: four waves re-fetching the same rows saturate the texture
+// path.)  The 260 products are split
+// statically over the 4 waves (wave W owns the U blocks u = W mod 4 and a
+// contiguous range of the G pairs) so every accumulator index is a constant.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double mfma_f64_4x4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+constexpr int g4_nu(int nlb, int w) { return nlb > w ? (nlb - w + 3) / 4 : 0; }
+constexpr int g4_gcount(int nb, int nlb, int w)
+{
+    const int ng = nb * (nb + 1) / 2, total = ng + nb * nlb, target = (total + 3) / 4;
+    int start = 0, cnt = 0;
+    for (int v = 0; v <= w; ++v) {
+        start += cnt;
+        int want = target - nb * g4_nu(nlb, v);
+        if (want < 0) want = 0;
+        cnt = (v == 3) ? ng - start : (want < ng - start ? want : ng - start);
+    }
+    return cnt;
+}
+constexpr int g4_gstart(int nb, int nlb, int w)
+{
+    int start = 0;
+    for (int v = 0; v < w; ++v) start += g4_gcount(nb, nlb, v);
+    return start;
+}
+
+template <int NB, int NLB, int W>
+__device__ __forceinline__ void gram4_wave(double* smem, const double* __restrict__ Rblk, unsigned strideR_b,
+                                           unsigned ldr_b, int Tp, const double* __restrict__ U0T,
+                                           unsigned ldu_b, int L, int cbeg, int cend,
+                                           double* __restrict__ part, int chunk, int r0, int nres, int lane)
+{
+    constexpr int G0 = g4_gstart(NB, NLB, W), GN = g4_gcount(NB, NLB, W), NU = g4_nu(NLB, W);
+    constexpr int NACC = GN + NB * NU;
+    constexpr int NUS = (NLB + 3) / 4, SLOTS = NB + NUS, STAGE = SLOTS * 128;   // doubles per LDS stage
+    constexpr int NDMA = (SLOTS > W) ? (SLOTS - W + 3) / 4 : 0;                 // DMA slots of this wave
+    double acc[NACC > 0 ? NACC : 1];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.0;
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i = lane & 3;
+    const int rb = min(r0 + blk, nres - 1) - r0;                  // clamped resample of this lane group
+    __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)Rblk, (short)0, 0x7fffffff,
+                                                                    PLSX_RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)U0T, (short)0, 0x7fffffff,
+                                                                    PLSX_RSRC_FLAGS);
+    // global byte offsets of the 16-byte pieces this wave copies per stage
+    unsigned doff[NDMA > 0 ? NDMA : 1];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) {
+        const int t = W + 4 * d;
+        if (t < NB) {           // X slot t: lane (k, blk, i) <- R[r0+blk][4t+i][c + 2k .. 2k+1]
+            doff[d] = (unsigned)rb * strideR_b + (unsigned)min(4 * t + i, Tp - 1) * ldr_b + 16u * k;
+        } else {                // U slot: lane -> (u = 4n + (lane>>4), k = (lane>>2)&3, j = lane&3)
+            const int u = 4 * (t - NB) + (lane >> 4);
+            doff[d] = (unsigned)min(4 * u + (lane & 3), L - 1) * ldu_b + 16u * ((lane >> 2) & 3);
+        }
+    }
+    auto issue = [&](int c0, double* buf) {
+        const int so = c0 * 8;
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) {
+            const int t = W + 4 * d;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(t < NB ? rsR : rsU,
+                (__attribute__((address_space(3))) void*)(buf + t * 128), 16, doff[d], so, 0, 0);
+        }
+    };
+    const int nst = (cend - cbeg + 7) / 8;
+    const int cfull = cbeg + ((cend - cbeg) / 8) * 8;
+    issue(cbeg, smem);
+    __syncthreads();
+    const int uslot = k * 4 + i;                 // (k, j) position inside a U block, shared by the 4 resamples
+    for (int st = 0; st < nst; ++st) {
+        const int c0 = cbeg + 8 * st;
+        double* cur = smem + (st & 1) * STAGE;
+        if (st + 1 < nst) issue(c0 + 8, smem + ((st + 1) & 1) * STAGE);
+        d2 x[NB], u[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) x[q] = *reinterpret_cast<const d2*>(cur + (q * 64 + lane) * 2);
+#pragma unroll
+        for (int n = 0; n < NU; ++n)
+            u[n] = *reinterpret_cast<const d2*>(cur + NB * 128 + ((W + 4 * n) * 16 + uslot) * 2);
+        if (c0 >= cfull) {                                     // ragged last step: zero columns >= cend
+            const bool ok0 = c0 + 2 * k < cend, ok1 = c0 + 2 * k + 1 < cend;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) { x[q][0] = ok0 ? x[q][0] : 0.0; x[q][1] = ok1 ? x[q][1] : 0.0; }
+#pragma unroll
+            for (int n = 0; n < NU; ++n) { u[n][0] = ok0 ? u[n][0] : 0.0; u[n][1] = ok1 ? u[n][1] : 0.0; }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int p = 0;
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int q2 = q; q2 < NB; ++q2) {
+                    if (p >= G0 && p < G0 + GN) acc[p - G0] = mfma_f64_4x4(x[q][e], x[q2][e], acc[p - G0]);
+                    ++p;
+                }
+#pragma unroll
+            for (int n = 0; n < NU; ++n)
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    acc[GN + n * NB + q] = mfma_f64_4x4(x[q][e], u[n][e], acc[GN + n * NB + q]);
+        }
+        __syncthreads();         // drains the copy issued above, frees `cur` for the stage after next
+    }
+    // D[blk][i][j] sits in lane 16 i + 4 blk + j
+    const int oi = lane >> 4, ob = (lane >> 2) & 3, oj = lane & 3;
+    if (r0 + ob >= nres) return;
+    double* out = part + (((size_t)chunk * nres + r0 + ob) * 2) * 4096;
+    {
+        int p = 0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int q2 = q; q2 < NB; ++q2) {
+                if (p >= G0 && p < G0 + GN) out[(4 * q + oi) * 64 + 4 * q2 + oj] = acc[p - G0];
+                ++p;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < NU; ++n)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            out[4096 + (4 * q + oi) * 64 + 4 * (W + 4 * n) + oj] = acc[GN + n * NB + q];
+}
+
+// grid (nchunk, ceil(nres / 4)), block 256, dynamic LDS 2 stages x (NB + ceil(NLB/4)) KB.
+// NB = ceil(T'/4), NLB = ceil(L/4).  Partials in k_gram's format; only blocks
+// q <= q' of G are written (k_reduce_part with sym = 2 mirrors them).
+template <int NB, int NLB>
+__global__ __launch_bounds__(256, 2)
+void k_gram4(const double* __restrict__ R, long long strideR, int ldr, int Tp,
+             const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
+             double* __restrict__ part, int nres)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_g4[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, r0 = blockIdx.y * 4;
+    const int cbeg = chunk * cols_per_chunk;
+    const int cend = min(B, cbeg + cols_per_chunk);
+    const double* Rblk = R + (size_t)r0 * strideR;
+    const unsigned sb = (unsigned)(strideR * 8), lb = (unsigned)ldr * 8u, ub = (unsigned)ldu * 8u;
+    switch (w) {
+    case 0: gram4_wave<NB, NLB, 0>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    case 1: gram4_wave<NB, NLB, 1>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    case 2: gram4_wave<NB, NLB, 2>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    default: gram4_wave<NB, NLB, 3>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    }
+}
+
 // C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
 __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
                               int mtiles, int ntiles, int which,
@@ -675,7 +853,7 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
     if (idx >= M * N) return;
     int m = idx / N, n = idx % N;
     const int mo = m, no = n;
-    if (sym && (m >> 4) > (n >> 4)) { const int t = m; m = n; n = t; }   // only 16x16 tiles (a <= w) were computed
+    if (sym && (m >> sym) > (n >> sym)) { const int t = m; m = n; n = t; }   // sym = log2 of the block size whose upper triangle was computed
     const int tile = (m / 64) * ntiles + (n / 64);
     const size_t tiles = (size_t)mtiles * ntiles;
     const size_t off = ((size_t)which * tiles + tile) * 4096 + (m % 64) * 64 + (n % 64);

@@ -186,7 +186,7 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
     if (int e = ensure(ctx, ctx->mom_n, (size_t)groups * std::max(ctx->nmom_pad, 16) * 8, true)) return e;
     if (int e = ensure(ctx, ctx->Gm, nb * ctx->Tp * ctx->Tp * 8)) return e;
     if (int e = ensure(ctx, ctx->Pm, nb * ctx->Tp * ctx->L * 8)) return e;
-    if (int e = ensure(ctx, ctx->Mfrag, nb * ctx->nks_t * ctx->LT * 64 * 8)) return e;
+    if (int e = ensure(ctx, ctx->Mfrag, nb * ctx->nks_t * ctx->LT * 64 * 8 + 1024)) return e;   // + one DMA piece of slack
     ctx->Galloc = groups;
     return 0;
 }
@@ -562,13 +562,13 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     return 0;
 }
 
-template <int LT>
+template <int LT, int NKS>
 int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
 {
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     int nsplit = 1;
     if (!out && nres >= 64) {
-        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<LT>)), 1, 8);
+        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<LT, NKS>)), 1, 8);
         nsplit = std::min(nsplit, nres / 32);
     }
     const int rps = ceil_div(nres, std::max(nsplit, 1));
@@ -581,9 +581,17 @@ int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out,
         ps = ptr<double>(ctx->psum);
         pq = ptr<double>(ctx->psq);
     }
-    hipLaunchKernelGGL(k_urot<LT>, dim3(nblk, nsplit), dim3(256), 0, st, ptr<double>(ctx->R), ctx->strideR,
-                       ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), nres, ctx->B, ctx->L, usum, usq, out,
-                       rps, ps, pq);
+    // two LDS stages of the M operand (whole 1 KB DMA pieces)
+    const size_t lds = (size_t)2 * ceil_div(ctx->nks_t * LT, 2) * 1024;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_urot<LT, NKS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
+                       ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), nres, ctx->B, ctx->L, usum,
+                       usq, out, rps, ps, pq);
     LAUNCHCHK();
     if (nsplit > 1) {
         const long long count = (long long)ctx->B * ctx->L;
@@ -596,13 +604,25 @@ int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out,
 
 int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
 {
+    // square case (L blocks follow from T'): k-step count compiled in, fragments of the
+    // next resample prefetched; otherwise the generic kernel
+    const int nks = ctx->nks_t;
+    if (ctx->LT == ceil_div(nks, 4)) {
+        switch (nks) {
+#define UCASE(N) case N: return launch_urot<(N + 3) / 4, N>(ctx, nres, usum, usq, out, st);
+        UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
+        UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
+#undef UCASE
+        default: break;
+        }
+    }
     switch (ctx->LT) {
-        case 1: return launch_urot<1>(ctx, nres, usum, usq, out, st);
-        case 2: return launch_urot<2>(ctx, nres, usum, usq, out, st);
-        case 3: return launch_urot<3>(ctx, nres, usum, usq, out, st);
-        case 4: return launch_urot<4>(ctx, nres, usum, usq, out, st);
-        case 5: return launch_urot<5>(ctx, nres, usum, usq, out, st);
-        default: return launch_urot<6>(ctx, nres, usum, usq, out, st);
+        case 1: return launch_urot<1, 0>(ctx, nres, usum, usq, out, st);
+        case 2: return launch_urot<2, 0>(ctx, nres, usum, usq, out, st);
+        case 3: return launch_urot<3, 0>(ctx, nres, usum, usq, out, st);
+        case 4: return launch_urot<4, 0>(ctx, nres, usum, usq, out, st);
+        case 5: return launch_urot<5, 0>(ctx, nres, usum, usq, out, st);
+        default: return launch_urot<6, 0>(ctx, nres, usum, usq, out, st);
     }
 }
 

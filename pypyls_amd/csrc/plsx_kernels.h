@@ -1097,7 +1097,12 @@ void k_small(SmallArgs a)
 // (16 x L) tile kept in registers across the whole batch, or write U.
 // One wave per 16 feature columns, 4 waves per block.
 // ---------------------------------------------------------------------------
-template <int LT>
+// NKS > 0: the number of k-steps (T'/4) is a compile-time constant and the R
+// fragments of the NEXT resample are fetched while the current one is being
+// multiplied (full software pipeline across resamples; with the loads issued
+// right before use a wave idles for an HBM latency every 16 MFMAs).
+// NKS == 0: generic k-step count, fragments fetched four k-steps ahead.
+template <int LT, int NKS>
 __global__ __launch_bounds__(256)
 void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             const double* __restrict__ Mfrag, int nres, int B, int L,
@@ -1108,60 +1113,111 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     // its partial (sum, sum of squares) to psum / psq [split][B][L]; k_add_splits
     // adds them in split order (deterministic).  Splitting shortens the work
     // unit so the grid does not end in a nearly empty last round of blocks.
+    //
+    // The M operand of a resample (nks_t x LT fragments, shared by the four
+    // waves and by every block) is copied global -> LDS once per block and
+    // resample with the LDS-DMA path, double buffered; the MFMA B operands are
+    // then conflict-free ds_read_b64 instead of one L2 fetch per MFMA.
+    extern __shared__ __attribute__((aligned(16))) double sm_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b0 = (blockIdx.x * 4 + wave) * 16;
-    if (b0 >= B) return;
+    const int b_real = (blockIdx.x * 4 + wave) * 16;
+    const bool live = b_real < B;
+    const int b0 = live ? b_real : 0;            // idle waves keep pace for the barriers
     const int r_beg = blockIdx.y * res_per_split;
     const int r_end = min(nres, r_beg + res_per_split);
     d4 sum[LT], sq[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) { sum[l] = (d4){0, 0, 0, 0}; sq[l] = (d4){0, 0, 0, 0}; }
+    if (NKS > 0) nks_t = NKS;
     const size_t mstride = (size_t)nks_t * LT * 64;
+    const int pieces = (nks_t * LT + 1) / 2;     // 1 KB DMA pieces per stage
+    const int stage = pieces * 128;              // doubles
     // buffer-resource addressing: per-lane offsets are loop invariant, the k-step
     // offsets are SGPRs (no VALU address arithmetic next to the MFMAs)
     const int rvoff = ((lane >> 4) * ldr + b0 + (lane & 15)) * 8;
-    const int mvoff = lane * 8;
     const int rstep = 4 * ldr * 8;
-    for (int r = r_beg; r < r_end; ++r) {
-        d4 acc[LT];
-#pragma unroll
-        for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
-        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    auto issue = [&](int r, double* buf) {
         __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Mfrag + (size_t)r * mstride), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
-        // issue the R-fragment loads of several k-steps ahead of their MFMAs
-        // (HBM-latency bound otherwise: one 512-byte request per wave in flight)
-        int ks = 0;
-        for (; ks + 4 <= nks_t; ks += 4) {
-            double a[4];
+        for (int p = swave; p < pieces; p += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsM, (__attribute__((address_space(3))) void*)(buf + p * 128), 16, lane * 16, p * 1024, 0, 0);
+    };
+    if (r_beg >= r_end) return;
+    issue(r_beg, sm_u);
+    if constexpr (NKS > 0) {
+        auto load_all = [&](int r, double* a) {
+            __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks + u) * rstep, 0));
+            for (int ks = 0; ks < NKS; ++ks)
+                a[ks] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
+        };
+        double a_cur[NKS];
+        load_all(r_beg, a_cur);
+        __syncthreads();
+        for (int r = r_beg; r < r_end; ++r) {
+            const double* sM = sm_u + ((r - r_beg) & 1) * stage + lane;
+            if (r + 1 < r_end) issue(r + 1, sm_u + ((r - r_beg + 1) & 1) * stage);
+            double a_next[NKS];
+            load_all(min(r + 1, r_end - 1), a_next);
+            d4 acc[LT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    const double mv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                        rsM, mvoff, ((ks + u) * LT + l) * 512, 0));
-                    acc[l] = mfma_f64(a[u], mv, acc[l]);
-                }
-        }
-        for (; ks < nks_t; ++ks) {
-            const double a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a_cur[ks], sM[(ks * LT + l) * 64], acc[l]);
 #pragma unroll
             for (int l = 0; l < LT; ++l) {
-                const double mv = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                    rsM, mvoff, (ks * LT + l) * 512, 0));
-                acc[l] = mfma_f64(a, mv, acc[l]);
+                sum[l] += acc[l];
+                sq[l] += acc[l] * acc[l];
             }
-        }
 #pragma unroll
-        for (int l = 0; l < LT; ++l) {
-            sum[l] += acc[l];
-            sq[l] += acc[l] * acc[l];
+            for (int ks = 0; ks < NKS; ++ks) a_cur[ks] = a_next[ks];
+            // The copy of the next M was issued before the NKS fragment loads that
+            // are still in flight: wait for everything older than those (vmcnt is
+            // in order) instead of draining the prefetch, then barrier (frees this
+            // buffer for the copy after next).
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NKS) : "memory");
+        }
+    } else {
+        __syncthreads();
+        for (int r = r_beg; r < r_end; ++r) {
+            const double* sM = sm_u + ((r - r_beg) & 1) * stage + lane;
+            if (r + 1 < r_end) issue(r + 1, sm_u + ((r - r_beg + 1) & 1) * stage);
+            d4 acc[LT];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
+            __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+            int ks = 0;
+            for (; ks + 4 <= nks_t; ks += 4) {
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks + u) * rstep, 0));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int l = 0; l < LT; ++l)
+                        acc[l] = mfma_f64(a[u], sM[((ks + u) * LT + l) * 64], acc[l]);
+            }
+            for (; ks < nks_t; ++ks) {
+                const double a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
+#pragma unroll
+                for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a, sM[(ks * LT + l) * 64], acc[l]);
+            }
+#pragma unroll
+            for (int l = 0; l < LT; ++l) {
+                sum[l] += acc[l];
+                sq[l] += acc[l] * acc[l];
+            }
+            __syncthreads();         // drains the copy of the next M, frees this buffer
         }
     }
+    if (!live) return;
 #pragma unroll
     for (int l = 0; l < LT; ++l)
 #pragma unroll

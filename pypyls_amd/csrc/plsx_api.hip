@@ -500,7 +500,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     }
     // bootstrap mode with square P: the 4x4x4-MFMA kernel (no 16-row padding, symmetric G)
     {
-        static const bool no4 = getenv("PLSX_NO_GRAM4") != nullptr;
+        const bool no4 = getenv("PLSX_NO_GRAM4") != nullptr;
         const int nb4 = ceil_div(ctx->Tp, 4);
         // (14+ row blocks would spill at two waves per SIMD: T' > 52 keeps the 16x16x4 kernel)
         if (!no4 && mode == 1 && nb4 <= 13 && ceil_div(Erows, 4) == nb4 && 4 * ctx->strideR * 8 < (1LL << 31) &&
@@ -607,7 +607,8 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     // square case (L blocks follow from T'): k-step count compiled in, fragments of the
     // next resample prefetched; otherwise the generic kernel
     const int nks = ctx->nks_t;
-    if (ctx->LT == ceil_div(nks, 4)) {
+    const bool generic = getenv("PLSX_UROT_GENERIC") != nullptr;   // A/B and race check
+    if (!generic && ctx->LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: return launch_urot<(N + 3) / 4, N>(ctx, nres, usum, usq, out, st);
         UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)

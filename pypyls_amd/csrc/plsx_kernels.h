@@ -318,11 +318,21 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // XCD: block b runs on XCD b % 8, so each XCD's L2 keeps ONE group's A
     // operand at a time) and then the column blocks; groups beyond the first 8
     // follow in further sweeps over the columns.
+    // A last, partial sweep (n_groups % 8 = rem groups) would leave 8 - rem XCDs
+    // idle: its rem * ncolblk tiles are dealt out as eight contiguous ranges
+    // instead, one per XCD (each XCD then touches at most two groups' A).
     const int sweep = blockIdx.x / (8 * ncolblk);
     const int within = blockIdx.x - sweep * (8 * ncolblk);
-    const int grp = sweep * 8 + (within & 7);
-    const int colblk = within >> 3;
-    if (grp >= n_groups) return;
+    int grp = sweep * 8 + (within & 7);
+    int colblk = within >> 3;
+    if (sweep * 8 + 8 > n_groups) {
+        const int rem = n_groups - sweep * 8;
+        const int cnt = (rem * ncolblk + 7) >> 3;
+        const int id = (within & 7) * cnt + colblk;
+        if (colblk >= cnt || id >= rem * ncolblk) return;
+        grp = sweep * 8 + id / ncolblk;
+        colblk = id - (id / ncolblk) * ncolblk;
+    }
     const int col = colblk * (NW * 16) + wave * 16 + (lane & 15);
     const int kq = lane >> 4;
 

@@ -439,10 +439,10 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
 // E (Erows x B, leading dimension Bpad) is shared by all resamples (U0^T for the
 // bootstrap, the full-sample R for split-half).  T' <= 64 uses the
 // register-streamed k_gram, larger T' the generic tiled k_nt_gemm.
-template <int NB>
+template <int NB, bool WG>
 int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Pout, hipStream_t st)
 {
-    const void* kfn = reinterpret_cast<const void*>(k_gram4<NB, NB>);
+    const void* kfn = reinterpret_cast<const void*>(k_gram4<NB, NB, WG>);
     const int nblk = ceil_div(nres, 4);
     const int maxchunk = std::max(1, ctx->B / 512);
     int nchunk = std::max(1, ceil_div(2048, nblk));
@@ -454,11 +454,11 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
     double* part = ptr<double>(ctx->part);
     constexpr size_t lds = (size_t)2 * (NB + (NB + 3) / 4) * 128 * 8;
-    hipLaunchKernelGGL((k_gram4<NB, NB>), dim3(nchunk, nblk), dim3(256), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_gram4<NB, NB, WG>), dim3(nchunk, nblk), dim3(256), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres);
     LAUNCHCHK();
     const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
-    {
+    if (WG) {
         dim3 g(ceil_div(ctx->Tp * ctx->Tp, 256), nres);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 0, ptr<double>(ctx->Gm),
                            sG, ctx->Tp, ctx->Tp, ctx->Tp, 2);
@@ -473,10 +473,12 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
     return 0;
 }
 
-int run_gram4(plsx_ctx* ctx, int nres, int nb4, const double* E, int Erows, double* Pout, hipStream_t st)
+int run_gram4(plsx_ctx* ctx, int nres, int nb4, bool with_g, const double* E, int Erows, double* Pout,
+              hipStream_t st)
 {
     switch (nb4) {
-#define G4CASE(N) case N: return launch_gram4<N>(ctx, nres, E, Erows, Pout, st);
+#define G4CASE(N) case N: return with_g ? launch_gram4<N, true>(ctx, nres, E, Erows, Pout, st) \
+                                      : launch_gram4<N, false>(ctx, nres, E, Erows, Pout, st);
     G4CASE(1) G4CASE(2) G4CASE(3) G4CASE(4) G4CASE(5) G4CASE(6) G4CASE(7) G4CASE(8)
     G4CASE(9) G4CASE(10) G4CASE(11) G4CASE(12) G4CASE(13)
 #undef G4CASE
@@ -498,14 +500,15 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
                       mode == 1 ? E : nullptr, 0, ctx->Bpad, Erows, ctx->B, nres,
                       Gm, sG, ctx->Tp, mode == 1 ? Pout : nullptr, sP, Erows, st);
     }
-    // bootstrap mode with square P: the 4x4x4-MFMA kernel (no 16-row padding, symmetric G)
+    // square P (bootstrap G + P, or the cross product alone): the 4x4x4-MFMA kernel
+    // (no 16-row padding, symmetric G)
     {
         const bool no4 = getenv("PLSX_NO_GRAM4") != nullptr;
         const int nb4 = ceil_div(ctx->Tp, 4);
         // (14+ row blocks would spill at two waves per SIMD: T' > 52 keeps the 16x16x4 kernel)
-        if (!no4 && mode == 1 && nb4 <= 13 && ceil_div(Erows, 4) == nb4 && 4 * ctx->strideR * 8 < (1LL << 31) &&
+        if (!no4 && mode != 0 && nb4 <= 13 && ceil_div(Erows, 4) == nb4 && 4 * ctx->strideR * 8 < (1LL << 31) &&
             (long long)Erows * ctx->Bpad * 8 < (1LL << 31))
-            return run_gram4(ctx, nres, nb4, E, Erows, Pout, st);
+            return run_gram4(ctx, nres, nb4, mode == 1, E, Erows, Pout, st);
     }
     const void* kfn = (mode == 0) ? reinterpret_cast<const void*>(k_gram<0>)
                     : (mode == 1) ? reinterpret_cast<const void*>(k_gram<1>)

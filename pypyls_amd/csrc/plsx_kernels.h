@@ -709,8 +709,9 @@ __device__ __forceinline__ double mfma_f64_4x4(double a, double b, double c)
 }
 
 constexpr int g4_nu(int nlb, int w) { return nlb > w ? (nlb - w + 3) / 4 : 0; }
-constexpr int g4_gcount(int nb, int nlb, int w)
+constexpr int g4_gcount(int nb, int nlb, int w, bool wg = true)
 {
+    if (!wg) return 0;
     const int ng = nb * (nb + 1) / 2, total = ng + nb * nlb, target = (total + 3) / 4;
     int start = 0, cnt = 0;
     for (int v = 0; v <= w; ++v) {
@@ -721,20 +722,20 @@ constexpr int g4_gcount(int nb, int nlb, int w)
     }
     return cnt;
 }
-constexpr int g4_gstart(int nb, int nlb, int w)
+constexpr int g4_gstart(int nb, int nlb, int w, bool wg = true)
 {
     int start = 0;
-    for (int v = 0; v < w; ++v) start += g4_gcount(nb, nlb, v);
+    for (int v = 0; v < w; ++v) start += g4_gcount(nb, nlb, v, wg);
     return start;
 }
 
-template <int NB, int NLB, int W>
+template <int NB, int NLB, int W, bool WG>
 __device__ __forceinline__ void gram4_wave(double* smem, const double* __restrict__ Rblk, unsigned strideR_b,
                                            unsigned ldr_b, int Tp, const double* __restrict__ U0T,
                                            unsigned ldu_b, int L, int cbeg, int cend,
                                            double* __restrict__ part, int chunk, int r0, int nres, int lane)
 {
-    constexpr int G0 = g4_gstart(NB, NLB, W), GN = g4_gcount(NB, NLB, W), NU = g4_nu(NLB, W);
+    constexpr int G0 = g4_gstart(NB, NLB, W, WG), GN = g4_gcount(NB, NLB, W, WG), NU = g4_nu(NLB, W);
     constexpr int NACC = GN + NB * NU;
     constexpr int NUS = (NLB + 3) / 4, SLOTS = NB + NUS, STAGE = SLOTS * 128;   // doubles per LDS stage
     constexpr int NDMA = (SLOTS > W) ? (SLOTS - W + 3) / 4 : 0;                 // DMA slots of this wave
@@ -831,8 +832,9 @@ __device__ __forceinline__ void gram4_wave(double* smem, const double* __restric
 
 // grid (nchunk, ceil(nres / 4)), block 256, dynamic LDS 2 stages x (NB + ceil(NLB/4)) KB.
 // NB = ceil(T'/4), NLB = ceil(L/4).  Partials in k_gram's format; only blocks
-// q <= q' of G are written (k_reduce_part with sym = 2 mirrors them).
-template <int NB, int NLB>
+// q <= q' of G are written (k_reduce_part with sym = 2 mirrors them).  WG = false:
+// the cross product P = R . E^T only (split-half cross-Gram, SIMPLS signs).
+template <int NB, int NLB, bool WG = true>
 __global__ __launch_bounds__(256, 2)
 void k_gram4(const double* __restrict__ R, long long strideR, int ldr, int Tp,
              const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
@@ -846,10 +848,10 @@ void k_gram4(const double* __restrict__ R, long long strideR, int ldr, int Tp,
     const double* Rblk = R + (size_t)r0 * strideR;
     const unsigned sb = (unsigned)(strideR * 8), lb = (unsigned)ldr * 8u, ub = (unsigned)ldu * 8u;
     switch (w) {
-    case 0: gram4_wave<NB, NLB, 0>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
-    case 1: gram4_wave<NB, NLB, 1>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
-    case 2: gram4_wave<NB, NLB, 2>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
-    default: gram4_wave<NB, NLB, 3>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    case 0: gram4_wave<NB, NLB, 0, WG>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    case 1: gram4_wave<NB, NLB, 1, WG>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    case 2: gram4_wave<NB, NLB, 2, WG>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
+    default: gram4_wave<NB, NLB, 3, WG>(sm_g4, Rblk, sb, lb, Tp, U0T, ub, L, cbeg, cend, part, chunk, r0, nres, lane); break;
     }
 }
 

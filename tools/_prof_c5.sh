@@ -1,6 +1,6 @@
 #!/bin/bash
 repo=$(pwd); cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/prof_c5
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o p -- python "$repo/tools/bench_configs.py" c5 > /tmp/c5.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o p -- python "$repo/tools/bench_configs.py" ${CFG:-c5} > /tmp/c5.log 2>&1
 grep "^{" /tmp/c5.log | cut -c1-200
 f=$(find /tmp/prof_c5 -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'

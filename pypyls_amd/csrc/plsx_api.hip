@@ -630,6 +630,43 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     }
 }
 
+template <int LT, int NKS, class... Args>
+int launch_ucorr_t(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
+{
+    const size_t lds = (size_t)ctx->nks_t * LT * 64 * 8;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ucorr_partial<LT, NKS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL((k_ucorr_partial<LT, NKS>), grid, block, lds, st, args...);
+    return 0;
+}
+
+template <class... Args>
+int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
+{
+    const int nks = ctx->nks_t;
+    if (ctx->LT == ceil_div(nks, 4)) {
+        switch (nks) {
+#define UCASE(N) case N: return launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, args...);
+        UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
+        UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
+#undef UCASE
+        default: break;
+        }
+    }
+    switch (ctx->LT) {
+        case 1: return launch_ucorr_t<1, 0>(ctx, grid, block, st, args...);
+        case 2: return launch_ucorr_t<2, 0>(ctx, grid, block, st, args...);
+        case 3: return launch_ucorr_t<3, 0>(ctx, grid, block, st, args...);
+        case 4: return launch_ucorr_t<4, 0>(ctx, grid, block, st, args...);
+        case 5: return launch_ucorr_t<5, 0>(ctx, grid, block, st, args...);
+        default: return launch_ucorr_t<6, 0>(ctx, grid, block, st, args...);
+    }
+}
+
 SmallArgs small_args(plsx_ctx* ctx, int mode)
 {
     SmallArgs a;
@@ -1110,14 +1147,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
             dim3 grid(nchunk, m), block(256);
 #define UC_ARGS ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mvd), ctx->B, tpc, \
                 ptr<double>(ctx->part2), m
-            switch (ctx->LT) {
-                case 1: hipLaunchKernelGGL(k_ucorr_partial<1>, grid, block, 0, st, UC_ARGS); break;
-                case 2: hipLaunchKernelGGL(k_ucorr_partial<2>, grid, block, 0, st, UC_ARGS); break;
-                case 3: hipLaunchKernelGGL(k_ucorr_partial<3>, grid, block, 0, st, UC_ARGS); break;
-                case 4: hipLaunchKernelGGL(k_ucorr_partial<4>, grid, block, 0, st, UC_ARGS); break;
-                case 5: hipLaunchKernelGGL(k_ucorr_partial<5>, grid, block, 0, st, UC_ARGS); break;
-                default: hipLaunchKernelGGL(k_ucorr_partial<6>, grid, block, 0, st, UC_ARGS); break;
-            }
+            if (int e = launch_ucorr(ctx, grid, block, st, UC_ARGS)) return e;
 #undef UC_ARGS
             LAUNCHCHK();
             hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m, lpad,

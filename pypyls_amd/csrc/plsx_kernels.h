@@ -1337,38 +1337,36 @@ __global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restr
 // (S1, S2, S11, S22, S12) over features needed for the Pearson correlation of
 // the projected left singular vectors (efficient_corr(D1.T @ vd, D2.T @ vd),
 // base.py:766).  grid (nchunk, npairs), 4 waves, partial sums per block.
-template <int LT>
+// M is the same for every pair of the launch: it is copied to LDS once per
+// block (B operands = conflict-free ds_read_b64 instead of one L2 fetch per
+// MFMA); with a compile-time k-step count (NKS > 0) the R fragments of the next
+// feature tile are in flight while the current one is multiplied.
+template <int LT, int NKS>
 __global__ __launch_bounds__(256)
 void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                      const double* __restrict__ Mfrag, int B, int tiles_per_chunk,
                      double* __restrict__ part /* [nchunk][npairs][5][LT*16] */, int npairs)
 {
+    extern __shared__ __attribute__((aligned(16))) double sm_uc[];     // M: [nks_t][LT][64]
     __shared__ double red[4][5][LT * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x, pair = blockIdx.y;
+    if (NKS > 0) nks_t = NKS;
+    for (int i = threadIdx.x; i < nks_t * LT * 64; i += blockDim.x) sm_uc[i] = Mfrag[i];
+    __syncthreads();
+    const double* sM = sm_uc + lane;
     const double* R1 = R + (size_t)(2 * pair) * strideR;
     const double* R2 = R1 + strideR;
+    __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)R1, (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)R2, (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+    const int rstep = 4 * ldr * 8;
     double s1[LT], s2[LT], s11[LT], s22[LT], s12[LT];
 #pragma unroll
     for (int l = 0; l < LT; ++l) s1[l] = s2[l] = s11[l] = s22[l] = s12[l] = 0.0;
     const int ntile = (B + 15) / 16;
     const int t0 = chunk * tiles_per_chunk, t1 = min(ntile, t0 + tiles_per_chunk);
-    for (int tile = t0 + wave; tile < t1; tile += 4) {
-        const int b0 = tile * 16;
-        d4 e1[LT], e2[LT];
-#pragma unroll
-        for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
-        const size_t off = (size_t)(lane >> 4) * ldr + b0 + (lane & 15);
-        for (int ks = 0; ks < nks_t; ++ks) {
-            const double a1 = R1[off + (size_t)ks * 4 * ldr];
-            const double a2 = R2[off + (size_t)ks * 4 * ldr];
-#pragma unroll
-            for (int l = 0; l < LT; ++l) {
-                const double mv = Mfrag[((size_t)ks * LT + l) * 64 + lane];
-                e1[l] = mfma_f64(a1, mv, e1[l]);
-                e2[l] = mfma_f64(a2, mv, e2[l]);
-            }
-        }
+    auto tile_off = [&](int tile) { return ((lane >> 4) * ldr + tile * 16 + (lane & 15)) * 8; };
+    auto accumulate = [&](int b0, const d4* e1, const d4* e2) {
 #pragma unroll
         for (int l = 0; l < LT; ++l)
 #pragma unroll
@@ -1377,6 +1375,54 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
                 const double x = ok ? e1[l][i] : 0.0, y = ok ? e2[l][i] : 0.0;
                 s1[l] += x; s2[l] += y; s11[l] += x * x; s22[l] += y * y; s12[l] += x * y;
             }
+    };
+    if constexpr (NKS > 0) {
+        double a1[NKS], a2[NKS];
+        auto load_tile = [&](int tile, double* x1, double* x2) {
+            const int vo = tile_off(min(tile, t1 - 1));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                x1[ks] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, ks * rstep, 0));
+                x2[ks] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, vo, ks * rstep, 0));
+            }
+        };
+        if (t0 + wave < t1) load_tile(t0 + wave, a1, a2);
+        for (int tile = t0 + wave; tile < t1; tile += 4) {
+            double n1[NKS], n2[NKS];
+            load_tile(tile + 4, n1, n2);
+            d4 e1[LT], e2[LT];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    const double mv = sM[(ks * LT + l) * 64];
+                    e1[l] = mfma_f64(a1[ks], mv, e1[l]);
+                    e2[l] = mfma_f64(a2[ks], mv, e2[l]);
+                }
+            accumulate(tile * 16, e1, e2);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) { a1[ks] = n1[ks]; a2[ks] = n2[ks]; }
+        }
+    } else {
+        for (int tile = t0 + wave; tile < t1; tile += 4) {
+            d4 e1[LT], e2[LT];
+#pragma unroll
+            for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
+            const int vo = tile_off(tile);
+            for (int ks = 0; ks < nks_t; ++ks) {
+                const double a1 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, ks * rstep, 0));
+                const double a2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, vo, ks * rstep, 0));
+#pragma unroll
+                for (int l = 0; l < LT; ++l) {
+                    const double mv = sM[(ks * LT + l) * 64];
+                    e1[l] = mfma_f64(a1, mv, e1[l]);
+                    e2[l] = mfma_f64(a2, mv, e2[l]);
+                }
+            }
+            accumulate(tile * 16, e1, e2);
+        }
     }
     // reduce over the four row groups of the wave (lanes l, l+16, l+32, l+48)
 #pragma unroll

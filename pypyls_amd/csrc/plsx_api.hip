@@ -46,6 +46,7 @@ struct plsx_ctx {
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
+    Buf gws;                                            // small-solver workspace (T' > PLSX_LDS_TP)
     int dual = 0;
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
@@ -553,25 +554,70 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
     const int n = a.n, ld = n | 1;
+    if (n > PLSX_LDS_TP) {
+        // work matrices in a global workspace (L2), bookkeeping vectors in LDS
+        if (int e = ensure(ctx, ctx->gws, (size_t)nres * 2 * n * ld * 8)) return e;
+        a.gws = ptr<double>(ctx->gws);
+        const size_t lds = (size_t)2 * n * 8 + (size_t)2 * n * 4 + 64;
+        hipLaunchKernelGGL(k_small<true>, dim3(nres), dim3(256), lds, st, a);
+        LAUNCHCHK();
+        return 0;
+    }
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
     static size_t configured = 0;
     if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small),
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    hipLaunchKernelGGL(k_small, dim3(nres), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(k_small<false>, dim3(nres), dim3(256), lds, st, a);
     LAUNCHCHK();
     return 0;
 }
 
+// One launch of the rotation kernel for the chunk of L tiles [lt0, lt0 + LT).
 template <int LT, int NKS>
-int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
+int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
+                double* ps, double* pq, hipStream_t st)
 {
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
+    // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
+    const size_t lds = NKS < 0 ? 0 : (size_t)2 * ceil_div(ctx->nks_t * LT, 2) * 1024;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_urot<LT, NKS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
+    hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
+                       ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
+                       ctx->L, lt0 * 16, usum, usq, out, rps, ps, pq);
+    LAUNCHCHK();
+    return 0;
+}
+
+template <int NKS>
+int launch_urot_lt(plsx_ctx* ctx, int ltc, int nres, int lt0, int nsplit, int rps, double* usum, double* usq,
+                   double* out, double* ps, double* pq, hipStream_t st)
+{
+    switch (ltc) {
+        case 1: return launch_urot<1, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        case 2: return launch_urot<2, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        case 3: return launch_urot<3, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        case 4: return launch_urot<4, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        case 5: return launch_urot<5, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        default: return launch_urot<6, NKS>(ctx, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+    }
+}
+
+int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
+{
+    const int nks = ctx->nks_t, LT = ctx->LT;
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     int nsplit = 1;
     if (!out && nres >= 64) {
-        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<LT, NKS>)), 1, 8);
+        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)), 1, 8);
         nsplit = std::min(nsplit, nres / 32);
     }
     const int rps = ceil_div(nres, std::max(nsplit, 1));
@@ -584,18 +630,31 @@ int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out,
         ps = ptr<double>(ctx->psum);
         pq = ptr<double>(ctx->psq);
     }
-    // two LDS stages of the M operand (whole 1 KB DMA pieces)
-    const size_t lds = (size_t)2 * ceil_div(ctx->nks_t * LT, 2) * 1024;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_urot<LT, NKS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+    const bool generic = getenv("PLSX_UROT_GENERIC") != nullptr;   // A/B and race check
+    int rc = -1;
+    // square case (L tiles follow from T'): k-step count compiled in, fragments of the
+    // next resample prefetched
+    if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
+        switch (nks) {
+#define UCASE(N) case N: rc = launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;
+        UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
+        UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
+#undef UCASE
+        default: break;
+        }
     }
-    hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
-                       ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mfrag), nres, ctx->B, ctx->L, usum,
-                       usq, out, rps, ps, pq);
-    LAUNCHCHK();
+    if (rc < 0) {
+        // generic: one launch per chunk of PLSX_LT_CHUNK tiles; M through LDS while two
+        // stages of a chunk fit (150 KB), from L2 otherwise
+        rc = 0;
+        for (int lt0 = 0; lt0 < LT && rc == 0; lt0 += PLSX_LT_CHUNK) {
+            const int ltc = std::min(PLSX_LT_CHUNK, LT - lt0);
+            const bool in_lds = (size_t)2 * ceil_div(nks * ltc, 2) * 1024 <= 150 * 1024;
+            rc = in_lds ? launch_urot_lt<0>(ctx, ltc, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st)
+                        : launch_urot_lt<-1>(ctx, ltc, nres, lt0, nsplit, rps, usum, usq, out, ps, pq, st);
+        }
+    }
+    if (rc) return rc;
     if (nsplit > 1) {
         const long long count = (long long)ctx->B * ctx->L;
         hipLaunchKernelGGL(k_add_splits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, ps, pq, nsplit,
@@ -605,35 +664,11 @@ int launch_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out,
     return 0;
 }
 
-int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
-{
-    // square case (L blocks follow from T'): k-step count compiled in, fragments of the
-    // next resample prefetched; otherwise the generic kernel
-    const int nks = ctx->nks_t;
-    const bool generic = getenv("PLSX_UROT_GENERIC") != nullptr;   // A/B and race check
-    if (!generic && ctx->LT == ceil_div(nks, 4)) {
-        switch (nks) {
-#define UCASE(N) case N: return launch_urot<(N + 3) / 4, N>(ctx, nres, usum, usq, out, st);
-        UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
-        UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
-#undef UCASE
-        default: break;
-        }
-    }
-    switch (ctx->LT) {
-        case 1: return launch_urot<1, 0>(ctx, nres, usum, usq, out, st);
-        case 2: return launch_urot<2, 0>(ctx, nres, usum, usq, out, st);
-        case 3: return launch_urot<3, 0>(ctx, nres, usum, usq, out, st);
-        case 4: return launch_urot<4, 0>(ctx, nres, usum, usq, out, st);
-        case 5: return launch_urot<5, 0>(ctx, nres, usum, usq, out, st);
-        default: return launch_urot<6, 0>(ctx, nres, usum, usq, out, st);
-    }
-}
-
+// Split-half feature-axis sums: same chunking of L.
 template <int LT, int NKS, class... Args>
 int launch_ucorr_t(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
 {
-    const size_t lds = (size_t)ctx->nks_t * LT * 64 * 8;
+    const size_t lds = NKS < 0 ? 0 : (size_t)ctx->nks_t * LT * 64 * 8;
     static size_t configured = 0;
     if (lds > configured) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ucorr_partial<LT, NKS>),
@@ -644,27 +679,46 @@ int launch_ucorr_t(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args...
     return 0;
 }
 
-template <class... Args>
-int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
+template <int NKS, class... Args>
+int launch_ucorr_lt(plsx_ctx* ctx, int ltc, dim3 grid, dim3 block, hipStream_t st, Args... args)
 {
-    const int nks = ctx->nks_t;
-    if (ctx->LT == ceil_div(nks, 4)) {
+    switch (ltc) {
+        case 1: return launch_ucorr_t<1, NKS>(ctx, grid, block, st, args...);
+        case 2: return launch_ucorr_t<2, NKS>(ctx, grid, block, st, args...);
+        case 3: return launch_ucorr_t<3, NKS>(ctx, grid, block, st, args...);
+        case 4: return launch_ucorr_t<4, NKS>(ctx, grid, block, st, args...);
+        case 5: return launch_ucorr_t<5, NKS>(ctx, grid, block, st, args...);
+        default: return launch_ucorr_t<6, NKS>(ctx, grid, block, st, args...);
+    }
+}
+
+// M (fragment order, chunked) for all of L; partial sums [nchunk][npairs][5][lpad]
+int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, const double* M, int tpc,
+                 double* part, int npairs)
+{
+    const int nks = ctx->nks_t, LT = ctx->LT, lpad = LT * 16;
+    const double* R = ptr<double>(ctx->R);
+    if (LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
-#define UCASE(N) case N: return launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, args...);
+#define UCASE(N) case N: return launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
+                    nks, M, ctx->B, tpc, part, npairs, 0, lpad);
         UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
         UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
 #undef UCASE
         default: break;
         }
     }
-    switch (ctx->LT) {
-        case 1: return launch_ucorr_t<1, 0>(ctx, grid, block, st, args...);
-        case 2: return launch_ucorr_t<2, 0>(ctx, grid, block, st, args...);
-        case 3: return launch_ucorr_t<3, 0>(ctx, grid, block, st, args...);
-        case 4: return launch_ucorr_t<4, 0>(ctx, grid, block, st, args...);
-        case 5: return launch_ucorr_t<5, 0>(ctx, grid, block, st, args...);
-        default: return launch_ucorr_t<6, 0>(ctx, grid, block, st, args...);
+    for (int lt0 = 0; lt0 < LT; lt0 += PLSX_LT_CHUNK) {
+        const int ltc = std::min(PLSX_LT_CHUNK, LT - lt0);
+        const double* Mc = M + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, nks);
+        const bool in_lds = (size_t)nks * ltc * 512 <= 128 * 1024;       // + 15 KB of static reduction space
+        const int rc = in_lds ? launch_ucorr_lt<0>(ctx, ltc, grid, block, st, R, ctx->strideR, ctx->Bpad, nks, Mc,
+                                                   ctx->B, tpc, part, npairs, lt0 * 16, lpad)
+                              : launch_ucorr_lt<-1>(ctx, ltc, grid, block, st, R, ctx->strideR, ctx->Bpad, nks, Mc,
+                                                    ctx->B, tpc, part, npairs, lt0 * 16, lpad);
+        if (rc) return rc;
     }
+    return 0;
 }
 
 SmallArgs small_args(plsx_ctx* ctx, int mode)
@@ -720,7 +774,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -771,7 +825,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
     if (Tp > PLSX_MAX_TP) {
         char msg[160];
-        snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the on-chip solver limit %d", Tp,
+        snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the limit %d (one resample per 24-tile block)", Tp,
                  PLSX_MAX_TP);
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
@@ -827,6 +881,13 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         HIPCHK(hipMemcpyAsync(ctx->Y.p, d_Y, (size_t)S * T * 8, hipMemcpyDeviceToDevice, st));
     }
     plan_groups(ctx);
+    {
+        // one resample (data rows + its moment rows) must fit the 24 tiles of a block
+        const int tw1 = ctx->scaled ? ceil_div(J, 16) : 0;
+        if (ceil_div(Tp, 16) + 2 * tw1 > ctx->MT || tw1 * 16 > 48)
+            return fail(ctx, PLSX_ERR_UNSUPPORTED,
+                        "stacked dimension T' (plus its per-cell moment rows) exceeds the 384 rows of a block");
+    }
     if (int e = upload_rowmaps(ctx)) return e;
     ctx->fix = 0; ctx->npgf = 0; ctx->group_stride_f = 0;
     {
@@ -1145,10 +1206,8 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
             const int lpad = ctx->LT * 16;
             if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
             dim3 grid(nchunk, m), block(256);
-#define UC_ARGS ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, ctx->nks_t, ptr<double>(ctx->Mvd), ctx->B, tpc, \
-                ptr<double>(ctx->part2), m
-            if (int e = launch_ucorr(ctx, grid, block, st, UC_ARGS)) return e;
-#undef UC_ARGS
+            if (int e = launch_ucorr(ctx, grid, block, st, ptr<double>(ctx->Mvd), tpc, ptr<double>(ctx->part2), m))
+                return e;
             LAUNCHCHK();
             hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m, lpad,
                                ptr<double>(ctx->Cm), ptr<double>(ctx->Vp), ptr<double>(ctx->dp), Tp, L, ctx->B,

@@ -25,7 +25,9 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#define PLSX_MAX_TP 96          // largest T' handled by the on-chip solver
+#define PLSX_MAX_TP 352         // largest stacked dimension T' (22 data tiles of one resample per block)
+#define PLSX_LDS_TP 96          // largest T' whose small solver runs out of LDS (global workspace above)
+#define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
@@ -937,6 +939,22 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
     }
 }
 
+// Fragment-ordered M operand (T' x L) of k_urot / k_ucorr_partial: the 16-column
+// tiles of L are grouped in chunks of PLSX_LT_CHUNK (one launch per chunk: the
+// accumulators of more tiles do not fit the register file); inside a chunk
+// [k-step][tile][lane].  With L <= 96 there is one chunk and the layout is the
+// plain [k-step][LT][lane].
+__host__ __device__ inline size_t mfrag_chunk_base(int chunk, int nks_t) { return (size_t)chunk * PLSX_LT_CHUNK * nks_t * 64; }
+__device__ __forceinline__ void mfrag_decode(int idx, int nks_t, int LT, int& ks, int& lt, int& lane)
+{
+    const int per = PLSX_LT_CHUNK * nks_t * 64;
+    const int chunk = idx / per, rem = idx - chunk * per;
+    const int ltc = min(PLSX_LT_CHUNK, LT - chunk * PLSX_LT_CHUNK);
+    lane = rem & 63;
+    ks = (rem >> 6) / ltc;
+    lt = chunk * PLSX_LT_CHUNK + (rem >> 6) - ks * ltc;
+}
+
 enum { SMALL_DECOMP = 0, SMALL_PERM = 1, SMALL_BOOT = 2 };
 
 struct SmallArgs {
@@ -953,17 +971,22 @@ struct SmallArgs {
     double* out_d;     // DECOMP: (L)
     double* Mfrag;     // BOOT / DECOMP: [nres][nks_t][LT][64] fragment-ordered M (T' x L)
     int nks_t, LT;
+    double* gws;       // GWS: global workspace, 2 n (n|1) doubles per resample (T' > PLSX_LDS_TP)
 };
 
+// GWS = false: both n x n work matrices live in LDS (n <= PLSX_LDS_TP).
+// GWS = true: they live in a per-resample global workspace (L2); same code,
+// latency bound but one block per resample keeps the chip busy.
+template <bool GWS>
 __global__ __launch_bounds__(256)
 void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];
     const int n = a.n, L = a.L;
     const int ld = n | 1;
-    double* bufA = sm_s;                     // n x ld
-    double* bufV = sm_s + (size_t)n * ld;    // n x ld
-    double* lam = bufV + (size_t)n * ld;     // [n] eigenvalues of G (unsorted)
+    double* bufA = GWS ? a.gws + (size_t)blockIdx.x * 2 * n * ld : sm_s;     // n x ld
+    double* bufV = bufA + (size_t)n * ld;    // n x ld
+    double* lam = GWS ? sm_s : bufV + (size_t)n * ld;     // [n] eigenvalues of G (unsorted)
     double* sig = lam + n;                   // [n] singular values of temp
     int* rank = reinterpret_cast<int*>(sig + n);   // [n] rank of physical column (0 = largest)
     int* order = rank + n;                         // [n] physical column of rank k
@@ -1011,7 +1034,8 @@ void k_small(SmallArgs a)
         // M = V diag(1/d) for live LVs (zero otherwise): U = R^T . M
         const int tot = a.nks_t * a.LT * 64;
         for (int idx = tid; idx < tot; idx += blockDim.x) {
-            int lane = idx & 63, lt = (idx >> 6) % a.LT, ks = (idx >> 6) / a.LT;
+            int lane, lt, ks;
+            mfrag_decode(idx, a.nks_t, a.LT, ks, lt, lane);
             int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
             double v = 0.0;
             if (t < n && l < L) {
@@ -1092,7 +1116,8 @@ void k_small(SmallArgs a)
         // M[t][l] = sum_c (V Pv)[t][c] W[l][c] / sig_c   -> U_rot = R_b^T . M
         const int tot = a.nks_t * a.LT * 64;
         for (int idx = tid; idx < tot; idx += blockDim.x) {
-            int lane = idx & 63, lt = (idx >> 6) % a.LT, ks = (idx >> 6) / a.LT;
+            int lane, lt, ks;
+            mfrag_decode(idx, a.nks_t, a.LT, ks, lt, lane);
             int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
             double s = 0.0;
             if (t < n && l < L)
@@ -1114,10 +1139,14 @@ void k_small(SmallArgs a)
 // multiplied (full software pipeline across resamples; with the loads issued
 // right before use a wave idles for an HBM latency every 16 MFMAs).
 // NKS == 0: generic k-step count, fragments fetched four k-steps ahead.
+// NKS < 0: as NKS == 0 but the M operand is read from global memory / L2 (T' so
+// large that two LDS stages of it do not fit).
+// LT = tiles of this launch's chunk of L (PLSX_LT_CHUNK at most), k0 = its first
+// column, mstride = doubles between the M operands of consecutive resamples.
 template <int LT, int NKS>
 __global__ __launch_bounds__(256)
 void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
-            const double* __restrict__ Mfrag, int nres, int B, int L,
+            const double* __restrict__ Mfrag, size_t mstride, int nres, int B, int L, int k0,
             double* __restrict__ usum, double* __restrict__ usq, double* __restrict__ out,
             int res_per_split, double* __restrict__ psum, double* __restrict__ psq)
 {
@@ -1141,7 +1170,6 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
 #pragma unroll
     for (int l = 0; l < LT; ++l) { sum[l] = (d4){0, 0, 0, 0}; sq[l] = (d4){0, 0, 0, 0}; }
     if (NKS > 0) nks_t = NKS;
-    const size_t mstride = (size_t)nks_t * LT * 64;
     const int pieces = (nks_t * LT + 1) / 2;     // 1 KB DMA pieces per stage
     const int stage = pieces * 128;              // doubles
     // buffer-resource addressing: per-lane offsets are loop invariant, the k-step
@@ -1150,6 +1178,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     const int rstep = 4 * ldr * 8;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     auto issue = [&](int r, double* buf) {
+        if (NKS < 0) return;
         __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Mfrag + (size_t)r * mstride), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
         for (int p = swave; p < pieces; p += 4)
@@ -1197,7 +1226,8 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     } else {
         __syncthreads();
         for (int r = r_beg; r < r_end; ++r) {
-            const double* sM = sm_u + ((r - r_beg) & 1) * stage + lane;
+            const double* sM = (NKS < 0) ? Mfrag + (size_t)r * mstride + lane
+                                         : sm_u + ((r - r_beg) & 1) * stage + lane;
             if (r + 1 < r_end) issue(r + 1, sm_u + ((r - r_beg + 1) & 1) * stage);
             d4 acc[LT];
 #pragma unroll
@@ -1234,7 +1264,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     for (int l = 0; l < LT; ++l)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int b = b0 + (lane >> 4) + 4 * i, k = l * 16 + (lane & 15);
+            const int b = b0 + (lane >> 4) + 4 * i, k = k0 + l * 16 + (lane & 15);
             if (b < B && k < L) {
                 const size_t o = (size_t)b * L + k;
                 if (out) out[o] = sum[l][i];
@@ -1341,20 +1371,25 @@ __global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restr
 // block (B operands = conflict-free ds_read_b64 instead of one L2 fetch per
 // MFMA); with a compile-time k-step count (NKS > 0) the R fragments of the next
 // feature tile are in flight while the current one is multiplied.
+// LT = tiles of this launch's chunk of L, k0 = its first column, lpad = padded L
+// (row pitch of the partial sums).  NKS < 0: M read from global memory (too
+// large for LDS).
 template <int LT, int NKS>
 __global__ __launch_bounds__(256)
 void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                      const double* __restrict__ Mfrag, int B, int tiles_per_chunk,
-                     double* __restrict__ part /* [nchunk][npairs][5][LT*16] */, int npairs)
+                     double* __restrict__ part /* [nchunk][npairs][5][lpad] */, int npairs, int k0, int lpad)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_uc[];     // M: [nks_t][LT][64]
     __shared__ double red[4][5][LT * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int chunk = blockIdx.x, pair = blockIdx.y;
     if (NKS > 0) nks_t = NKS;
-    for (int i = threadIdx.x; i < nks_t * LT * 64; i += blockDim.x) sm_uc[i] = Mfrag[i];
-    __syncthreads();
-    const double* sM = sm_uc + lane;
+    if (NKS >= 0) {
+        for (int i = threadIdx.x; i < nks_t * LT * 64; i += blockDim.x) sm_uc[i] = Mfrag[i];
+        __syncthreads();
+    }
+    const double* sM = (NKS < 0 ? Mfrag : sm_uc) + lane;
     const double* R1 = R + (size_t)(2 * pair) * strideR;
     const double* R2 = R1 + strideR;
     __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)R1, (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
@@ -1442,7 +1477,7 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
     __syncthreads();
     for (int idx = threadIdx.x; idx < 5 * LT * 16; idx += blockDim.x) {
         const int k = idx / (LT * 16), c = idx % (LT * 16);
-        part[(((size_t)chunk * npairs + pair) * 5 + k) * (LT * 16) + c] =
+        part[(((size_t)chunk * npairs + pair) * 5 + k) * lpad + k0 + c] =
             red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
     }
 }

@@ -21,7 +21,10 @@ def _bind(eng, X, Y, groups, n_cond, **kw):
 
 @pytest.mark.parametrize('S,B,T,groups,n_cond', [
     (90, 333, 80, [90], 1),          # T' = 80 > 64: generic tiled Gram path, LT = 5
-    (96, 211, 24, [24, 24], 2),      # T' = J*T = 4*24 = 96 = the solver limit, ragged B
+    (96, 211, 24, [24, 24], 2),      # T' = J*T = 4*24 = 96 = the LDS solver limit, ragged B
+    (140, 600, 100, [140], 1),       # T' = 100 (the reference's own test width): global-workspace solver, LT = 7
+    (200, 500, 30, [25, 25], 4),     # T' = 8 cells x 30 = 240: two chunks of L tiles, M operand from L2
+    (400, 900, 352, [400], 1),       # T' = 352 = the block limit (22 data tiles + moments)
     (33, 17, 2, [33], 1),            # tiny, S not a multiple of 8, B < 128
     (603, 140, 3, [603], 1),         # S > 512
 ])
@@ -57,8 +60,8 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     from pypyls_amd import resampling as rsmp
     rs = np.random.RandomState(0)
     eng = _engine()
-    with pytest.raises(PlsxError):                       # T' = 97 > 96
-        eng.set_data(rs.randn(120, 50), rs.randn(120, 97), rsmp.cell_of_row([120], 1), 1, 1, 0)
+    with pytest.raises(PlsxError):                       # T' = 353 > 352
+        eng.set_data(rs.randn(400, 50), rs.randn(400, 353), rsmp.cell_of_row([400], 1), 1, 1, 0)
     with pytest.raises(PlsxError):                       # perm before set_data / set_original
         _engine().perm(np.zeros((0, 1), int))
     X, Y = rs.randn(30, 40), rs.randn(30, 3)

@@ -210,7 +210,7 @@ def test_errors_and_layout():
     with pytest.raises(ValueError):
         pls.meancentered_pls(X, n_perm=0, n_boot=0)                 # 1 group, 1 cond
     with pytest.raises(pls.engine.PlsxError):
-        pls.behavioral_pls(X, rs.rand(30, 100), n_perm=0, n_boot=0, test_split=0)   # T' > 96
+        pls.behavioral_pls(X, rs.rand(30, 353), n_perm=0, n_boot=0, test_split=0)   # T' > 352
     res = pls.behavioral_pls(X, Y, n_perm=8, n_boot=8, test_split=0, seed=3, verbose=False)
     assert res.x_weights.shape == (40, 5) and res.y_weights.shape == (5, 5)
     assert res.x_scores.shape == (30, 5) and res.y_scores.shape == (30, 5)

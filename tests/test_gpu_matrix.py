@@ -179,3 +179,48 @@ def test_regression_errors():
         _reg(Y=rs.rand(RS, RT, 10), aggfunc=lambda x: x)
     with pytest.raises(ValueError):
         _reg(Y=rs.rand(RS, RT, 10), bootsamples=[[10], [10]])
+
+
+# ---- wide behaviour matrices (the reference's tests use 100 Y columns) ----------
+@pytest.mark.parametrize('n_groups,n_cond,n_split', [(1, 1, 4), (1, 2, None), (2, 1, 3)])
+def test_behavioral_wide_y(n_groups, n_cond, n_split):
+    """T = 100 behaviours, T' = 100 / 200 stacked rows: global-workspace small
+    solver, chunked L tiles; parity against the oracle incl. split-half and
+    cross-validation."""
+    import pypyls_amd as pls
+    Sw, Bw, Tw = 320, 420, 100          # training cells keep >= T rows: full-rank train decompositions
+    r2 = np.random.RandomState(77)
+    Xw = r2.randn(Sw, Bw)
+    Yw = r2.randn(Sw, Tw) + 0.4 * Xw[:, :Tw]
+    groups = [Sw // n_cond // n_groups] * n_groups
+    from pypyls_amd import resampling as rsmp
+    kw = {}
+    n_perm = 5
+    if n_split:
+        kw['_splitsamples'] = rsmp.gen_splits(groups, n_cond, n_split, seed=1)
+        kw['_perm_splitsamples'] = np.stack([rsmp.gen_splits(groups, n_cond, n_split, seed=10 + i)
+                                             for i in range(n_perm)])
+    cvs = rsmp.gen_splits(groups, n_cond, 2, seed=3, test_size=0.25)
+    kw['_cvsplits'] = cvs
+    res = pls.behavioral_pls(Xw, Yw, groups=groups, n_cond=n_cond, n_perm=n_perm, n_boot=4,
+                             n_split=n_split or 0, test_split=2, test_size=0.25, seed=4321, verbose=False, **kw)
+    J = n_groups * n_cond
+    assert res.singvals.shape == (J * Tw,)
+    assert res.bootres.x_weights_normed.shape == (Bw, J * Tw)
+    assert res.cvres.pearson_r.shape == (Tw, 2)
+    want = ref.run_plsc(Xw, Yw, method='behavioral', groups=groups, n_cond=n_cond,
+                        permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples,
+                        splitsamples=kw.get('_splitsamples'), perm_splitsamples=kw.get('_perm_splitsamples'))
+    spec = ref.Spec('behavioral', groups, n_cond)
+    cv_r, cv_r2 = ref.crossval(spec, Xw, Yw, cvs)
+    assert_close(res.singvals, want['singvals'], 1e-6, what='singvals')
+    assert_close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-6, what='perm')
+    assert_close(res.permres.pvals, want['permres']['pvals'], 0, what='pvals')
+    lead = slice(0, 20)
+    assert_close(res.bootres.x_weights_normed[:, lead], want['bootres']['x_weights_normed'][:, lead], 1e-4, what='bsr')
+    assert_close(res.cvres.pearson_r, cv_r, 1e-6, what='cv r')
+    assert_close(res.cvres.r_squared, cv_r2, 1e-6, what='cv r2')
+    if n_split:
+        assert_close(res.splitres.ucorr, want['splitres']['ucorr'], 1e-6, what='ucorr')
+        assert_close(res.splitres.vcorr, want['splitres']['vcorr'], 1e-6, what='vcorr')
+        assert_close(res.splitres.ucorr_pvals, want['splitres']['ucorr_pvals'], 0, what='ucorr p')

@@ -211,7 +211,11 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     if (ctx->scratch_fixed) return cap;
     const double gb_per_group = (double)std::max(ctx->npg, ctx->npgf) * ctx->Tpp * (double)ctx->Bpad * 8.0 /
                                 1073741824.0;
-    const double c_group = 40.0 * gb_per_group, c_launch = 2.5;
+    // per-launch cost: one wave of the small solver -- 2.5 ms out of LDS, but ~150 ms
+    // x (T'/200)^3 out of the global workspace (T' > PLSX_LDS_TP, latency bound, one
+    // block per resample: only a large batch keeps the chip busy)
+    const double tn = ctx->Tp / 200.0;
+    const double c_group = 40.0 * gb_per_group, c_launch = ctx->Tp > PLSX_LDS_TP ? 150.0 * tn * tn * tn : 2.5;
     int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
     g = std::max(g, ctx->Galloc);
     return std::max(1, std::min(g, cap));

@@ -939,6 +939,85 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
     }
 }
 
+// Same algorithm for work matrices in GLOBAL memory (T' > PLSX_LDS_TP): every
+// access is an L2 round trip, so all rows a lane owns (IT = rows / 8) are
+// loaded before the first use -- one latency per column pair instead of one
+// per row (the generic loop above waits on every row: 0.31 s for n = 200).
+template <int IT>
+__device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+{
+    const int tid = threadIdx.x;
+    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
+    const int np = (n + 1) >> 1, ne = np * 2;
+    const double tol = 1e-15;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int step = 0; step < ne - 1; ++step) {
+            for (int pr = grp; pr < np; pr += ngrp) {
+                int p, q;
+                if (pr == 0) { p = step; q = ne - 1; }
+                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= n) continue;
+                double* ap = A + (size_t)p * ld + sub;
+                double* aq = A + (size_t)q * ld + sub;
+                double x[IT], y[IT];
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const bool ok = sub + 8 * i < m;
+                    x[i] = ok ? ap[8 * i] : 0.0;
+                    y[i] = ok ? aq[8 * i] : 0.0;
+                }
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    alpha += x[i] * x[i]; beta += y[i] * y[i]; gamma += x[i] * y[i];
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    alpha += __shfl_xor(alpha, o);
+                    beta += __shfl_xor(beta, o);
+                    gamma += __shfl_xor(gamma, o);
+                }
+                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+                    if (sub + 8 * i < m) { ap[8 * i] = c * x[i] - sn * y[i]; aq[8 * i] = sn * x[i] + c * y[i]; }
+                double* vp = V + (size_t)p * ld + sub;
+                double* vq = V + (size_t)q * ld + sub;
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const bool ok = sub + 8 * i < mv;
+                    x[i] = ok ? vp[8 * i] : 0.0;
+                    y[i] = ok ? vq[8 * i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+                    if (sub + 8 * i < mv) { vp[8 * i] = c * x[i] - sn * y[i]; vq[8 * i] = sn * x[i] + c * y[i]; }
+                if (sub == 0) *flag = 1;
+            }
+            __syncthreads();
+        }
+        const int any = *flag;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
+__device__ void jacobi_cols_big(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+{
+    const int rows = max(m, mv);
+    if (rows <= 104) jacobi_cols_big_t<13>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 152) jacobi_cols_big_t<19>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 200) jacobi_cols_big_t<25>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 256) jacobi_cols_big_t<32>(A, m, V, mv, n, ld, flag);
+    else jacobi_cols_big_t<44>(A, m, V, mv, n, ld, flag);      // <= 352 rows
+}
+
 // Fragment-ordered M operand (T' x L) of k_urot / k_ucorr_partial: the 16-column
 // tiles of L are grouped in chunks of PLSX_LT_CHUNK (one launch per chunk: the
 // accumulators of more tiles do not fit the register file); inside a chunk
@@ -1002,7 +1081,8 @@ void k_small(SmallArgs a)
         bufV[c * ld + i] = (i == c) ? 1.0 : 0.0;
     }
     __syncthreads();
-    jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
+    if (GWS) jacobi_cols_big(bufA, n, bufV, n, n, ld, &s_flag);
+    else jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
     // eigenvalues = column norms of G.V (G is PSD)
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
@@ -1085,7 +1165,8 @@ void k_small(SmallArgs a)
         }
     }
     __syncthreads();
-    jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
+    if (GWS) jacobi_cols_big(bufA, L, bufV, n, n, ld, &s_flag);
+    else jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
         for (int i = 0; i < L; ++i) { double x = bufA[c * ld + i]; s += x * x; }

@@ -47,6 +47,8 @@ struct plsx_ctx {
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
     Buf gws;                                            // small-solver workspace (T' > PLSX_LDS_TP)
+    Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
+    int has_cellS = 0;
     int dual = 0;
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
@@ -245,7 +247,7 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
-                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg);
+                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg, SplitEpi{});
     LAUNCHCHK();
     if (ctx->timing) {
         HIPCHK(hipEventRecord(e1, st));
@@ -324,7 +326,7 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
                        ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->Xn), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npgf * ctx->Tpp,
                        ptr<int>(ctx->out_row_f), ptr<int>(ctx->mom_idx_f), ptr<double>(ctx->mom_n), 0,
-                       groups, ncolblk, (double*)nullptr);
+                       groups, ncolblk, (double*)nullptr, SplitEpi{});
     LAUNCHCHK();
     if (ctx->timing) {
         HIPCHK(hipEventRecord(e1, st));
@@ -778,7 +780,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete ctx;
@@ -893,7 +895,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
                         "stacked dimension T' (plus its per-cell moment rows) exceeds the 384 rows of a block");
     }
     if (int e = upload_rowmaps(ctx)) return e;
-    ctx->fix = 0; ctx->npgf = 0; ctx->group_stride_f = 0;
+    ctx->fix = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
     {
         const char* nf = getenv("PLSX_NO_FIXED_X");
         if (method == PLSX_BEHAVIORAL && !ctx->cov && !(nf && atoi(nf))) {
@@ -1164,6 +1166,81 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
     return PLSX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// First halves of m splits through the cross-product kernel as raw sums; its
+// epilogue writes both halves of split i to R slots 2i and 2i + 1 (see SplitEpi).
+template <int NSQ>
+int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_t st)
+{
+    constexpr int MT = 24, NW = 4, KT = 1, NMOM = NSQ * 16;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
+    const size_t epi = (size_t)NW * 5 * NMOM * 16 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
+    const size_t lds = std::max(stage, epi);
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ, 2048>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ, 2048>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds,
+                       st, ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                       ptr<double>(ctx->R), ctx->Bpad, ctx->npg * 2 * ctx->Tpp, ptr<int>(ctx->out_row_s),
+                       ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 0), groups,
+                       ncolblk, (double*)nullptr, se);
+    LAUNCHCHK();
+    return 0;
+}
+
+int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, hipStream_t st)
+{
+    const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
+    if (!ctx->has_cellS) {
+        if (int e = ensure(ctx, ctx->cellS, (size_t)2 * J * ctx->Bpad * 8, true)) return e;
+        hipLaunchKernelGGL(k_cell_moments, dim3(ceil_div(ctx->B, 256)), dim3(256), 0, st, ptr<double>(ctx->Xc),
+                           ctx->Bpad, ctx->B, J, ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len),
+                           ptr<double>(ctx->cellS), ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad);
+        LAUNCHCHK();
+        std::vector<int> orow(rows, -1);
+        for (int rr = 0; rr < ctx->npg; ++rr)
+            for (int t = 0; t < ctx->Tp; ++t) orow[rr * ctx->Tp + t] = rr * 2 * ctx->Tpp + t;
+        if (int e = ensure(ctx, ctx->out_row_s, rows * sizeof(int))) return e;
+        HIPCHK(hipMemcpy(ctx->out_row_s.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+        ctx->has_cellS = 1;
+    }
+    const int groups = ceil_div(m, ctx->npg);
+    if (int e = ensure_scratch(ctx, 2 * groups)) return e;
+    if (int e = ensure(ctx, ctx->rowc, (size_t)groups * rows * 5 * 8)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->mom_n.p, 0, (size_t)groups * std::max(ctx->nmom_pad, 16) * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->rowc.p, 0, (size_t)groups * rows * 5 * 8, st));
+    GroupLayout lay;
+    lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = J; lay.T = ctx->T; lay.MT = ctx->MT;
+    lay.w0 = ctx->w0; lay.sq0 = ctx->sq0; lay.Tpp = ctx->Tpp;
+    hipLaunchKernelGGL(k_build_A_split, dim3(m, J), dim3(256), 0, st, ptr<double>(ctx->Y), ctx->T, S,
+                       ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), perm, masks, lay,
+                       ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->mom_n), ctx->nmom_pad,
+                       ptr<double>(ctx->rowc));
+    LAUNCHCHK();
+    SplitEpi se;
+    se.Rfull = ptr<double>(ctx->Rfull);
+    se.cellS1 = ptr<double>(ctx->cellS);
+    se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
+    se.cell_len = ptr<int>(ctx->cell_len);
+    se.rowc = ptr<double>(ctx->rowc);
+    se.J = J; se.Tpp = ctx->Tpp;
+    switch (ctx->MT - ctx->sq0) {
+        case 1: return launch_xprod_split<1>(ctx, groups, se, st);
+        case 2: return launch_xprod_split<2>(ctx, groups, se, st);
+        default: return launch_xprod_split<3>(ctx, groups, se, st);
+    }
+}
+}  // namespace
+
+extern "C" {
+
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, const uint8_t* d_masks,
                           int ns, double* d_ucorr, double* d_vcorr, void* stream)
 {
@@ -1180,6 +1257,10 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     if (int e = ensure(ctx, ctx->dp, (size_t)L * 8)) return e;
     if (int e = ensure(ctx, ctx->Mvd, (size_t)ctx->nks_t * ctx->LT * 64 * 8)) return e;
     const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
+    // behavioral correlation mode: only the first half of a split takes the MFMA pass
+    const bool fused = ctx->scaled && !permute_x && ctx->Gcap >= 2 && !getenv("PLSX_NO_SPLIT_FUSE");
+    // splits per pass (the fused path writes two R slots per split from groups of npg splits)
+    const int spp = fused ? std::max(1, std::min(nb / 2, (ctx->Gcap / 2) * ctx->npg)) : nb / 2;
     for (int p = 0; p < np; ++p) {
         const int* perm = d_perm_idx ? d_perm_idx + (size_t)p * S : nullptr;
         // full-sample arrangement: R_p, then V_p, d_p and M = V_p / d_p (= vd, fragment order)
@@ -1189,16 +1270,21 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
         SmallArgs a = small_args(ctx, SMALL_DECOMP);
         a.out_V = ptr<double>(ctx->Vp); a.out_d = ptr<double>(ctx->dp); a.Mfrag = ptr<double>(ctx->Mvd);
         if (int e = run_small(ctx, a, 1, st)) return e;
-        for (int off = 0; off < ns; off += nb / 2) {
-            const int m = std::min(nb / 2, ns - off);            // splits in this pass
-            if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
-            if (int e = ensure(ctx, ctx->srcy, (size_t)2 * m * S * sizeof(int))) return e;
-            hipLaunchKernelGGL(k_split_src, dim3(ceil_div(S, 256), 2 * m), dim3(256), 0, st, perm,
-                               d_masks + ((size_t)p * ns + off) * S, m, S, permute_x,
-                               ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
-            LAUNCHCHK();
-            if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy), 2 * m, st))
-                return e;
+        for (int off = 0; off < ns; off += spp) {
+            const int m = std::min(spp, ns - off);               // splits in this pass
+            if (fused) {
+                if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, st)) return e;
+            } else {
+                if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
+                if (int e = ensure(ctx, ctx->srcy, (size_t)2 * m * S * sizeof(int))) return e;
+                hipLaunchKernelGGL(k_split_src, dim3(ceil_div(S, 256), 2 * m), dim3(256), 0, st, perm,
+                                   d_masks + ((size_t)p * ns + off) * S, m, S, permute_x,
+                                   ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
+                LAUNCHCHK();
+                if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy), 2 * m,
+                                      st))
+                    return e;
+            }
             // C_h = D_h . R_p^T  (T' x T')
             if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
             if (int e = run_gram_ex(ctx, 2 * m, 2, ptr<double>(ctx->Rfull), Tp, ptr<double>(ctx->Cm), st)) return e;

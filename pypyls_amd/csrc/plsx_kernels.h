@@ -233,6 +233,99 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
     }
 }
 
+// Column sums of Xc and Xc^2 per cell: S1[j][b], S2[j][b] (full-sample moments
+// the fused split-half epilogue subtracts the first half's from).
+__global__ void k_cell_moments(const double* __restrict__ Xc, int ldx, int B, int J,
+                               const int* __restrict__ cell_start, const int* __restrict__ cell_len,
+                               double* __restrict__ S1, double* __restrict__ S2)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int j = 0; j < J; ++j) {
+        const int r0 = cell_start[j], n = cell_len[j];
+        double s = 0.0, q = 0.0;
+        for (int i = r0; i < r0 + n; ++i) { const double x = Xc[(size_t)i * ldx + b]; s += x; q += x * x; }
+        S1[(size_t)j * ldx + b] = s;
+        S2[(size_t)j * ldx + b] = q;
+    }
+}
+
+// Fused split-half (behavioral PLS, correlation mode).  Only the FIRST half of a
+// split goes through the MFMA pass, as raw sums: data rows hold
+// d = Y[perm] - mean_cell(Y[perm]) on the half's rows, the moment rows its
+// counts.  Everything about a half is additive over rows, so the second half is
+// (full sample) - (first half):
+//   C_h[t][b] = sum_{i in h} d_it x_ib,  Sx_h, Sxx_h, Sy_h, Syy_h, n_h;
+//   R_h = (C_h - Sy_h Sx_h / n_h) / ((n_h - 1) sigma_y,h sigma_x,h),
+//   C_full = (n_F - 1) sigma_y,F sigma_x,F R_full  (R_full: the arrangement's own
+//   z-scored cross-product, already computed for its decomposition).
+// The epilogue of k_xprod forms both halves from the accumulators: one MFMA
+// pass per split instead of two.
+struct SplitEpi {
+    const double* Rfull;     // (T' rows) x ldr of the arrangement
+    const double* cellS1;    // [J][ldr]
+    const double* cellS2;    // [J][ldr]
+    const int* cell_len;     // [J]
+    const double* rowc;      // [groups][MT*16][5]: Sy1, 1/((n1-1) sy1), Sy2, 1/((n2-1) sy2), (nF-1) syF
+    int J, Tpp;
+};
+
+// grid (n_splits, J), block 256, dynamic LDS 0.
+__global__ void k_build_A_split(const double* __restrict__ Y, int T, int S,
+                                const int* __restrict__ cell_start, const int* __restrict__ cell_len,
+                                const int* __restrict__ perm, const uint8_t* __restrict__ masks,
+                                GroupLayout lay, double* __restrict__ Afrag, size_t group_stride,
+                                double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc)
+{
+    const int i = blockIdx.x, j = blockIdx.y;
+    const int g = i / lay.n, rr = i % lay.n;
+    const int start = cell_start[j], len = cell_len[j];
+    const uint8_t* mk = masks + (size_t)i * S;
+    const int tid = threadIdx.x;
+    double* A = Afrag + (size_t)g * group_stride;
+    __shared__ int s_n1;
+    if (tid == 0) {
+        int c = 0;
+        for (int p = start; p < start + len; ++p) c += mk[p] != 0;
+        s_n1 = c;
+    }
+    __syncthreads();
+    const int n1 = s_n1, n2 = len - n1;
+    for (int t = tid; t < T; t += blockDim.x) {
+        double s = 0.0;
+        for (int p = start; p < start + len; ++p) s += Y[(size_t)(perm ? perm[p] : p) * T + t];
+        const double mF = s / (double)len;
+        double syyF = 0.0, sy1 = 0.0, syy1 = 0.0, syF = 0.0;
+        for (int p = start; p < start + len; ++p) {
+            const double d = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
+            syF += d; syyF += d * d;
+            if (mk[p]) { sy1 += d; syy1 += d * d; }
+        }
+        const double sy2 = syF - sy1, syy2 = syyF - syy1;
+        const double v1 = (n1 > 1) ? (syy1 - sy1 * sy1 / n1) / (n1 - 1.0) : 0.0;
+        const double v2 = (n2 > 1) ? (syy2 - sy2 * sy2 / n2) / (n2 - 1.0) : 0.0;
+        const double vF = (syyF - syF * syF / len) / (len - 1.0);
+        const int row = rr * lay.Tp + j * T + t;
+        double* rc = rowc + ((size_t)g * lay.MT * 16 + row) * 5;
+        rc[0] = sy1;
+        rc[1] = (v1 > 0.0) ? 1.0 / ((n1 - 1.0) * sqrt(v1)) : 0.0;
+        rc[2] = sy2;
+        rc[3] = (v2 > 0.0) ? 1.0 / ((n2 - 1.0) * sqrt(v2)) : 0.0;
+        rc[4] = (vF > 0.0) ? (len - 1.0) * sqrt(vF) : 0.0;
+        // data row: d on the first half's rows
+        for (int p = start; p < start + len; ++p)
+            if (mk[p]) A[afrag_off(row, p, lay.MT)] = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
+    }
+    const int mrow = rr * lay.J + j;
+    for (int pl = tid; pl < len; pl += blockDim.x) {
+        const int p = start + pl;
+        if (!mk[p]) continue;
+        A[afrag_off(lay.w0 * 16 + mrow, p, lay.MT)] = 1.0;
+        A[afrag_off(lay.sq0 * 16 + mrow, p, lay.MT)] = 1.0;
+    }
+    if (tid == 0) mom_n[(size_t)g * nmom_pad + mrow] = (double)n1;
+}
+
 // ---------------------------------------------------------------------------
 // K_R: resampled cross-product  R[r] = scale o (A_r . X)
 // ---------------------------------------------------------------------------
@@ -306,7 +399,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              double* __restrict__ R, int ldr, int rows_per_group,
              const int* __restrict__ out_row, const int* __restrict__ mom_idx,
              const double* __restrict__ mom_n, int nmom_pad,
-             int n_groups, int ncolblk, double* __restrict__ mom_out)
+             int n_groups, int ncolblk, double* __restrict__ mom_out, SplitEpi se)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = NW * 64;                      // threads
@@ -413,6 +506,60 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
     // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
+    constexpr bool SPLIT = (DBG & 2048) != 0;
+    if constexpr (SPLIT && NSQ > 0) {
+        // fused split-half: both halves from the first half's raw sums (see SplitEpi)
+        double* w5 = smem + wave * (5 * NMOM * 16);          // u1, v1, u2, v2, sF : [5][NMOM][16] per wave
+        int* s_out = reinterpret_cast<int*>(smem + NW * 5 * NMOM * 16);
+        int* s_mom = s_out + MT * 16;
+        double* s_rc = reinterpret_cast<double*>(s_mom + MT * 16);   // [MT*16][5]
+        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+        for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
+        // moments of the first half sit in the accumulators of tiles W0+j / SQ0+j
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int mr = j * 16 + kq + 4 * i;
+                const int o = mr * 16 + (lane & 15);
+                const double n1 = mom_n[(size_t)grp * nmom_pad + mr];
+                const double m1 = acc[W0 + j][i], m2 = acc[SQ0 + j][i];
+                const int jc = mr % se.J;
+                const double nF = (double)se.cell_len[jc];
+                const double SF = se.cellS1[(size_t)jc * ldr + col], SFF = se.cellS2[(size_t)jc * ldr + col];
+                const double n2 = nF - n1;
+                const bool ok = n1 > 1.5 && n2 > 1.5;
+                const double var1 = ok ? (m2 - m1 * m1 / n1) / (n1 - 1.0) : 0.0;
+                const double s2x = SF - m1, s2xx = SFF - m2;
+                const double var2 = ok ? (s2xx - s2x * s2x / n2) / (n2 - 1.0) : 0.0;
+                const double varF = (SFF - SF * SF / nF) / (nF - 1.0);
+                w5[0 * NMOM * 16 + o] = ok ? m1 / n1 : 0.0;
+                w5[1 * NMOM * 16 + o] = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
+                w5[2 * NMOM * 16 + o] = ok ? s2x / n2 : 0.0;
+                w5[3 * NMOM * 16 + o] = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
+                w5[4 * NMOM * 16 + o] = (varF > 0.0) ? sqrt(varF) : 0.0;
+            }
+        __syncthreads();
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+        const int pitch2 = 2 * se.Tpp;
+#pragma unroll
+        for (int m = 0; m < W0; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m * 16 + kq + 4 * i;
+                const int orow = s_out[row];
+                if (orow < 0) continue;
+                const int o = s_mom[row] * 16 + (lane & 15);
+                const double* rc = s_rc + row * 5;
+                const int t = orow % pitch2;
+                const double c1 = acc[m][i];
+                const double cf = se.Rfull[(size_t)t * ldr + col] * rc[4] * w5[4 * NMOM * 16 + o];
+                Rg[(size_t)orow * ldr] = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * NMOM * 16 + o];
+                Rg[(size_t)(orow + se.Tpp) * ldr] =
+                    ((cf - c1) - rc[2] * w5[2 * NMOM * 16 + o]) * rc[3] * w5[3 * NMOM * 16 + o];
+            }
+        return;
+    }
     double* sS = smem + wave * (2 * NMOM * 16);      // m1 -> 1/std : [NMOM][16] per wave
     double* sQ = sS + NMOM * 16;                     // m2
     int* s_out = reinterpret_cast<int*>(smem + NW * 2 * NMOM * 16);   // row maps, shared

@@ -257,3 +257,27 @@ def test_bootstrap_kernel_variants_agree(shape, monkeypatch):
         assert np.array_equal(a, b)                       # same arithmetic, same order
     for a, b in zip(got['default'], got['gram16']):
         assert_close(a, b, 1e-9, what='gram4 vs gram16')
+
+
+@pytest.mark.parametrize('shape', [(60, 900, 5, [60], 1), (72, 500, 4, [18, 18], 2)])
+def test_split_half_fused_equals_two_pass(shape, monkeypatch):
+    """Fused split-half (second half = full sample - first half, one MFMA pass
+    per split) against the two-pass path (PLSX_NO_SPLIT_FUSE), original and
+    permuted arrangements."""
+    from pypyls_amd import resampling as rsmp
+    S, B, T, groups, n_cond = shape
+    X, Y, rs = _data(S, B, T, seed=21)
+    n_split = 9
+    perms = rsmp.gen_permsamp(groups, n_cond, 3, seed=5)
+    masks = np.stack([rsmp.gen_splits(groups, n_cond, n_split, seed=30 + i) for i in range(3)])   # (P, S, ns)
+    got = {}
+    for key in ('fused', 'two_pass'):
+        monkeypatch.delenv('PLSX_NO_SPLIT_FUSE', raising=False)
+        if key == 'two_pass':
+            monkeypatch.setenv('PLSX_NO_SPLIT_FUSE', '1')
+        eng = _engine()
+        _setup(eng, X, Y, groups, n_cond)
+        got[key] = (eng.split_half(masks[0]), eng.split_half(masks, perms=perms))
+    for a, b in zip(got['fused'], got['two_pass']):
+        for x, y in zip(a, b):
+            assert_close(x, y, 1e-9, what='fused vs two-pass split-half')

@@ -836,6 +836,9 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
     ctx->has_data = ctx->has_orig = false;
+    // a re-bound context keeps its scratch: the padding rows (t >= T') of every R slot must
+    // read as zero under the new layout too
+    if (ctx->R.p) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
     ctx->has_okx = ctx->has_oky = false;
     ctx->Galloc = 0;
     ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_MEANCENTERED) ? 0 : T;

@@ -179,3 +179,31 @@ def test_nonfinite_input_rejected():
         pls.behavioral_pls(X, Yb, n_perm=0, n_boot=0, test_split=0)
     with pytest.raises(ValueError):
         pls.meancentered_pls(Xb, groups=[15, 15], n_perm=0, n_boot=0)
+
+
+def test_context_rebinding_matches_fresh_context():
+    """plsx_set_data on a context that already ran another problem (larger, then
+    smaller, different method): stale scratch must not leak into the results."""
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(9)
+
+    def run(eng, S, B, T, groups, n_cond):
+        X = np.random.RandomState(S + B).randn(S, B)
+        Y = np.random.RandomState(T).randn(S, T) + 0.4 * X[:, :T]
+        spec = _bind(eng, X, Y, groups, n_cond)
+        U, d, V = ref.decompose(spec, X, Y)
+        eng.set_original(U, np.diag(d), V)
+        perms = rsmp.gen_permsamp(groups, n_cond, 6, seed=1)
+        boots = rsmp.gen_bootsamp(groups, n_cond, 6, seed=2)
+        masks = rsmp.gen_splits(groups, n_cond, 5, seed=3)
+        usum, usq, dist = eng.boot(boots)
+        uc, vc = eng.split_half(masks)
+        return eng.perm(perms), usum.cpu().numpy(), usq.cpu().numpy(), dist, uc, vc
+
+    shapes = [(90, 700, 12, [45, 45], 1), (40, 130, 3, [40], 1), (64, 300, 20, [16, 16], 2)]
+    shared = _engine()
+    for shp in shapes:
+        got = run(shared, *shp)
+        want = run(_engine(), *shp)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)

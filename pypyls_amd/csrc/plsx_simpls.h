@@ -139,12 +139,43 @@ void k_simpls_dual(SimplsArgs a)
         }
     }
     const double ssY = block_sum(ssy_part, red);
-    // Z = K_r Yd, column by column
-    for (int t = 0; t < T; ++t) {
-        for (int p = tid; p < S; p += NT) va[p] = Yd[(size_t)p * T + t];
+    // Z = K_r Yd.  K (S x S) does not fit an XCD's L2, so every pass over it is
+    // paid in fabric bandwidth (the kernel's bottleneck): the T columns are done
+    // in tiles of ZT with one pass per tile instead of one per column.  Yd is
+    // already centred over the included rows (excluded rows are zero), so only the
+    // output centring of kop() remains.
+    {
+        constexpr int ZT = 10;
         __syncthreads();
-        kop(a.K, S, xs, inc, ninc, va, vz, nullptr, vc, red);
-        for (int p = tid; p < S; p += NT) Z[(size_t)p * T + t] = vz[p];
+        for (int t0 = 0; t0 < T; t0 += ZT) {
+            const int nt = min(ZT, T - t0);
+            for (int p = tid; p < S; p += NT) {
+                double acc[ZT];
+#pragma unroll
+                for (int t = 0; t < ZT; ++t) acc[t] = 0.0;
+                if (inc[p]) {
+                    const int col = xs[p];
+                    for (int q = 0; q < S; ++q) {
+                        if (!inc[q]) continue;
+                        const double kv = a.K[(size_t)xs[q] * S + col];
+                        const double* yq = Yd + (size_t)q * T + t0;
+#pragma unroll
+                        for (int t = 0; t < ZT; ++t)
+                            if (t < nt) acc[t] += kv * yq[t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < ZT; ++t)
+                    if (t < nt) Z[(size_t)p * T + t0 + t] = acc[t];
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            double part = 0.0;
+            for (int p = tid; p < S; p += NT) if (inc[p]) part += Z[(size_t)p * T + t];
+            const double zmean = block_sum(part, red) / ninc;
+            for (int p = tid; p < S; p += NT) if (inc[p]) Z[(size_t)p * T + t] -= zmean;
+        }
         __syncthreads();
     }
     // H = Yd^T Z

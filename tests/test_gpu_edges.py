@@ -207,3 +207,27 @@ def test_context_rebinding_matches_fresh_context():
         want = run(_engine(), *shp)
         for a, b in zip(got, want):
             assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_full_size_one_resample_against_oracle():
+    """One permutation and one bootstrap at the BASELINE size, directly against
+    the oracle (~10 s of host time)."""
+    from pypyls_amd import hostmath, resampling as rsmp
+    S, B, T = 500, 200000, 50
+    rs = np.random.RandomState(3)
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.3 * X[:, :T]
+    eng = _engine()
+    spec = _bind(eng, X, Y, [S], 1)
+    xw, sv, yw = eng.decompose()
+    xw, yw = hostmath.sign_convention(xw, yw)
+    eng.set_original(xw, sv, yw)
+    perm = rsmp.gen_permsamp([S], 1, 1, seed=11)
+    boot = rsmp.gen_bootsamp([S], 1, 1, seed=12)
+    got_p = eng.perm(perm)[:, 0]
+    want_p = ref.single_perm(spec, X, Y, perm[:, 0], yw)[0]
+    assert_close(got_p, want_p, 1e-7, what='perm singvals at full size')
+    usum, usq, dist = eng.boot(boot)
+    wd, wu = ref.single_boot(spec, X, Y, boot[:, 0], xw, np.diag(sv))
+    assert_close(usum.cpu().numpy(), wu, 1e-6, what='rotated bootstrap weights at full size')
+    assert_close(dist[:, :, 0], wd, 1e-7, what='bootstrap distrib at full size')

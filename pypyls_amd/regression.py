@@ -126,16 +126,23 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     k = n_components
 
     # regression.py:395-397 (on copies: the reference centres the caller's X in place)
-    Xc = X.astype(np.float64) - np.nanmean(X, axis=0, keepdims=True)
     Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
-    okx, oky = _row_ok(Xc), _row_ok(Yc)
-    mask = okx & oky
-    masked = not mask.all()
-    B, T = Xc.shape[1], Yc.shape[1]
+    B, T = X.shape[1], Yc.shape[1]
     eng = kwargs.get('_engine') or Engine()
-    eng.set_data_regression(np.nan_to_num(Xc), np.nan_to_num(Yc), k)
-    if masked:
-        eng.simpls_set_row_masks(okx, oky)
+    if np.isfinite(X.mean(axis=0)).all() and np.isfinite(Yc).all():
+        # no missing data (one cheap pass): the device centres X itself (plsx_set_data),
+        # so the S x B matrix is not copied / centred / scanned on the host
+        okx = oky = mask = np.ones(S, dtype=bool)
+        masked = False
+        eng.set_data_regression(X, Yc, k)
+    else:
+        Xc = X.astype(np.float64) - np.nanmean(X, axis=0, keepdims=True)
+        okx, oky = _row_ok(Xc), _row_ok(Yc)
+        mask = okx & oky
+        masked = not mask.all()
+        eng.set_data_regression(np.nan_to_num(Xc), np.nan_to_num(Yc), k)
+        if masked:
+            eng.simpls_set_row_masks(okx, oky)
     res = PLSResults(inputs=inputs)
 
     # the reference's rank-1 randomized SVD draws normal((min(B, T), 11)) per

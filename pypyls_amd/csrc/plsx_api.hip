@@ -565,7 +565,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
         if (int e = ensure(ctx, ctx->gws, (size_t)nres * 2 * n * ld * 8)) return e;
         a.gws = ptr<double>(ctx->gws);
         const size_t lds = (size_t)2 * n * 8 + (size_t)2 * n * 4 + 64;
-        hipLaunchKernelGGL(k_small<true>, dim3(nres), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(k_small<true>, dim3(nres), dim3(1024), lds, st, a);
         LAUNCHCHK();
         return 0;
     }

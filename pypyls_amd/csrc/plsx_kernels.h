@@ -1086,25 +1086,32 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
     }
 }
 
-// Same algorithm for work matrices in GLOBAL memory (T' > PLSX_LDS_TP): every
-// access is an L2 round trip, so all rows a lane owns (IT = rows / 8) are
-// loaded before the first use -- one latency per column pair instead of one
-// per row (the generic loop above waits on every row: 0.31 s for n = 200).
-template <int IT>
+// Same algorithm for work matrices in GLOBAL memory (T' > PLSX_LDS_TP).  Every
+// access is an L2 round trip (~2 us when the same lines were just written), so
+// the step time is (passes over the pairs) x (round trips per pass): the block
+// has 1024 threads so that all pairs of a step are in flight at once (LANES
+// lanes per pair, IT = rows / LANES values per lane, loaded before the first
+// use: one round trip for the two A columns, one for the two V columns).
+// The row-at-a-time loop of jacobi_cols took 0.31 s for n = 200; this, 8 lanes x
+// 256-thread blocks 0.15 s.
+template <int IT, int LANES>
 __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, int ld, int* flag)
 {
     const int tid = threadIdx.x;
-    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
-    const int np = (n + 1) >> 1, ne = np * 2;
+    const int sub = tid % LANES, grp = tid / LANES, ngrp = blockDim.x / LANES;
+    const int np = (n + 1) >> 1, ne = np * 2, mod = ne - 1;
     const double tol = 1e-15;
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
-        for (int step = 0; step < ne - 1; ++step) {
+        for (int step = 0; step < mod; ++step) {
             for (int pr = grp; pr < np; pr += ngrp) {
                 int p, q;
                 if (pr == 0) { p = step; q = ne - 1; }
-                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
+                else {
+                    p = step + pr; if (p >= mod) p -= mod;
+                    q = step + mod - pr; if (q >= mod) q -= mod;
+                }
                 if (p > q) { int t = p; p = q; q = t; }
                 if (q >= n) continue;
                 double* ap = A + (size_t)p * ld + sub;
@@ -1112,9 +1119,9 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
                 double x[IT], y[IT];
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + 8 * i < m;
-                    x[i] = ok ? ap[8 * i] : 0.0;
-                    y[i] = ok ? aq[8 * i] : 0.0;
+                    const bool ok = sub + LANES * i < m;
+                    x[i] = ok ? ap[LANES * i] : 0.0;
+                    y[i] = ok ? aq[LANES * i] : 0.0;
                 }
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
@@ -1122,7 +1129,7 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
                     alpha += x[i] * x[i]; beta += y[i] * y[i]; gamma += x[i] * y[i];
                 }
 #pragma unroll
-                for (int o = 1; o < 8; o <<= 1) {
+                for (int o = 1; o < LANES; o <<= 1) {
                     alpha += __shfl_xor(alpha, o);
                     beta += __shfl_xor(beta, o);
                     gamma += __shfl_xor(gamma, o);
@@ -1133,18 +1140,24 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
                 const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
-                    if (sub + 8 * i < m) { ap[8 * i] = c * x[i] - sn * y[i]; aq[8 * i] = sn * x[i] + c * y[i]; }
+                    if (sub + LANES * i < m) {
+                        ap[LANES * i] = c * x[i] - sn * y[i];
+                        aq[LANES * i] = sn * x[i] + c * y[i];
+                    }
                 double* vp = V + (size_t)p * ld + sub;
                 double* vq = V + (size_t)q * ld + sub;
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + 8 * i < mv;
-                    x[i] = ok ? vp[8 * i] : 0.0;
-                    y[i] = ok ? vq[8 * i] : 0.0;
+                    const bool ok = sub + LANES * i < mv;
+                    x[i] = ok ? vp[LANES * i] : 0.0;
+                    y[i] = ok ? vq[LANES * i] : 0.0;
                 }
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
-                    if (sub + 8 * i < mv) { vp[8 * i] = c * x[i] - sn * y[i]; vq[8 * i] = sn * x[i] + c * y[i]; }
+                    if (sub + LANES * i < mv) {
+                        vp[LANES * i] = c * x[i] - sn * y[i];
+                        vq[LANES * i] = sn * x[i] + c * y[i];
+                    }
                 if (sub == 0) *flag = 1;
             }
             __syncthreads();
@@ -1158,11 +1171,11 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
 __device__ void jacobi_cols_big(double* A, int m, double* V, int mv, int n, int ld, int* flag)
 {
     const int rows = max(m, mv);
-    if (rows <= 104) jacobi_cols_big_t<13>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 152) jacobi_cols_big_t<19>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 200) jacobi_cols_big_t<25>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 256) jacobi_cols_big_t<32>(A, m, V, mv, n, ld, flag);
-    else jacobi_cols_big_t<44>(A, m, V, mv, n, ld, flag);      // <= 352 rows
+    if (rows <= 104) jacobi_cols_big_t<13, 8>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 152) jacobi_cols_big_t<19, 8>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 200) jacobi_cols_big_t<25, 8>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 256) jacobi_cols_big_t<16, 16>(A, m, V, mv, n, ld, flag);
+    else jacobi_cols_big_t<22, 16>(A, m, V, mv, n, ld, flag);   // <= 352 rows
 }
 
 // Fragment-ordered M operand (T' x L) of k_urot / k_ucorr_partial: the 16-column
@@ -1204,7 +1217,7 @@ struct SmallArgs {
 // GWS = true: they live in a per-resample global workspace (L2); same code,
 // latency bound but one block per resample keeps the chip busy.
 template <bool GWS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(GWS ? 1024 : 256)
 void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];

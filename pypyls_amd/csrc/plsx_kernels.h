@@ -10,8 +10,13 @@
 // index so HBM accesses are row-contiguous.
 //
 //   k_xprod      R = scale o (A . X)          (n*T' x S) . (S x B)     "K_R"
-//   k_nt_gemm    C = P . Q^T, contraction over B (Gram / projections)  "K_G"
+//                (+ split-half epilogue: both halves from one pass)
+//   k_gram4      bootstrap Gram G = R R^T (upper blocks) and P = R U0 on
+//                v_mfma_f64_4x4x4_4b_f64 (4-row granularity)           "K_G"
+//   k_gram / k_nt_gemm   the same products on 16x16x4 tiles (T' > 52, G only,
+//                generic NT GEMM: dual-space permutations, SIMPLS K, CV)
 //   k_urot       U = R^T . M, fused sum / sum-of-squares accumulation  "K_U"
+//   k_ucorr_partial   split-half feature-axis correlation sums
 //   k_small      T'xT' Jacobi eigen-solve + Procrustes polar factor    "K4-K6"
 //
 // Reference semantics implemented (pyls/...): compute.xcorr :55-94,

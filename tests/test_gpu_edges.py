@@ -1,4 +1,5 @@
 """Edge cases and full-size properties of the device path (GPU only)."""
+import os
 import numpy as np
 import pytest
 
@@ -231,3 +232,16 @@ def test_full_size_one_resample_against_oracle():
     wd, wu = ref.single_boot(spec, X, Y, boot[:, 0], xw, np.diag(sv))
     assert_close(usum.cpu().numpy(), wu, 1e-6, what='rotated bootstrap weights at full size')
     assert_close(dist[:, :, 0], wd, 1e-7, what='bootstrap distrib at full size')
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: random designs / shapes / options (behavioral with and
+    without covariance, mean-centred with every centring, 1-3 groups x 1-3
+    conditions, B from 3 to 1500, rotate on / off, split-half) against the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '40', '123'],
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert 'failures: 0 of 40' in proc.stdout

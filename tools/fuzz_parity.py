@@ -94,6 +94,33 @@ def one_case(rs, idx):
     return desc, 'ok'
 
 
+def regression_case(rs, idx):
+    import pypyls_amd as pls
+    global LAST
+    S = int(rs.randint(12, 90))
+    B = int(rs.choice([5, 40, 300, 1200]))
+    T = int(rs.choice([1, 3, 8, 20]))
+    k = int(rs.randint(1, min(S - 3, B, T, 12) + 1))      # beyond rank(Y) = T the components are noise-defined
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T)
+    m = min(T, B)
+    Y[:, :m] += 0.6 * X[:, :m]
+    nan_rows = rs.rand() < 0.3
+    if nan_rows:
+        X[int(rs.randint(S))] = np.nan
+        Y[int(rs.randint(S))] = np.nan
+        k = min(k, S - 5)
+    LAST = desc = dict(i=idx, method='regression', S=S, B=B, T=T, k=k, nan_rows=bool(nan_rows))
+    res = pls.pls_regression(X, Y, n_components=k, n_perm=6, n_boot=5, seed=int(rs.randint(1 << 30)), verbose=False)
+    want = ref.run_regression(X, Y, k, permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples)
+    for key in ('x_weights', 'y_loadings', 'varexp'):
+        close(res[key], want[key], 1e-5, key)
+    close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-5, 'perm varexp')
+    close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-4, 'bsr')
+    close(res.bootres.y_loadings_boot, want['bootres']['y_loadings_boot'], 1e-5, 'y_loadings_boot')
+    return desc, 'ok'
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -102,7 +129,7 @@ def main():
     for i in range(n):
         sub = np.random.RandomState(rs.randint(1 << 30))
         try:
-            desc, status = one_case(sub, i)
+            desc, status = regression_case(sub, i) if i % 5 == 4 else one_case(sub, i)
         except Exception as e:                          # report and go on
             bad += 1
             print('FAIL', i, type(e).__name__, str(e)[:200], LAST, flush=True)

@@ -1197,7 +1197,8 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_
     return 0;
 }
 
-int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, hipStream_t st)
+int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
+                    hipStream_t st)
 {
     const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
     if (!ctx->has_cellS) {
@@ -1228,7 +1229,7 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
                        ptr<double>(ctx->rowc));
     LAUNCHCHK();
     SplitEpi se;
-    se.Rfull = ptr<double>(ctx->Rfull);
+    se.Rfull = Rfull;
     se.cellS1 = ptr<double>(ctx->cellS);
     se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
     se.cell_len = ptr<int>(ctx->cell_len);
@@ -1255,57 +1256,76 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     const int S = ctx->S, Tp = ctx->Tp, L = ctx->L;
     const int nb = ((launch_groups(ctx, 2LL * np * ns, ctx->npg) * ctx->npg) / 2) * 2;   // slots per super-batch (pairs of halves)
     if (nb < 2) return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_split_half_batch: scratch too small");
-    if (int e = ensure(ctx, ctx->Rfull, (size_t)ctx->strideR * 8)) return e;
-    if (int e = ensure(ctx, ctx->Vp, (size_t)Tp * L * 8)) return e;
-    if (int e = ensure(ctx, ctx->dp, (size_t)L * 8)) return e;
-    if (int e = ensure(ctx, ctx->Mvd, (size_t)ctx->nks_t * ctx->LT * 64 * 8)) return e;
+    // Arrangements (permutations) are decomposed in chunks: one cross-product launch, one
+    // Gram launch and one small-solver launch for up to `pcmax` of them instead of three
+    // latency-bound launches per permutation (4 ms each at c4, as much as ten of its splits).
+    const size_t mstride = (size_t)ctx->nks_t * ctx->LT * 64;
+    int pcmax = 1;
+    if (d_perm_idx) {
+        const long long by_mem = std::max<long long>(1, (4LL << 30) / (ctx->strideR * 8));
+        pcmax = (int)std::min<long long>(std::min<long long>(64, by_mem), np);
+        pcmax = std::min(pcmax, std::max(1, ctx->Gcap * ctx->npg));
+    }
+    if (int e = ensure(ctx, ctx->Rfull, (size_t)pcmax * ctx->strideR * 8)) return e;
+    if (int e = ensure(ctx, ctx->Vp, (size_t)pcmax * Tp * L * 8)) return e;
+    if (int e = ensure(ctx, ctx->dp, (size_t)pcmax * L * 8)) return e;
+    if (int e = ensure(ctx, ctx->Mvd, (size_t)pcmax * mstride * 8 + 1024)) return e;
     const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
     // behavioral correlation mode: only the first half of a split takes the MFMA pass
     const bool fused = ctx->scaled && !permute_x && ctx->Gcap >= 2 && !getenv("PLSX_NO_SPLIT_FUSE");
     // splits per pass (the fused path writes two R slots per split from groups of npg splits)
     const int spp = fused ? std::max(1, std::min(nb / 2, (ctx->Gcap / 2) * ctx->npg)) : nb / 2;
-    for (int p = 0; p < np; ++p) {
-        const int* perm = d_perm_idx ? d_perm_idx + (size_t)p * S : nullptr;
-        // full-sample arrangement: R_p, then V_p, d_p and M = V_p / d_p (= vd, fragment order)
-        if (int e = run_xprod(ctx, permute_x ? perm : nullptr, permute_x ? nullptr : perm, 1, st)) return e;
-        HIPCHK(hipMemcpyAsync(ctx->Rfull.p, ctx->R.p, (size_t)ctx->strideR * 8, hipMemcpyDeviceToDevice, st));
-        if (int e = run_gram(ctx, 1, false, st)) return e;
+    for (int p0 = 0; p0 < np; p0 += pcmax) {
+        const int pc = std::min(pcmax, np - p0);
+        const int* pblock = d_perm_idx ? d_perm_idx + (size_t)p0 * S : nullptr;
+        // full-sample arrangements: R_p, then V_p, d_p and M = V_p / d_p (= vd, fragment order)
+        if (int e = run_xprod(ctx, permute_x ? pblock : nullptr, permute_x ? nullptr : pblock, pc, st)) return e;
+        HIPCHK(hipMemcpyAsync(ctx->Rfull.p, ctx->R.p, (size_t)pc * ctx->strideR * 8, hipMemcpyDeviceToDevice, st));
+        if (int e = run_gram(ctx, pc, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_DECOMP);
         a.out_V = ptr<double>(ctx->Vp); a.out_d = ptr<double>(ctx->dp); a.Mfrag = ptr<double>(ctx->Mvd);
-        if (int e = run_small(ctx, a, 1, st)) return e;
-        for (int off = 0; off < ns; off += spp) {
-            const int m = std::min(spp, ns - off);               // splits in this pass
-            if (fused) {
-                if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, st)) return e;
-            } else {
-                if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
-                if (int e = ensure(ctx, ctx->srcy, (size_t)2 * m * S * sizeof(int))) return e;
-                hipLaunchKernelGGL(k_split_src, dim3(ceil_div(S, 256), 2 * m), dim3(256), 0, st, perm,
-                                   d_masks + ((size_t)p * ns + off) * S, m, S, permute_x,
-                                   ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
+        if (int e = run_small(ctx, a, pc, st)) return e;
+        for (int pi = 0; pi < pc; ++pi) {
+            const int p = p0 + pi;
+            const int* perm = d_perm_idx ? d_perm_idx + (size_t)p * S : nullptr;
+            const double* Rfull = ptr<double>(ctx->Rfull) + (size_t)pi * ctx->strideR;
+            const double* Vp = ptr<double>(ctx->Vp) + (size_t)pi * Tp * L;
+            const double* dp = ptr<double>(ctx->dp) + (size_t)pi * L;
+            const double* Mvd = ptr<double>(ctx->Mvd) + (size_t)pi * mstride;
+            for (int off = 0; off < ns; off += spp) {
+                const int m = std::min(spp, ns - off);               // splits in this pass
+                if (fused) {
+                    if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, Rfull, st))
+                        return e;
+                } else {
+                    if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
+                    if (int e = ensure(ctx, ctx->srcy, (size_t)2 * m * S * sizeof(int))) return e;
+                    hipLaunchKernelGGL(k_split_src, dim3(ceil_div(S, 256), 2 * m), dim3(256), 0, st, perm,
+                                       d_masks + ((size_t)p * ns + off) * S, m, S, permute_x,
+                                       ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
+                    LAUNCHCHK();
+                    if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy),
+                                          2 * m, st))
+                        return e;
+                }
+                // C_h = D_h . R_p^T  (T' x T')
+                if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
+                if (int e = run_gram_ex(ctx, 2 * m, 2, Rfull, Tp, ptr<double>(ctx->Cm), st)) return e;
+                // feature-axis sums of E_h = D_h^T . vd
+                const int ntile = ceil_div(ctx->B, 16);
+                int nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
+                const int tpc = ceil_div(ntile, nchunk);
+                nchunk = ceil_div(ntile, tpc);
+                const int lpad = ctx->LT * 16;
+                if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
+                dim3 grid(nchunk, m), block(256);
+                if (int e = launch_ucorr(ctx, grid, block, st, Mvd, tpc, ptr<double>(ctx->part2), m)) return e;
                 LAUNCHCHK();
-                if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy), 2 * m,
-                                      st))
-                    return e;
+                hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m,
+                                   lpad, ptr<double>(ctx->Cm), Vp, dp, Tp, L, ctx->B,
+                                   d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
+                LAUNCHCHK();
             }
-            // C_h = D_h . R_p^T  (T' x T')
-            if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
-            if (int e = run_gram_ex(ctx, 2 * m, 2, ptr<double>(ctx->Rfull), Tp, ptr<double>(ctx->Cm), st)) return e;
-            // feature-axis sums of E_h = D_h^T . vd
-            const int ntile = ceil_div(ctx->B, 16);
-            int nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
-            const int tpc = ceil_div(ntile, nchunk);
-            nchunk = ceil_div(ntile, tpc);
-            const int lpad = ctx->LT * 16;
-            if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
-            dim3 grid(nchunk, m), block(256);
-            if (int e = launch_ucorr(ctx, grid, block, st, ptr<double>(ctx->Mvd), tpc, ptr<double>(ctx->part2), m))
-                return e;
-            LAUNCHCHK();
-            hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m, lpad,
-                               ptr<double>(ctx->Cm), ptr<double>(ctx->Vp), ptr<double>(ctx->dp), Tp, L, ctx->B,
-                               d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
-            LAUNCHCHK();
         }
     }
     return PLSX_OK;

@@ -1321,7 +1321,8 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
                 dim3 grid(nchunk, m), block(256);
                 if (int e = launch_ucorr(ctx, grid, block, st, Mvd, tpc, ptr<double>(ctx->part2), m)) return e;
                 LAUNCHCHK();
-                hipLaunchKernelGGL(k_split_final, dim3(m), dim3(64), 0, st, ptr<double>(ctx->part2), nchunk, m,
+                hipLaunchKernelGGL(k_split_final, dim3(m), dim3(256), (size_t)4 * round_up(L, 64) * 5 * 8, st,
+                                   ptr<double>(ctx->part2), nchunk, m,
                                    lpad, ptr<double>(ctx->Cm), Vp, dp, Tp, L, ctx->B,
                                    d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
                 LAUNCHCHK();

@@ -275,51 +275,77 @@ struct SplitEpi {
     int J, Tpp;
 };
 
-// grid (n_splits, J), block 256, dynamic LDS 0.
-__global__ void k_build_A_split(const double* __restrict__ Y, int T, int S,
-                                const int* __restrict__ cell_start, const int* __restrict__ cell_len,
-                                const int* __restrict__ perm, const uint8_t* __restrict__ masks,
-                                GroupLayout lay, double* __restrict__ Afrag, size_t group_stride,
-                                double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc)
+// grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
+__global__ __launch_bounds__(256)
+void k_build_A_split(const double* __restrict__ Y, int T, int S,
+                     const int* __restrict__ cell_start, const int* __restrict__ cell_len,
+                     const int* __restrict__ perm, const uint8_t* __restrict__ masks,
+                     GroupLayout lay, double* __restrict__ Afrag, size_t group_stride,
+                     double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc)
 {
     const int i = blockIdx.x, j = blockIdx.y;
     const int g = i / lay.n, rr = i % lay.n;
     const int start = cell_start[j], len = cell_len[j];
     const uint8_t* mk = masks + (size_t)i * S;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tl = tid & 63, q = tid >> 6;
     double* A = Afrag + (size_t)g * group_stride;
     __shared__ int s_n1;
+    __shared__ double s_part[4][64][4];          // per quarter: sum y, sum y^2, sum_h1 y, sum_h1 y^2
+    __shared__ double s_mean[64];
     if (tid == 0) {
         int c = 0;
         for (int p = start; p < start + len; ++p) c += mk[p] != 0;
         s_n1 = c;
     }
-    __syncthreads();
-    const int n1 = s_n1, n2 = len - n1;
-    for (int t = tid; t < T; t += blockDim.x) {
-        double s = 0.0;
-        for (int p = start; p < start + len; ++p) s += Y[(size_t)(perm ? perm[p] : p) * T + t];
-        const double mF = s / (double)len;
-        double syyF = 0.0, sy1 = 0.0, syy1 = 0.0, syF = 0.0;
-        for (int p = start; p < start + len; ++p) {
-            const double d = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
-            syF += d; syyF += d * d;
-            if (mk[p]) { sy1 += d; syy1 += d * d; }
+    const int p0 = start + (int)((long long)len * q / 4), p1 = start + (int)((long long)len * (q + 1) / 4);
+    for (int tb = 0; tb < T; tb += 64) {
+        const int t = tb + tl;
+        __syncthreads();
+        if (t < T) {
+            // raw moments relative to the first row's value (shift keeps them well conditioned)
+            const double y0 = Y[(size_t)(perm ? perm[start] : start) * T + t];
+            double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            for (int p = p0; p < p1; ++p) {
+                const double d = Y[(size_t)(perm ? perm[p] : p) * T + t] - y0;
+                a0 += d; a1 += d * d;
+                if (mk[p]) { b0 += d; b1 += d * d; }
+            }
+            s_part[q][tl][0] = a0; s_part[q][tl][1] = a1; s_part[q][tl][2] = b0; s_part[q][tl][3] = b1;
         }
-        const double sy2 = syF - sy1, syy2 = syyF - syy1;
-        const double v1 = (n1 > 1) ? (syy1 - sy1 * sy1 / n1) / (n1 - 1.0) : 0.0;
-        const double v2 = (n2 > 1) ? (syy2 - sy2 * sy2 / n2) / (n2 - 1.0) : 0.0;
-        const double vF = (syyF - syF * syF / len) / (len - 1.0);
-        const int row = rr * lay.Tp + j * T + t;
-        double* rc = rowc + ((size_t)g * lay.MT * 16 + row) * 5;
-        rc[0] = sy1;
-        rc[1] = (v1 > 0.0) ? 1.0 / ((n1 - 1.0) * sqrt(v1)) : 0.0;
-        rc[2] = sy2;
-        rc[3] = (v2 > 0.0) ? 1.0 / ((n2 - 1.0) * sqrt(v2)) : 0.0;
-        rc[4] = (vF > 0.0) ? (len - 1.0) * sqrt(vF) : 0.0;
-        // data row: d on the first half's rows
-        for (int p = start; p < start + len; ++p)
-            if (mk[p]) A[afrag_off(row, p, lay.MT)] = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
+        __syncthreads();
+        if (t < T && q == 0) {
+            const int n1 = s_n1, n2 = len - n1;
+            double syF = 0, syyF = 0, sy1 = 0, syy1 = 0;
+            for (int qq = 0; qq < 4; ++qq) {
+                syF += s_part[qq][tl][0]; syyF += s_part[qq][tl][1];
+                sy1 += s_part[qq][tl][2]; syy1 += s_part[qq][tl][3];
+            }
+            const double y0 = Y[(size_t)(perm ? perm[start] : start) * T + t];
+            const double mS = syF / (double)len;               // cell mean relative to y0
+            s_mean[tl] = y0 + mS;
+            // moments of d = y - mean_cell from the shifted ones
+            const double cyyF = syyF - syF * syF / len;
+            const double c1 = sy1 - n1 * mS;                    // sum over half 1 of d
+            const double cyy1 = syy1 - 2.0 * mS * sy1 + n1 * mS * mS;
+            const double c2 = -c1, cyy2 = cyyF - cyy1;          // sum of d over the cell is 0
+            const double v1 = (n1 > 1) ? (cyy1 - c1 * c1 / n1) / (n1 - 1.0) : 0.0;
+            const double v2 = (n2 > 1) ? (cyy2 - c2 * c2 / n2) / (n2 - 1.0) : 0.0;
+            const double vF = cyyF / (len - 1.0);
+            const int row = rr * lay.Tp + j * T + t;
+            double* rc = rowc + ((size_t)g * lay.MT * 16 + row) * 5;
+            rc[0] = c1;
+            rc[1] = (v1 > 0.0) ? 1.0 / ((n1 - 1.0) * sqrt(v1)) : 0.0;
+            rc[2] = c2;
+            rc[3] = (v2 > 0.0) ? 1.0 / ((n2 - 1.0) * sqrt(v2)) : 0.0;
+            rc[4] = (vF > 0.0) ? (len - 1.0) * sqrt(vF) : 0.0;
+        }
+        __syncthreads();
+        if (t < T) {
+            const double mF = s_mean[tl];
+            const int row = rr * lay.Tp + j * T + t;
+            for (int p = p0; p < p1; ++p)
+                if (mk[p]) A[afrag_off(row, p, lay.MT)] = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
+        }
     }
     const int mrow = rr * lay.J + j;
     for (int pl = tid; pl < len; pl += blockDim.x) {
@@ -328,7 +354,7 @@ __global__ void k_build_A_split(const double* __restrict__ Y, int T, int S,
         A[afrag_off(lay.w0 * 16 + mrow, p, lay.MT)] = 1.0;
         A[afrag_off(lay.sq0 * 16 + mrow, p, lay.MT)] = 1.0;
     }
-    if (tid == 0) mom_n[(size_t)g * nmom_pad + mrow] = (double)n1;
+    if (tid == 0) mom_n[(size_t)g * nmom_pad + mrow] = (double)s_n1;
 }
 
 // ---------------------------------------------------------------------------
@@ -1731,27 +1757,25 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
 // Final split-half correlations of one split (block = pair):
 //   ucorr[l] from the feature-axis sums; vcorr[l] = Pearson over the T' rows of
 //   F_h = C_h . (V d^-2) with C_h = D_h . R_full^T  (= D_h @ ud, base.py:767).
-__global__ void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int lpad,
-                              const double* __restrict__ C /* [2*npairs][n][n] */,
-                              const double* __restrict__ V /* n x L */, const double* __restrict__ d,
-                              int n, int L, int B, double* __restrict__ ucorr, double* __restrict__ vcorr)
+__global__ __launch_bounds__(256)
+void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int lpad,
+                   const double* __restrict__ C /* [2*npairs][n][n] */,
+                   const double* __restrict__ V /* n x L */, const double* __restrict__ d,
+                   int n, int L, int B, double* __restrict__ ucorr, double* __restrict__ vcorr)
 {
+    // thread = (LV l, quarter q of the T' rows): partial sums of the five moments of
+    // F_h[:, l] in LDS, added in a fixed order (deterministic)
+    extern __shared__ double sm_sf[];            // [4][lpad64][5]
     const int pair = blockIdx.x;
-    for (int l = threadIdx.x; l < L; l += blockDim.x) {
-        double s[5] = {0, 0, 0, 0, 0};
-        for (int c = 0; c < nchunk; ++c)
-            for (int k = 0; k < 5; ++k) s[k] += part[(((size_t)c * npairs + pair) * 5 + k) * lpad + l];
-        const double nb = (double)B;
-        const double cov = s[4] - s[0] * s[1] / nb;
-        const double v1 = s[2] - s[0] * s[0] / nb, v2 = s[3] - s[1] * s[1] / nb;
-        double rr = cov / sqrt(v1 * v2);
-        ucorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);   // NaN stays NaN
-        // vcorr
-        const double* C1 = C + (size_t)(2 * pair) * n * n;
-        const double* C2 = C1 + (size_t)n * n;
+    const int lq = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int lp64 = (L + 63) / 64 * 64;
+    const double* C1 = C + (size_t)(2 * pair) * n * n;
+    const double* C2 = C1 + (size_t)n * n;
+    const int t0 = (int)((long long)n * q / 4), t1 = (int)((long long)n * (q + 1) / 4);
+    for (int l = lq; l < L; l += 64) {
         const double inv = 1.0 / (d[l] * d[l]);
         double f1s = 0, f2s = 0, f11 = 0, f22 = 0, f12 = 0;
-        for (int t = 0; t < n; ++t) {
+        for (int t = t0; t < t1; ++t) {
             double f1 = 0, f2 = 0;
             for (int u = 0; u < n; ++u) {
                 const double vv = V[(size_t)u * L + l];
@@ -1761,9 +1785,25 @@ __global__ void k_split_final(const double* __restrict__ part, int nchunk, int n
             f1 *= inv; f2 *= inv;
             f1s += f1; f2s += f2; f11 += f1 * f1; f22 += f2 * f2; f12 += f1 * f2;
         }
+        double* o = sm_sf + ((size_t)q * lp64 + l) * 5;
+        o[0] = f1s; o[1] = f2s; o[2] = f11; o[3] = f22; o[4] = f12;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < nchunk; ++c)
+            for (int k = 0; k < 5; ++k) s[k] += part[(((size_t)c * npairs + pair) * 5 + k) * lpad + l];
+        const double nb = (double)B;
+        const double cov = s[4] - s[0] * s[1] / nb;
+        const double v1 = s[2] - s[0] * s[0] / nb, v2 = s[3] - s[1] * s[1] / nb;
+        double rr = cov / sqrt(v1 * v2);
+        ucorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);   // NaN stays NaN
+        double f[5] = {0, 0, 0, 0, 0};
+        for (int qq = 0; qq < 4; ++qq)
+            for (int k = 0; k < 5; ++k) f[k] += sm_sf[((size_t)qq * lp64 + l) * 5 + k];
         const double nn = (double)n;
-        const double cv = f12 - f1s * f2s / nn;
-        const double w1 = f11 - f1s * f1s / nn, w2 = f22 - f2s * f2s / nn;
+        const double cv = f[4] - f[0] * f[1] / nn;
+        const double w1 = f[2] - f[0] * f[0] / nn, w2 = f[3] - f[1] * f[1] / nn;
         rr = cv / sqrt(w1 * w2);
         vcorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);
     }

@@ -98,6 +98,25 @@ def _torch():
     return torch
 
 
+def check_index_array(samples, S):
+    """Row indices as the reference's fancy indexing ``X[inds]`` accepts them
+    (pyls/base.py:569,599): integer dtype, negatives wrap like numpy's, anything
+    outside [-S, S) raises IndexError.  The kernels index device memory with
+    these values unchecked, so they are validated here."""
+    samples = np.asarray(samples)
+    if samples.dtype == bool or not np.issubdtype(samples.dtype, np.integer):
+        raise IndexError('resampling arrays must hold integer row indices, got dtype {}'
+                         .format(samples.dtype))
+    if samples.size:
+        lo, hi = int(samples.min()), int(samples.max())
+        if lo < -S or hi >= S:
+            raise IndexError('index {} is out of bounds for axis 0 with size {}'
+                             .format(lo if lo < -S else hi, S))
+        if lo < 0:
+            samples = np.where(samples < 0, samples + S, samples)
+    return samples
+
+
 class Engine(object):
     """One device context.  All ndarray arguments / results are host numpy
     arrays unless a method says it returns a device tensor."""
@@ -195,7 +214,7 @@ class Engine(object):
         if samples.ndim != 2 or samples.shape[0] != self.S:
             raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'
                              .format(self.S, samples.shape))
-        return self._dev(samples.T, np.int32)
+        return self._dev(check_index_array(samples, self.S).T, np.int32)
 
     # -- kernels ----------------------------------------------------------
     def crosscov(self, xsrc=None, ysrc=None, n=None):

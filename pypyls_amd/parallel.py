@@ -32,6 +32,28 @@ def rank_world():
     return d.get_rank(), d.get_world_size()
 
 
+def shared_seed(seed):
+    """Seed every rank must use so that all ranks draw IDENTICAL index arrays.
+
+    The reference draws permutation / bootstrap / split arrays from one
+    RandomState (pyls/base.py:37,109,188); sharding them over ranks only works
+    when every rank generates the same full arrays.  An integer seed is already
+    shared.  ``None`` (numpy's global state) or a RandomState instance differs
+    per process, so rank 0 draws one integer from it and broadcasts it."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return seed
+    import numbers
+    if isinstance(seed, numbers.Integral):
+        return seed
+    box = [None]
+    if d.get_rank() == 0:
+        rs = np.random.mtrand._rand if (seed is None or seed is np.random) else seed
+        box[0] = int(rs.randint(0, 2 ** 31 - 1))
+    d.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def shard_bounds(n, rank, world):
     """Contiguous slice [lo, hi) of n resamples owned by ``rank``; sizes
     differ by at most one, earlier ranks take the remainder."""

@@ -63,7 +63,8 @@ class _PLSCRun(object):
                              .format(len(X), len(Y)))
         kwargs.setdefault('permindices', True)
         self.inputs = PLSInputs(X=X, Y=Y, groups=groups, n_cond=n_cond, **kwargs)
-        self.rs = resampling.check_random_state(self.inputs.get('seed'))
+        # under torch.distributed every rank must draw the same index arrays
+        self.rs = resampling.check_random_state(parallel.shared_seed(self.inputs.get('seed')))
         self.cells = resampling.cell_of_row(groups, n_cond)
         self.n_cells = len(groups) * n_cond
         self.engine = kwargs.get('_engine')

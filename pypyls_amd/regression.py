@@ -79,6 +79,8 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     S = len(X)
     agg = None
     third = None                                   # (C, n_boot) third-axis resamples for 3-D Y
+    bootsamples_out = None
+    seed = parallel.shared_seed(seed)              # all ranks draw the same index arrays
     if Y.ndim == 3:
         # regression.py:208-235
         if not callable(aggfunc) and aggfunc not in _AGGFUNCS:

@@ -143,3 +143,64 @@ def test_collect_multiprocess_gloo(tmp_path, world):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok') == world
+
+
+def test_check_index_array():
+    """User-supplied resampling arrays are validated like numpy fancy indexing
+    (pyls/base.py:569,599): integer dtype, negatives wrap, out of range raises."""
+    from pypyls_amd.engine import check_index_array
+    a = np.array([[0, 4], [-1, 2], [3, -5]])
+    np.testing.assert_array_equal(check_index_array(a, 5), [[0, 4], [4, 2], [3, 0]])
+    for bad in (np.array([[0, 5]]), np.array([[-6, 1]]), np.array([[2 ** 40, 0]])):
+        with pytest.raises(IndexError):
+            check_index_array(bad, 5)
+    with pytest.raises(IndexError):
+        check_index_array(np.array([[0.0, 1.0]]), 5)
+    with pytest.raises(IndexError):
+        check_index_array(np.array([[True, False]]), 5)
+    assert check_index_array(np.zeros((5, 0), int), 5).shape == (5, 0)
+
+
+def test_regression_3d_y_without_bootstraps_reaches_the_engine():
+    """3-D Y with n_boot=0 died on an unbound local before any work."""
+    import torch
+    import pypyls_amd as pls
+    from pypyls_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: covered by the gpu tests')
+    rs = np.random.RandomState(0)
+    with pytest.raises(engine.PlsxError):
+        pls.pls_regression(rs.rand(12, 6), rs.rand(12, 3, 4), n_components=2, n_perm=0, n_boot=0)
+
+
+_SEED_WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+from pypyls_amd import parallel, resampling
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank = dist.get_rank()
+np.random.seed(1000 + rank)                      # ranks start from DIFFERENT global states
+assert parallel.shared_seed(77) == 77
+for seed in (None, np.random.RandomState(5 + rank)):
+    s = parallel.shared_seed(seed)
+    perms = resampling.gen_permsamp([6, 7], 2, 9, seed=s, verbose=False)
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, (s, perms.tobytes()))
+    assert all(b == box[0] for b in box), 'ranks drew different index arrays'
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_shared_seed_multiprocess_gloo(tmp_path):
+    """ADVICE r1: with seed=None every rank must still draw the same arrays."""
+    script = tmp_path / 'seed_worker.py'
+    script.write_text(_SEED_WORKER.format(root=ROOT))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)]
+    out = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'), capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == 2

@@ -1,28 +1,47 @@
 #!/usr/bin/env python3
 """
-bench.py -- resamples/sec (perm + boot) of the PLS-C resampling hot path.
+bench.py -- throughput of the PLS resampling hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4] [--mode weak]
 
-Workload (BASELINE.json metric): behavioral PLS,
-X (500 x 200000), Y (500 x 50), fp64, synthetic
-(RandomState(0): X = randn, Y = randn + 0.3 * X[:, :T]).  One "step" = one
-pass of the hot path over one batch of resamples per GPU: PERMS permutations
-+ BOOTS bootstraps (index arrays already in HBM), i.e. for every resample
-gather/permute -> per-cell z-score -> R = Yn^T Xn -> Gram-side Jacobi SVD ->
-Procrustes -> null value / running sum U, sum U^2 + distrib.  Weak scaling:
-every rank processes its own PERMS + BOOTS per step with a full replica of X;
-no collective inside the data path (the one all-gather of results happens
-once per analysis, outside the steady-state step).
+``--gpus N`` with N > 1 launches N ranks itself (one process per GPU,
+``torch.distributed.run`` on 127.0.0.1) unless it is already running under a
+launcher (WORLD_SIZE set); it fails loudly when fewer GPUs are visible.  The
+reported ``n_gpus`` is the world size of the RCCL process group.
+
+Default workload = BASELINE.json's metric: behavioral PLS, X (500 x 200000),
+Y (500 x 50), fp64, synthetic (RandomState(0): X = randn, Y = randn +
+0.3 X[:, :T]).  One "step" (weak mode) = one analysis-sized pass of the hot
+path per GPU: PERMS permutations + BOOTS bootstraps with index arrays already
+in HBM -- gather/permute -> per-cell z-score -> R = Yn^T Xn -> Gram-side Jacobi
+SVD -> Procrustes -> null value / running sum U, sum U^2 + distrib -- followed
+by THE one collective of the analysis (all-gather of [perm slice | distrib
+slice | sum U | sum U^2], pypyls_amd/parallel.py) on RCCL.  Weak scaling:
+every rank runs its own PERMS + BOOTS per step on a full replica of X.
+
+``value`` uses the product's default permutation route, which for PLS-C is the
+S x S dual-space shortcut (no pass over X per permutation; SURVEY.md section
+8d asks for it to be reported separately).  ``value_primal`` is the same step
+with the permutations forced through the feature pass R_p = A_p X -- the
+north-star pipeline -- measured in a second timed region of the same run.
+
+``--mode strong``: one step = ONE analysis of --n-perm + --n-boot resamples
+(default 10000 + 10000) split over the ranks with parallel.shard_bounds; the
+seed-compatible host index generation, the H2D copies of the index shards and
+the one all-gather are inside the clock.
+
+``--config`` selects another BASELINE config (bench lines for the record; the
+driver runs the default): c2, c3, c5, c4split.
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,29 +53,409 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor; = FP32 matri
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md
 
 
-def synth(S, B, T):
-    rs = np.random.RandomState(0)
+def synth(S, B, T, seed=0):
+    rs = np.random.RandomState(seed)
     X = rs.randn(S, B)
     Y = rs.randn(S, T) + 0.3 * X[:, :T]
     return X, Y
 
 
-def cpu_baseline(X, Y, x_weights, y_weights, n_each, seed=1234):
-    """Oracle (numpy restatement of the reference path) timed on the host
-    cores: n_each permutations + n_each bootstraps of the same workload."""
-    from oracle import cpu_ref as ref
-    from pypyls_amd import resampling
-    S = X.shape[0]
-    spec = ref.Spec('behavioral', [S], 1)
-    perms = resampling.gen_permsamp([S], 1, n_each, seed=seed, verbose=False)
-    boots = resampling.gen_bootsamp([S], 1, n_each, seed=seed + 1, verbose=False)
-    t0 = time.perf_counter()
-    for i in range(n_each):
-        ref.single_perm(spec, X, Y, perms[:, i], y_weights)
-    for i in range(n_each):
-        ref.single_boot(spec, X, Y, boots[:, i], x_weights)
-    dt = time.perf_counter() - t0
-    return 2 * n_each / dt, dt
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: spawn the N ranks."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write('bench.py: --gpus {} requested but only {} GPU(s) are visible\n'
+                         .format(args.gpus, have))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+           str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------
+
+class PLSC(object):
+    """behavioral / mean-centred PLS: permutations + bootstraps."""
+
+    def __init__(self, args, name, method, S, B, T, groups, n_cond, perms, boots, cpu_each):
+        self.args, self.name, self.method = args, name, method
+        self.S, self.B, self.T, self.groups, self.n_cond = S, B, T, groups, n_cond
+        self.perms, self.boots, self.cpu_each = perms, boots, cpu_each
+        self.unit = 'resamples/s'
+
+    def describe(self, world):
+        if self.method == 'behavioral':
+            return 'behavioral_pls X({}x{}) Y({}x{}) fp64, n_split=0, test_split=0'.format(
+                self.S, self.B, self.S, self.T)
+        return 'meancentered_pls X({}x{}) groups={} n_cond={} mean_centering=0 fp64'.format(
+            self.S, self.B, self.groups, self.n_cond)
+
+    def setup(self, rank, n_steps, dev):
+        import torch
+        from pypyls_amd import resampling, hostmath
+        from pypyls_amd.engine import Engine
+        S, B, T = self.S, self.B, self.T
+        rs = np.random.RandomState(0)
+        if self.method == 'behavioral':
+            self.X, self.Y = synth(S, B, T)
+        else:
+            self.X = rs.randn(S, B)
+            self.X += 0.25 * rs.randn(len(self.groups) * self.n_cond, B)[
+                resampling.cell_of_row(self.groups, self.n_cond)]
+            self.Y = None
+        # long-lived engine: fixed super-batch scratch, mapped during warm-up
+        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng.set_data(self.X, self.Y, resampling.cell_of_row(self.groups, self.n_cond), len(self.groups),
+                     self.n_cond, 0 if self.method == 'behavioral' else 1)
+        xw, sv, yw = eng.decompose()
+        self.xw, self.yw = hostmath.sign_convention(xw, yw)
+        self.sv = sv
+        eng.set_original(self.xw, sv, self.yw)
+        L, Tp = eng.L, eng.Tp
+        self.Tp, self.L = Tp, L
+        self.dev = dev
+        if self.args.mode == 'weak':
+            # distinct index arrays per rank and per step, resident in HBM before timing
+            self.perm_idx, self.boot_idx = [], []
+            for s in range(n_steps):
+                seed = 1234 + 1000 * rank + s
+                self.perm_idx.append(eng.index_tensor(
+                    resampling.gen_permsamp(self.groups, self.n_cond, self.perms, seed=seed, verbose=False)))
+                self.boot_idx.append(eng.index_tensor(
+                    resampling.gen_bootsamp(self.groups, self.n_cond, self.boots, seed=seed + 500,
+                                            verbose=False)))
+            pmax, rmax = self.perms, self.boots
+        else:
+            from pypyls_amd import parallel
+            _, world = parallel.rank_world()
+            pmax = parallel.shard_bounds(self.perms, 0, world)[1]
+            rmax = parallel.shard_bounds(self.boots, 0, world)[1]
+        self.pmax, self.rmax = pmax, rmax
+        self.out_sv = torch.zeros((pmax, L), dtype=torch.float64, device=dev)
+        self.dist_out = torch.zeros((rmax, Tp, L), dtype=torch.float64, device=dev)
+        self.usum = torch.zeros((B, L), dtype=torch.float64, device=dev)
+        self.usq = torch.zeros((B, L), dtype=torch.float64, device=dev)
+        self.legs = []
+
+    def units_per_step(self, world):
+        return (self.perms + self.boots) * (world if self.args.mode == 'weak' else 1)
+
+    def step(self, i, timed=False):
+        import torch
+        from pypyls_amd import parallel
+        eng = self.eng
+        ev = None
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        self.usum.zero_()
+        self.usq.zero_()
+        if self.args.mode == 'weak':
+            eng.perm_into(self.perm_idx[i], self.out_sv, rotate=True)
+            if ev:
+                ev[1].record()
+            eng.boot_into(self.boot_idx[i], self.usum, self.usq, self.dist_out)
+        else:
+            self._strong_step(i)
+            if ev:
+                ev[1].record()
+        if ev:
+            ev[2].record()
+        # the ONE collective of the analysis
+        self.result = parallel.gather_device([(self.out_sv, self.pmax), (self.dist_out, self.rmax)],
+                                             [self.usum, self.usq])
+        if ev:
+            ev[3].record()
+            self.legs.append(ev)
+
+    def _strong_step(self, i):
+        """One whole analysis: seed-compatible index generation on the host (every
+        rank draws the same arrays from the same seed), this rank's shard to the
+        device, permutations, bootstraps.  The bootstrap arrays are generated in a
+        worker thread while the device runs the permutations."""
+        from pypyls_amd import parallel, resampling
+        eng = self.eng
+        rank, world = parallel.rank_world()
+        seed = 4321 + i
+        box = {}
+
+        def gen_boots():
+            box['b'] = resampling.gen_bootsamp(self.groups, self.n_cond, self.boots, seed=seed + 500,
+                                               verbose=False)
+        th = threading.Thread(target=gen_boots)
+        perms = resampling.gen_permsamp(self.groups, self.n_cond, self.perms, seed=seed, verbose=False)
+        th.start()
+        lo, hi = parallel.shard_bounds(self.perms, rank, world)
+        if hi > lo:
+            eng.perm_into(eng.index_tensor(perms[:, lo:hi]), self.out_sv[:hi - lo], rotate=True)
+        th.join()
+        lo, hi = parallel.shard_bounds(self.boots, rank, world)
+        if hi > lo:
+            eng.boot_into(eng.index_tensor(box['b'][:, lo:hi]), self.usum, self.usq, self.dist_out[:hi - lo])
+
+    def roofline(self, kt, steps, world):
+        """Dominant kernel k_xprod.  Algorithmic work per resample of THIS kernel:
+        2 S T' B flop (first term of SURVEY 8d W_F) and 8 S (B + T') bytes (W_B)."""
+        S, B, Tp = self.S, self.B, self.Tp
+        tm = self.eng.last_timing()
+        launches = max(int(tm.get('xprod_launches', 0)), 1)
+        avg_ms = tm.get('xprod_ms', 0.0) / launches
+        units = tm.get('xprod_resamples', 0) / launches
+        fl = 2.0 * S * Tp * B * units
+        by = 8.0 * S * (B + Tp) * units
+        tf = fl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        tb = by / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        f_m, f_h = tf / PEAK_FP64_MFMA_TFLOPS, tb / PEAK_HBM_TBS
+        mf = f_m >= f_h
+        return {'bound': 'mfma' if mf else 'hbm', 'kernel': 'k_xprod<{}>'.format(int(tm.get('m_tiles', 0))),
+                'achieved': tf if mf else tb * 1e3, 'peak': PEAK_FP64_MFMA_TFLOPS if mf else PEAK_HBM_TBS * 1e3,
+                'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': max(f_m, f_h),
+                'frac_mfma': f_m, 'frac_hbm_algorithmic': f_h,
+                'avg_launch_ms': avg_ms, 'launches': launches, 'resamples_per_launch': units}
+
+    def pipeline(self, ms_per_step, primal):
+        """Whole-step fractions with the algorithmic work of the formulation."""
+        S, B, Tp, L = self.S, self.B, self.Tp, self.L
+        wf_boot = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
+        wb = 8.0 * S * (B + Tp)
+        if primal:
+            wf_perm, wb_perm = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B, wb
+        else:
+            wf_perm = 2.0 * Tp * S * S + 2.0 * Tp * Tp * S + 2.0 * S * S * B / max(self.perms, 1)
+            wb_perm = 8.0 * (S * B / max(self.perms, 1) + 3.0 * Tp * S)
+        per_s = 1e3 / ms_per_step
+        return (per_s * (self.perms * wf_perm + self.boots * wf_boot) / (PEAK_FP64_MFMA_TFLOPS * 1e12),
+                per_s * (self.perms * wb_perm + self.boots * wb) / (PEAK_HBM_TBS * 1e12))
+
+    def cpu_baseline(self):
+        from oracle import cpu_ref as ref
+        from pypyls_amd import resampling
+        n = self.cpu_each
+        spec = ref.Spec(self.method, self.groups, self.n_cond)
+        Y = self.Y if self.Y is not None else spec.dummy.astype(float)
+        perms = resampling.gen_permsamp(self.groups, self.n_cond, n, seed=1234, verbose=False)
+        boots = resampling.gen_bootsamp(self.groups, self.n_cond, n, seed=1235, verbose=False)
+        t0 = time.perf_counter()
+        for i in range(n):
+            ref.single_perm(spec, self.X, Y, perms[:, i], self.yw)
+        for i in range(n):
+            ref.single_boot(spec, self.X, Y, boots[:, i], self.xw, np.diag(self.sv))
+        dt = time.perf_counter() - t0
+        return 2 * n / dt, '{} permutations + {} bootstraps of the same workload through oracle/cpu_ref.py ' \
+                           '(numpy, BLAS threads = host cores), {:.1f} s'.format(n, n, dt)
+
+
+class Simpls(object):
+    """c5: pls_regression (SIMPLS) X (1000 x 100000), Y (1000 x 20), k = 15."""
+
+    def __init__(self, args):
+        self.args, self.name = args, 'c5'
+        self.S, self.B, self.T, self.k = 1000, 100000, 20, 15
+        self.perms, self.boots = args.perms or 1000, args.boots or 1000
+        self.unit = 'resamples/s'
+
+    def describe(self, world):
+        return 'pls_regression (SIMPLS) X({}x{}) Y({}x{}) n_components={} fp64 (T = 20 > 11: pinned on the ' \
+               'oracle\'s exact SIMPLS, reference parity unpinned)'.format(self.S, self.B, self.S, self.T, self.k)
+
+    def setup(self, rank, n_steps, dev):
+        import torch
+        from pypyls_amd import resampling
+        from pypyls_amd.engine import Engine
+        S, B, T, k = self.S, self.B, self.T, self.k
+        X, Y = synth(S, B, T)
+        self.Xc = X - X.mean(axis=0, keepdims=True)
+        self.Yc = Y - Y.mean(axis=0, keepdims=True)
+        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng.set_data_regression(self.Xc, self.Yc, k)
+        W, pct, cvec, _ = eng.simpls_decompose()
+        idx = np.argmax(np.abs(W), axis=0)
+        sg = np.sign(W[idx, np.arange(k)])
+        self.W = W * sg
+        eng.simpls_set_original(self.W)
+        self.perm_idx, self.boot_idx = [], []
+        for s in range(n_steps):
+            seed = 1234 + 1000 * rank + s
+            self.perm_idx.append(eng.index_tensor(resampling.gen_permsamp([S], 1, self.perms, seed=seed,
+                                                                          verbose=False)))
+            self.boot_idx.append(eng.index_tensor(resampling.gen_bootsamp([S], 1, self.boots, seed=seed + 500,
+                                                                          verbose=False)))
+        self.out = torch.zeros((self.perms, k), dtype=torch.float64, device=dev)
+        self.yl = torch.zeros((self.boots, T, k), dtype=torch.float64, device=dev)
+        self.usum = torch.zeros((B, k), dtype=torch.float64, device=dev)
+        self.usq = torch.zeros((B, k), dtype=torch.float64, device=dev)
+        self.legs = []
+
+    def units_per_step(self, world):
+        return (self.perms + self.boots) * world
+
+    def step(self, i, timed=False):
+        import torch
+        from pypyls_amd import parallel
+        ev = None
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        self.usum.zero_()
+        self.usq.zero_()
+        self.eng.simpls_perm_into(self.perm_idx[i], self.out)
+        if ev:
+            ev[1].record()
+        self.eng.simpls_boot_into(self.boot_idx[i], self.usum, self.usq, self.yl)
+        if ev:
+            ev[2].record()
+        self.result = parallel.gather_device([(self.out, self.perms), (self.yl, self.boots)],
+                                             [self.usum, self.usq])
+        if ev:
+            ev[3].record()
+            self.legs.append(ev)
+
+    def roofline(self, kt, steps, world):
+        """Dominant kernel: the dual-space solver.  Algorithmic work per resample
+        in THIS (dual) formulation: every product with K_r = Jc K[xs, xs] Jc is
+        2 S^2 flop; there are T for Z = K_r Yd plus 2 per component
+        (regression.py:56-186 restated in S dimensions), i.e. (T + 2k) 2 S^2 flop;
+        bytes: K (8 S^2) read once per resample at best.  SURVEY 8d's primal model
+        (31 passes over X, 24.8 GB per resample) is reported beside it."""
+        S, T, k, B = self.S, self.T, self.k, self.B
+        ms, n = kt.get('k_simpls_dual', (0.0, 0))
+        units = steps * (self.perms + self.boots)
+        fl = (T + 2.0 * k) * 2.0 * S * S * units
+        by = 8.0 * S * S * units
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tb = by / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        f_m, f_h = tf / PEAK_FP64_MFMA_TFLOPS, tb / PEAK_HBM_TBS
+        mf = f_m >= f_h
+        primal_bytes = (1 + 2 * k) * 8.0 * S * B
+        return {'bound': 'mfma' if mf else 'hbm', 'kernel': 'k_simpls_dual',
+                'achieved': tf if mf else tb * 1e3, 'peak': PEAK_FP64_MFMA_TFLOPS if mf else PEAK_HBM_TBS * 1e3,
+                'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': max(f_m, f_h), 'frac_mfma': f_m,
+                'frac_hbm_algorithmic': f_h, 'avg_launch_ms': ms / max(n, 1), 'launches': n,
+                'primal_model_hbm_resamples_per_s': PEAK_HBM_TBS * 1e12 / primal_bytes}
+
+    def pipeline(self, ms_per_step, primal):
+        return None, None
+
+    def cpu_baseline(self):
+        from oracle import cpu_ref as ref
+        from pypyls_amd import resampling
+        perms = resampling.gen_permsamp([self.S], 1, 2, seed=1234, verbose=False)
+        boots = resampling.gen_bootsamp([self.S], 1, 2, seed=1235, verbose=False)
+        t0 = time.perf_counter()
+        for i in range(2):
+            ref.regression_single_perm(self.Xc, self.Yc, perms[:, i], self.k)
+        for i in range(2):
+            ref.regression_single_boot(self.Xc, self.Yc, boots[:, i], self.k, self.W)
+        dt = time.perf_counter() - t0
+        return 4 / dt, '2 permutations + 2 bootstraps through oracle/cpu_ref.py (primal SIMPLS, numpy), ' \
+                       '{:.1f} s'.format(dt)
+
+
+class SplitHalf(object):
+    """c4 split-half leg: permuted arrangements x n_split = 100 splits."""
+
+    def __init__(self, args):
+        self.args, self.name = args, 'c4split'
+        self.S, self.B, self.T = 500, 200000, 50
+        self.arr, self.ns = args.perms or 8, 100
+        self.unit = 'splits/s'
+
+    def describe(self, world):
+        return 'behavioral_pls X({}x{}) Y({}x{}) fp64 split-half leg: {} permuted arrangements x n_split={} ' \
+               'per step (each arrangement decomposed on the device first)'.format(
+                   self.S, self.B, self.S, self.T, self.arr, self.ns)
+
+    def setup(self, rank, n_steps, dev):
+        import torch
+        from pypyls_amd import resampling
+        from pypyls_amd.engine import Engine
+        S, B, T = self.S, self.B, self.T
+        self.X, self.Y = synth(S, B, T)
+        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng.set_data(self.X, self.Y, resampling.cell_of_row([S], 1), 1, 1, 0)
+        self.L = eng.L
+        self.perm_idx, self.masks = [], []
+        for s in range(n_steps):
+            seed = 77 + 1000 * rank + s
+            self.perm_idx.append(eng.index_tensor(resampling.gen_permsamp([S], 1, self.arr, seed=seed,
+                                                                          verbose=False)))
+            m = np.stack([resampling.gen_splits([S], 1, self.ns, seed=seed * 131 + i) for i in range(self.arr)])
+            self.masks.append(torch.from_numpy(np.ascontiguousarray(m.transpose(0, 2, 1), dtype=np.uint8)).to(dev))
+        self.uc = torch.zeros((self.arr, self.ns, self.L), dtype=torch.float64, device=dev)
+        self.vc = torch.zeros((self.arr, self.ns, self.L), dtype=torch.float64, device=dev)
+        self.legs = []
+
+    def units_per_step(self, world):
+        return self.arr * self.ns * world
+
+    def step(self, i, timed=False):
+        from pypyls_amd import parallel
+        self.eng.split_half_into(self.perm_idx[i], self.masks[i], self.uc, self.vc)
+        self.result = parallel.gather_device([(self.uc, self.arr), (self.vc, self.arr)], [])
+
+    def roofline(self, kt, steps, world):
+        """Whole split against SURVEY 8d's W_F(split) = 2 S T' B + 8 T' L B flop
+        (two half-sample cross-products + four projections), MFMA bound; the
+        dominant kernel (largest summed time) is named with its share."""
+        S, B, Tp, L = self.S, self.B, self.T, self.L
+        tot = sum(v[0] for v in kt.values()) or 1.0
+        dom = max(kt, key=lambda k: kt[k][0]) if kt else 'k_xprod'
+        units = steps * self.arr * self.ns
+        wf = (2.0 * S * Tp * B + 8.0 * Tp * L * B) * units
+        tf = wf / (tot * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': PEAK_FP64_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': tf / PEAK_FP64_MFMA_TFLOPS,
+                'dominant_kernel_share': kt.get(dom, (0, 0))[0] / tot,
+                'note': 'achieved = W_F(split) x splits / summed kernel time of the split-half launches'}
+
+    def pipeline(self, ms_per_step, primal):
+        return None, None
+
+    def cpu_baseline(self):
+        from oracle import cpu_ref as ref
+        from pypyls_amd import resampling
+        spec = ref.Spec('behavioral', [self.S], 1)
+        masks = resampling.gen_splits([self.S], 1, 2, seed=5)
+        U, d, V = ref.decompose(spec, self.X, self.Y)
+        di = np.linalg.inv(d)
+        t0 = time.perf_counter()
+        ref.split_half(spec, self.X, self.Y, U @ di, V @ di, masks)
+        dt = time.perf_counter() - t0
+        return 2 / dt, '2 splits of the original arrangement through oracle/cpu_ref.py split_half (numpy), ' \
+                       '{:.1f} s'.format(dt)
+
+
+def make_workload(args):
+    c = args.config
+    if c == 'c4':
+        return PLSC(args, 'c4', 'behavioral', args.S, args.B, args.T, [args.S], 1,
+                    args.perms or (10000 if args.mode == 'strong' else 1008),
+                    args.boots or (10000 if args.mode == 'strong' else 1008), args.cpu_sample)
+    if c == 'c2':
+        return PLSC(args, 'c2', 'behavioral', 80, 10000, 10, [80], 1, args.perms or 5000, args.boots or 5000,
+                    200)
+    if c == 'c3':
+        return PLSC(args, 'c3', 'meancentered', 200, 50000, 0, [25, 25, 25, 25], 2, args.perms or 10000,
+                    args.boots or 10000, 100)
+    if c == 'c5':
+        return Simpls(args)
+    if c == 'c4split':
+        return SplitHalf(args)
+    raise SystemExit('unknown --config ' + c)
 
 
 def main():
@@ -64,169 +463,151 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='c4', choices=['c4', 'c2', 'c3', 'c5', 'c4split'])
+    ap.add_argument('--mode', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--S', type=int, default=500)
     ap.add_argument('--B', type=int, default=200000)
     ap.add_argument('--T', type=int, default=50)
-    ap.add_argument('--perms', type=int, default=1008, help='permutations per step per GPU')
-    ap.add_argument('--boots', type=int, default=1008, help='bootstraps per step per GPU')
+    ap.add_argument('--perms', type=int, default=0,
+                    help='permutations per step (per GPU in weak mode, total in strong mode)')
+    ap.add_argument('--boots', type=int, default=0, help='bootstraps per step (same convention)')
     ap.add_argument('--cpu-sample', type=int, default=8,
                     help='permutations and bootstraps (each) timed for the CPU baseline; 0 = skip')
+    ap.add_argument('--no-primal', action='store_true', help='skip the second (feature-pass) timed region')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and rank == 0:
+        sys.stderr.write('bench.py: --gpus {} but the launcher started {} rank(s); using {}\n'
+                         .format(args.gpus, world, world))
+    if torch.cuda.device_count() < (world if world > 1 else 1):
+        sys.stderr.write('bench.py: {} rank(s) but {} visible GPU(s)\n'.format(world, torch.cuda.device_count()))
+        sys.exit(2)
     backend = os.environ.get('PLSX_BENCH_BACKEND', 'nccl')   # 'gloo' only for single-GPU dry runs
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device('cuda', torch.cuda.current_device())
+    # The process group exists at N = 1 too, so the collective of the step runs on
+    # RCCL in every configuration the driver measures.
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(free_port()))
+    collective = backend
+    try:
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', torch.cuda.current_device()))
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device('cuda', torch.cuda.current_device())
+    except Exception as exc:                               # pragma: no cover
+        if world > 1:
+            raise
+        collective = 'none (process group init failed: {})'.format(str(exc)[:120])
+    world = dist.get_world_size() if dist.is_initialized() else 1
 
-    from pypyls_amd import resampling, hostmath
-    from pypyls_amd.engine import Engine
-
-    S, B, T = args.S, args.B, args.T
-    X, Y = synth(S, B, T)
-    # long-lived engine: fixed 48 GB super-batch scratch, mapped during warm-up
-    eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
-    eng.set_data(X, Y, resampling.cell_of_row([S], 1), 1, 1, 0)
-    xw, sv, yw = eng.decompose()
-    xw, yw = hostmath.sign_convention(xw, yw)
-    eng.set_original(xw, sv, yw)
-    L, Tp = eng.L, eng.Tp
-
-    # distinct index arrays per rank and per step, resident in HBM before timing
+    wl = make_workload(args)
     n_steps = args.steps + args.warmup
-    perm_idx, boot_idx = [], []
-    for s in range(n_steps):
-        seed = 1234 + 1000 * rank + s
-        perm_idx.append(eng.index_tensor(
-            resampling.gen_permsamp([S], 1, args.perms, seed=seed, verbose=False)))
-        boot_idx.append(eng.index_tensor(
-            resampling.gen_bootsamp([S], 1, args.boots, seed=seed + 500, verbose=False)))
-    out_sv = torch.empty((args.perms, L), dtype=torch.float64, device=dev)
-    dist_out = torch.empty((args.boots, Tp, L), dtype=torch.float64, device=dev)
-    usum = torch.zeros((B, L), dtype=torch.float64, device=dev)
-    usq = torch.zeros((B, L), dtype=torch.float64, device=dev)
+    wl.setup(rank, n_steps, dev)
+    eng = wl.eng
 
-    leg_events = []
+    def timed_region():
+        for i in range(args.warmup):
+            wl.step(i)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        eng.set_timing(True)
+        wl.legs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_steps):
+            wl.step(i, timed=True)
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist.is_initialized() and world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
 
-    def step(i, timed=False):
-        if timed:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            ev[0].record()
-        eng.perm_into(perm_idx[i], out_sv, rotate=True)
-        if timed:
-            ev[1].record()
-        eng.boot_into(boot_idx[i], usum, usq, dist_out)
-        if timed:
-            ev[2].record()
-            leg_events.append(ev)
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    eng.set_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_steps):
-        step(i, timed=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device=dev if backend == 'nccl' else torch.device('cpu'))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region()
     timing = eng.last_timing()
+    kt = eng.kernel_timing()
+    roof = wl.roofline(kt, args.steps, world) if rank == 0 else None
+    legs = [[e[j].elapsed_time(e[j + 1]) for j in range(3)] for e in wl.legs]
     eng.set_timing(False)
+    dual = bool(timing.get('dual_perm', 0))
+
+    # second region: permutations through the feature pass (the north-star pipeline)
+    elapsed_primal = None
+    if isinstance(wl, PLSC) and dual and not args.no_primal:
+        eng.set_perm_path(False)
+        elapsed_primal = timed_region()
+        legs_p = [[e[j].elapsed_time(e[j + 1]) for j in range(3)] for e in wl.legs]
+        eng.set_timing(False)
+        eng.set_perm_path(True)
 
     if rank == 0:
-        per_step = args.perms + args.boots
-        total = per_step * args.steps * world
-        value = total / elapsed
-        # dominant kernel: k_xprod.  Algorithmic flops per resample of this
-        # kernel: 2*S*T'*B (first term of SURVEY section 8d W_F); a launch
-        # processes `launch_units` resamples.
-        launches = max(int(timing.get('xprod_launches', 0)), 1)
-        avg_ms = timing.get('xprod_ms', 0.0) / launches
-        dual = bool(timing.get('dual_perm', 0))
-        # resamples the timed k_xprod launches covered (bootstraps only when the
-        # permutations take the dual S x S path and launch no k_xprod at all)
-        units_per_launch = timing.get('xprod_resamples', per_step * args.steps) / launches
-        flops_launch = 2.0 * S * Tp * B * units_per_launch
-        achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_xprod.json')
+        units = wl.units_per_step(world)
+        value = units * args.steps / elapsed
+        ms_step = 1e3 * elapsed / args.steps
+        cfgd = {'workload': '{} (BASELINE config {}) on {} GPU(s)'.format(wl.describe(world), wl.name, world),
+                'mode': args.mode, 'collective': '{} all_gather_into_tensor, 1 per step, world {}'.format(
+                    collective, world),
+                'parallelism': 'resample-sharded x{}'.format(world),
+                'kernel_ms_per_step': {k: v[0] / args.steps for k, v in kt.items()}}
+        if isinstance(wl, (PLSC, Simpls)):
+            cfgd.update({'perms_per_step': wl.perms, 'boots_per_step': wl.boots,
+                         'per': 'GPU' if args.mode == 'weak' else 'analysis (all GPUs)'})
+        if legs:
+            names = ['perm_ms_per_step', 'boot_ms_per_step', 'collective_ms_per_step'] if args.mode == 'weak' \
+                else ['indexgen_h2d_resample_ms_per_step', 'unused', 'collective_ms_per_step']
+            for j, nm in enumerate(names):
+                if nm != 'unused':
+                    cfgd[nm] = float(np.mean([l[j] for l in legs]))
+        out = {
+            'metric': 'resamples/sec (perm+boot), behavioral_pls X({}x{})/Y({}x{}) fp64'.format(
+                wl.S, wl.B, wl.S, wl.T) if wl.name == 'c4' else '{} ({})'.format(wl.unit, wl.name),
+            'value': value, 'unit': wl.unit, 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_step, 'higher_is_better': True,
+            'scaling': args.mode, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': cfgd, 'roofline': roof,
+        }
+        if isinstance(wl, PLSC):
+            cfgd['perm_path'] = 'dual (S x S kernel; included in value, excluded from value_primal)' if dual \
+                else 'feature pass'
+            pm, ph = wl.pipeline(ms_step, primal=not dual)
+            roof['pipeline_frac_mfma'], roof['pipeline_frac_hbm'] = pm, ph
+            if elapsed_primal is not None:
+                out['value_primal'] = units * args.steps / elapsed_primal
+                out['ms_per_step_primal'] = 1e3 * elapsed_primal / args.steps
+                cfgd['perm_ms_per_step_primal'] = float(np.mean([l[0] for l in legs_p]))
+                pm, ph = wl.pipeline(out['ms_per_step_primal'], primal=True)
+                roof['pipeline_frac_mfma_primal'], roof['pipeline_frac_hbm_primal'] = pm, ph
+            elif not dual:
+                out['value_primal'] = value
+        roof['traffic'] = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_{}.json'.format(wl.name))
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get('hbm_bytes_per_launch') * units_per_launch / tj.get('resamples_per_launch')
+                roof['traffic'] = tj['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/traffic_{}.json ({})'.format(wl.name, tj.get('kernel', ''))
             except Exception:
-                traffic = None
-        # whole-pipeline fractions: algorithmic flops / bytes of THIS formulation
-        # (DESIGN.md section 5).  Bootstrap: cross-product + Gram + R.U0 + U
-        # rotation, all O(B).  Permutation: O(B) only without the dual path;
-        # with it, the S x S kernel once per call plus O(T' S^2) per permutation.
-        wf_boot = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
-        wb_boot = 8.0 * S * (B + Tp)
-        if dual:
-            wf_perm = 2.0 * Tp * S * S + 2.0 * Tp * Tp * S + 2.0 * S * S * B / max(args.perms, 1)
-            wb_perm = 8.0 * (S * B / max(args.perms, 1) + 3.0 * Tp * S)
-        else:
-            wf_perm = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B
-            wb_perm = wb_boot
-        steps_per_s = args.steps / elapsed
-        frac_mfma = steps_per_s * (args.perms * wf_perm + args.boots * wf_boot) / (PEAK_FP64_MFMA_TFLOPS * 1e12)
-        frac_hbm = steps_per_s * (args.perms * wb_perm + args.boots * wb_boot) / (PEAK_HBM_TBS * 1e12)
-        perm_ms = sum(e[0].elapsed_time(e[1]) for e in leg_events) / max(len(leg_events), 1)
-        boot_ms = sum(e[1].elapsed_time(e[2]) for e in leg_events) / max(len(leg_events), 1)
-        out = {
-            'metric': 'resamples/sec (perm+boot), behavioral_pls X({}x{})/Y({}x{}) fp64'
-                      .format(S, B, S, T),
-            'value': value, 'unit': 'resamples/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'behavioral_pls X({}x{}) Y({}x{}) fp64 (BASELINE configs[3] '
-                                   'shape on {} GPU(s)), n_split=0, test_split=0'
-                                   .format(S, B, S, T, world),
-                       'perms_per_step_per_gpu': args.perms, 'boots_per_step_per_gpu': args.boots,
-                       'perm_path': 'dual (S x S kernel)' if dual else 'feature pass',
-                       'perm_ms_per_step': perm_ms, 'boot_ms_per_step': boot_ms,
-                       'parallelism': 'resample-sharded x{}'.format(world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_xprod<{}>'.format(int(timing.get('m_tiles', 0))),
-                         'achieved': achieved, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,
-                         'avg_launch_ms': avg_ms, 'launches': launches,
-                         'resamples_per_launch': units_per_launch,
-                         'measured_mfma_f64_peak_tflops': eng.mfma_f64_peak(),
-                         'pipeline_frac_mfma': frac_mfma, 'pipeline_frac_hbm': frac_hbm},
-        }
+                pass
+        roof['measured_mfma_f64_peak_tflops'] = eng.mfma_f64_peak()
         if world == 1 and args.cpu_sample > 0:
-            cores = os.cpu_count() or 1
-            v, dt = cpu_baseline(X, Y, xw, yw, args.cpu_sample)
-            out['cpu_baseline'] = {
-                'value': v, 'unit': 'resamples/s', 'cores': cores, 'kind': 'port',
-                'sample': '{} permutations + {} bootstraps of the same workload through '
-                          'oracle/cpu_ref.py (numpy, BLAS threads = host cores), {:.1f} s'
-                          .format(args.cpu_sample, args.cpu_sample, dt)}
-        print(json.dumps(out))
-    if world > 1:
+            v, sample = wl.cpu_baseline()
+            out['cpu_baseline'] = {'value': v, 'unit': wl.unit, 'cores': os.cpu_count() or 1, 'kind': 'port',
+                                   'sample': sample}
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -252,8 +252,27 @@ int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
  * (joblib workers size themselves, pyls/base.py:490-507). */
 int plsx_set_scratch(plsx_ctx* ctx, double max_gb, int fixed);
 
-/* Enable (1) / disable (0) event timing of the cross-product kernel. */
+/* Enable (1) / disable (0) event timing of the kernel launches (HIP events on
+ * the launch stream); enabling clears the records. */
 int plsx_set_timing(plsx_ctx* ctx, int enable);
+
+/* Summed duration (ms) and launch count of one kernel class since timing was
+ * enabled: 0 k_xprod (cross-product), 1 k_gram / k_gram4 (+ partial reduce),
+ * 2 k_small (Jacobi + Procrustes), 3 k_urot (+ split add), 4 k_nt_gemm
+ * (+ reduce), 5 k_ucorr_partial, 6 k_simpls_dual, 7 reserved.
+ * plsx_kernel_class_name returns the label, NULL past the last class.
+ * Measurement only; no reference counterpart. */
+int plsx_kernel_timing(const plsx_ctx* ctx, int kernel_class, double* ms, int* launches);
+const char* plsx_kernel_class_name(int kernel_class);
+
+/* Route of plsx_perm_batch: dual = 1 (default where available) forms the S x S
+ * kernel of the fixed feature matrix once per call and never touches the
+ * features again; dual = 0 takes the feature pass R_p = A_p X per permutation,
+ * the same pipeline the bootstrap uses (the north-star pipeline; what
+ * bench.py reports as value_primal).  Both give the same statistics to
+ * rounding.  Returns the route now in effect (0 / 1) or a negative status.
+ * Equivalent environment switch at bind time: PLSX_NO_DUAL_PERM=1. */
+int plsx_set_perm_path(plsx_ctx* ctx, int dual);
 
 #ifdef __cplusplus
 }

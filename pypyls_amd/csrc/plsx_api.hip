@@ -29,8 +29,10 @@ struct plsx_ctx {
     // problem
     int method = 0, S = 0, B = 0, T = 0, J = 0, n_groups = 0, n_cond = 1, mc = 0, cov = 0;
     int Tp = 0, Tpp = 0, L = 0, Kpad = 0, nks = 0, Bx = 0, Bpad = 0;
-    // plan
-    int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, Gcap = 0, Galloc = 0;
+    // plan.  momrows: the group carries per-cell moment rows (feature mean / std of the
+    // resampled rows come out of the same pass); scaled: the epilogue also applies 1/std
+    // to R (correlation mode).  Covariance mode keeps the rows for cross-validation's zmap.
+    int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, momrows = 0, Gcap = 0, Galloc = 0;
     int nks_t = 0, LT = 0;
     size_t group_stride = 0;
     // fixed-X fast path (behavioral permutations): pre-scaled features, no moment tiles
@@ -49,16 +51,16 @@ struct plsx_ctx {
     Buf gws;                                            // small-solver workspace (T' > PLSX_LDS_TP)
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
-    int dual = 0;
+    int dual = 0, dual_ok = 0;
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
     bool has_okx = false, has_oky = false;
     double* mom_out_arg = nullptr;                      // set while a launch should export feature moments
     int ncomp = 0;
-    // timing of the cross-product kernel
+    // per-kernel-class timing (HIP events on the launch stream)
     int timing = 0;
-    int variant = 0;        // cross-product kernel variant (PLSX_XPROD_VARIANT, tuning only)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    struct TimedEv { int cls; hipEvent_t e0, e1; };
+    std::vector<TimedEv> events;
     long long timed_units = 0;
     double scratch_gb = 48.0;                           // super-batch scratch budget
     int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
@@ -123,6 +125,41 @@ void release(Buf& b)
 template <class T>
 T* ptr(const Buf& b) { return static_cast<T*>(b.p); }
 
+// Kernels that need more than the default 64 KB of dynamic LDS.  The attribute
+// belongs to the (device, function) pair, so it is set on every launch path
+// instead of being cached in a per-process flag (a second context on another
+// GPU of the same process must not skip it); the call costs ~1 us.
+template <class F>
+hipError_t set_lds(F* fn, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+// kernel classes of plsx_kernel_timing()
+enum { KC_XPROD = 0, KC_GRAM, KC_SMALL, KC_UROT, KC_NT, KC_UCORR, KC_SIMPLS, KC_BUILD, KC_COUNT };
+const char* const kKernelClassNames[KC_COUNT] = {"k_xprod", "k_gram", "k_small", "k_urot", "k_nt_gemm",
+                                                 "k_ucorr_partial", "k_simpls_dual", "k_build_A"};
+
+// Brackets the launches of one kernel class with two events when timing is on.
+struct KTimer {
+    plsx_ctx* c; int cls; hipStream_t st; hipEvent_t e0 = nullptr;
+    KTimer(plsx_ctx* ctx, int k, hipStream_t s) : c(ctx), cls(k), st(s)
+    {
+        if (c->timing && hipEventCreate(&e0) == hipSuccess) (void)hipEventRecord(e0, st);
+    }
+    ~KTimer()
+    {
+        if (!e0) return;
+        hipEvent_t e1 = nullptr;
+        if (hipEventCreate(&e1) == hipSuccess) {
+            (void)hipEventRecord(e1, st);
+            c->events.push_back({cls, e0, e1});
+        } else (void)hipEventDestroy(e0);
+    }
+};
+
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
@@ -130,7 +167,8 @@ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 void plan_groups(plsx_ctx* c)
 {
     c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;   // mean-centred / regression: no feature scaling
-    const int Jw = c->scaled ? c->J : 0;
+    c->momrows = (c->method == PLSX_BEHAVIORAL) ? 1 : 0;
+    const int Jw = c->momrows ? c->J : 0;
     int best = 1;
     for (int n = 1; n <= 512; ++n) {
         int td = ceil_div(n * c->Tp, 16), tw = Jw ? ceil_div(n * Jw, 16) : 0;
@@ -160,8 +198,6 @@ int upload_rowmaps(plsx_ctx* ctx)
 {
     const int rows = ctx->MT * 16;
     std::vector<int> out_row(rows, -1), mom_idx(rows, -1);
-    const int data_tiles = ctx->scaled ? ctx->w0 : ceil_div(ctx->npg * ctx->Tp, 16);
-    (void)data_tiles;
     for (int rr = 0; rr < ctx->npg; ++rr)
         for (int t = 0; t < ctx->Tp; ++t) {
             int row = rr * ctx->Tp + t;
@@ -223,65 +259,32 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     return std::max(1, std::min(g, cap));
 }
 
-template <int MT, int NW, int KT, int NSQ, int DBG = 0>
+template <int MT, int NW, int KT, int NSQ>
 int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 {
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
     const size_t epi = (size_t)NW * 2 * NSQ * 16 * 16 * 8 + (size_t)2 * MT * 16 * 4;
     const size_t lds = std::max(stage, epi);
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ, DBG>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, NSQ>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
     dim3 grid(ncolblk * round_up(groups, 8)), block(NW * 64);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, st));
-    }
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ, DBG>), grid, block, lds, st,
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ>), grid, block, lds, st,
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
                        std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg, SplitEpi{});
     LAUNCHCHK();
-    if (ctx->timing) {
-        HIPCHK(hipEventRecord(e1, st));
-        ctx->events.emplace_back(e0, e1);
-    }
     return 0;
-}
-
-template <int NW, int KT>
-int launch_xprod_nsq(plsx_ctx* ctx, int groups, hipStream_t st)
-{
-    switch (ctx->MT - ctx->sq0) {          // number of second-moment tiles (0..3)
-        case 0: return launch_xprod_t<24, NW, KT, 0>(ctx, groups, st);
-        case 1: return launch_xprod_t<24, NW, KT, 1>(ctx, groups, st);
-        case 2: return launch_xprod_t<24, NW, KT, 2>(ctx, groups, st);
-        default: return launch_xprod_t<24, NW, KT, 3>(ctx, groups, st);
-    }
 }
 
 int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 {
-    switch (ctx->variant) {
-        case 1: return launch_xprod_nsq<8, 2>(ctx, groups, st);
-        case 3: return launch_xprod_nsq<4, 2>(ctx, groups, st);
-        case 2: return launch_xprod_nsq<8, 1>(ctx, groups, st);
-        case 10: return launch_xprod_t<24, 4, 1, 1, 64>(ctx, groups, st);  // +12 VALU per k-step (cost probe)
-        case 7: return launch_xprod_t<24, 4, 1, 1, 128>(ctx, groups, st);  // flat-addressed loads (pre-buffer-resource)
-        case 11: return launch_xprod_t<24, 4, 1, 1, 1>(ctx, groups, st);   // tuning probes (wrong results)
-        case 12: return launch_xprod_t<24, 4, 1, 1, 2>(ctx, groups, st);
-        case 13: return launch_xprod_t<24, 4, 1, 1, 3>(ctx, groups, st);
-        case 14: return launch_xprod_t<24, 4, 1, 1, 4>(ctx, groups, st);
-        case 16: return launch_xprod_t<24, 4, 1, 1, 6>(ctx, groups, st);
-        case 17: return launch_xprod_t<24, 4, 1, 1, 7>(ctx, groups, st);
-        default: return launch_xprod_nsq<4, 1>(ctx, groups, st);
+    switch (ctx->MT - ctx->sq0) {          // number of second-moment tiles (0..3)
+        case 0: return launch_xprod_t<24, 4, 1, 0>(ctx, groups, st);
+        case 1: return launch_xprod_t<24, 4, 1, 1>(ctx, groups, st);
+        case 2: return launch_xprod_t<24, 4, 1, 2>(ctx, groups, st);
+        default: return launch_xprod_t<24, 4, 1, 3>(ctx, groups, st);
     }
 }
 
@@ -308,30 +311,16 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
     constexpr int MT = 25, NW = 4, KT = 1;
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
     const size_t lds = std::max(stage, (size_t)2 * MT * 16 * 4);
-    static bool configured = false;
-    if (!configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, 0, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
     dim3 grid(ncolblk * round_up(groups, 8)), block(NW * 64);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
-        HIPCHK(hipEventRecord(e0, st));
-    }
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 0>), grid, block, lds, st,
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0>), grid, block, lds, st,
                        ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->Xn), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npgf * ctx->Tpp,
                        ptr<int>(ctx->out_row_f), ptr<int>(ctx->mom_idx_f), ptr<double>(ctx->mom_n), 0,
                        groups, ncolblk, (double*)nullptr, SplitEpi{});
     LAUNCHCHK();
-    if (ctx->timing) {
-        HIPCHK(hipEventRecord(e1, st));
-        ctx->events.emplace_back(e0, e1);
-    }
     return 0;
 }
 
@@ -357,7 +346,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
         hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ystack ? ystack : ptr<double>(ctx->Y),
                            ystack ? (long long)ctx->S * ctx->T : 0LL, ctx->T, ctx->S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay,
-                           ctx->cov, ctx->scaled, ptr<double>(ctx->Afrag), ctx->group_stride,
+                           ctx->cov, ctx->momrows, ptr<double>(ctx->Afrag), ctx->group_stride,
                            ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16));
     } else {
         dim3 grid(nres), block(256);
@@ -422,6 +411,7 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     if (int e = ensure(ctx, ctx->part, bytes)) return e;
     a.part = ptr<double>(ctx->part);
     dim3 grid(nchunk, tiles, batch), block(256);
+    KTimer tm(ctx, KC_NT, st);
     hipLaunchKernelGGL(k_nt_gemm, grid, block, 0, st, a);
     LAUNCHCHK();
     {
@@ -461,6 +451,7 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
     double* part = ptr<double>(ctx->part);
     constexpr size_t lds = (size_t)2 * (NB + (NB + 3) / 4) * 128 * 8;
+    KTimer tm(ctx, KC_GRAM, st);
     hipLaunchKernelGGL((k_gram4<NB, NB, WG>), dim3(nchunk, nblk), dim3(256), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres);
     LAUNCHCHK();
@@ -530,6 +521,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
     double* part = ptr<double>(ctx->part);
     dim3 grid(nchunk, nres), block(256);
+    KTimer tm(ctx, KC_GRAM, st);
 #define GRAM_ARGS R, ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres
     if (mode == 0) hipLaunchKernelGGL(k_gram<0>, grid, block, 0, st, GRAM_ARGS);
     else if (mode == 1) hipLaunchKernelGGL(k_gram<1>, grid, block, 0, st, GRAM_ARGS);
@@ -560,6 +552,7 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
     const int n = a.n, ld = n | 1;
+    KTimer tm(ctx, KC_SMALL, st);
     if (n > PLSX_LDS_TP) {
         // work matrices in a global workspace (L2), bookkeeping vectors in LDS
         if (int e = ensure(ctx, ctx->gws, (size_t)nres * 2 * n * ld * 8)) return e;
@@ -570,12 +563,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
         return 0;
     }
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_small<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_small<false>, lds));
     hipLaunchKernelGGL(k_small<false>, dim3(nres), dim3(256), lds, st, a);
     LAUNCHCHK();
     return 0;
@@ -589,12 +577,7 @@ int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* u
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
     const size_t lds = NKS < 0 ? 0 : (size_t)2 * ceil_div(ctx->nks_t * LT, 2) * 1024;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_urot<LT, NKS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_urot<LT, NKS>, lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
     hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
@@ -620,6 +603,7 @@ int launch_urot_lt(plsx_ctx* ctx, int ltc, int nres, int lt0, int nsplit, int rp
 int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st)
 {
     const int nks = ctx->nks_t, LT = ctx->LT;
+    KTimer tm(ctx, KC_UROT, st);
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     int nsplit = 1;
     if (!out && nres >= 64) {
@@ -675,12 +659,7 @@ template <int LT, int NKS, class... Args>
 int launch_ucorr_t(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
 {
     const size_t lds = NKS < 0 ? 0 : (size_t)ctx->nks_t * LT * 64 * 8;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ucorr_partial<LT, NKS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_ucorr_partial<LT, NKS>, lds));
     hipLaunchKernelGGL((k_ucorr_partial<LT, NKS>), grid, block, lds, st, args...);
     return 0;
 }
@@ -704,6 +683,7 @@ int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, const dou
 {
     const int nks = ctx->nks_t, LT = ctx->LT, lpad = LT * 16;
     const double* R = ptr<double>(ctx->R);
+    KTimer tm(ctx, KC_UCORR, st);
     if (LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: return launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
@@ -782,7 +762,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
         release(*b);
-    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
     return PLSX_OK;
 }
@@ -847,7 +827,6 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     ctx->cov = (flags & PLSX_FLAG_COVARIANCE) ? 1 : 0;
     ctx->Tp = Tp; ctx->Tpp = round_up(Tp, 4); ctx->L = std::min(Tp, B);
     ctx->Kpad = round_up(S, 8); ctx->nks = ctx->Kpad / 4;
-    { const char* v = getenv("PLSX_XPROD_VARIANT"); ctx->variant = v ? atoi(v) : 0; }
     ctx->Bx = B + ctx->L; ctx->Bpad = round_up(ctx->Bx, 128);
     ctx->nks_t = ctx->Tpp / 4; ctx->LT = ceil_div(ctx->L, 16);
     ctx->strideR = (long long)ctx->Tpp * ctx->Bpad;
@@ -892,7 +871,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     plan_groups(ctx);
     {
         // one resample (data rows + its moment rows) must fit the 24 tiles of a block
-        const int tw1 = ctx->scaled ? ceil_div(J, 16) : 0;
+        const int tw1 = ctx->momrows ? ceil_div(J, 16) : 0;
         if (ceil_div(Tp, 16) + 2 * tw1 > ctx->MT || tw1 * 16 > 48)
             return fail(ctx, PLSX_ERR_UNSUPPORTED,
                         "stacked dimension T' (plus its per-cell moment rows) exceeds the 384 rows of a block");
@@ -927,8 +906,8 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     {
         // dual permutation path: needs a resample-independent feature matrix
         const char* nd = getenv("PLSX_NO_DUAL_PERM");
-        ctx->dual = (!(nd && atoi(nd)) &&
-                     (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->fix || ctx->cov)))) ? 1 : 0;
+        ctx->dual_ok = (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->fix || ctx->cov))) ? 1 : 0;
+        ctx->dual = (ctx->dual_ok && !(nd && atoi(nd))) ? 1 : 0;
     }
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
@@ -1181,14 +1160,10 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
     const size_t epi = (size_t)NW * 5 * NMOM * 16 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
     const size_t lds = std::max(stage, epi);
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_xprod<MT, NW, KT, NSQ, 2048>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, NSQ, true>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ, 2048>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds,
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ, true>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds,
                        st, ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
                        ptr<double>(ctx->R), ctx->Bpad, ctx->npg * 2 * ctx->Tpp, ptr<int>(ctx->out_row_s),
                        ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 0), groups,
@@ -1337,8 +1312,6 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
     NEED_DATA();
     if (ctx->method != PLSX_BEHAVIORAL)
         return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: cross-validation is defined for behavioral PLS");
-    if (ctx->cov)
-        return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_crossval_batch: covariance=True is not supported");
     if (!d_masks || !d_r || !d_r2 || m < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1422,12 +1395,8 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     if (lds > 160 * 1024)
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
                     "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_simpls_dual),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_simpls_dual, lds));
+    KTimer tm(ctx, KC_SIMPLS, st);
     hipLaunchKernelGGL(k_simpls_dual, dim3(nres), dim3(512), lds, st, a);
     LAUNCHCHK();
     return 0;
@@ -1541,7 +1510,7 @@ int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, con
                   int n_boot, int add_orig, long long count, double* d_bsr, double* d_se, void* stream)
 {
     if (!ctx) return PLSX_ERR_ARG;
-    if (!d_orig || !d_usum || !d_usq || !d_bsr || !d_se || count < 1 || n_boot < 2)
+    if (!d_orig || !d_usum || !d_usq || !d_bsr || !d_se || count < 1 || n_boot < 1)
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_rel: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_boot_rel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
@@ -1587,12 +1556,7 @@ int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, i
     if (p2 > 16384) return fail(ctx, PLSX_ERR_UNSUPPORTED, "plsx_percentile_ci: more than 16384 values per series");
     HIPCHK(hipSetDevice(ctx->device));
     const size_t lds = (size_t)p2 * 8;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_percentile2),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    HIPCHK(set_lds(k_percentile2, lds));
     hipLaunchKernelGGL(k_percentile2, dim3((unsigned)nseries), dim3(256), lds, static_cast<hipStream_t>(stream),
                        d_data, n, p2, i_lo, g_lo, i_hi, g_hi, d_lo, d_hi);
     LAUNCHCHK();
@@ -1613,7 +1577,7 @@ int plsx_set_timing(plsx_ctx* ctx, int enable)
 {
     if (!ctx) return PLSX_ERR_ARG;
     ctx->timing = enable ? 1 : 0;
-    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     ctx->events.clear();
     ctx->timed_units = 0;
     return PLSX_OK;
@@ -1624,16 +1588,49 @@ int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
     plsx_ctx* ctx = const_cast<plsx_ctx*>(cctx);
     if (!ctx || !out || cap < 1) return PLSX_ERR_ARG;
     double ms = 0.0;
+    int launches = 0;
     for (auto& ev : ctx->events) {
+        if (ev.cls != KC_XPROD) continue;
         float t = 0.f;
-        if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess)
+        if (hipEventSynchronize(ev.e1) == hipSuccess && hipEventElapsedTime(&t, ev.e0, ev.e1) == hipSuccess)
             ms += t;
+        ++launches;
     }
-    double vals[7] = {ms, (double)ctx->events.size(), (double)ctx->npg, (double)ctx->MT,
+    double vals[7] = {ms, (double)launches, (double)ctx->npg, (double)ctx->MT,
                       (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual};
     int n = std::min(cap, 7);
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
+}
+
+int plsx_kernel_timing(const plsx_ctx* cctx, int kernel_class, double* ms_out, int* launches_out)
+{
+    plsx_ctx* ctx = const_cast<plsx_ctx*>(cctx);
+    if (!ctx || kernel_class < 0 || kernel_class >= KC_COUNT) return PLSX_ERR_ARG;
+    double ms = 0.0;
+    int launches = 0;
+    for (auto& ev : ctx->events) {
+        if (ev.cls != kernel_class) continue;
+        float t = 0.f;
+        if (hipEventSynchronize(ev.e1) == hipSuccess && hipEventElapsedTime(&t, ev.e0, ev.e1) == hipSuccess)
+            ms += t;
+        ++launches;
+    }
+    if (ms_out) *ms_out = ms;
+    if (launches_out) *launches_out = launches;
+    return PLSX_OK;
+}
+
+const char* plsx_kernel_class_name(int kernel_class)
+{
+    return (kernel_class >= 0 && kernel_class < KC_COUNT) ? kKernelClassNames[kernel_class] : nullptr;
+}
+
+int plsx_set_perm_path(plsx_ctx* ctx, int dual)
+{
+    NEED_DATA();
+    ctx->dual = (dual && ctx->dual_ok) ? 1 : 0;
+    return ctx->dual;
 }
 
 }  // extern "C"

@@ -333,10 +333,14 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
             const double vF = cyyF / (len - 1.0);
             const int row = rr * lay.Tp + j * T + t;
             double* rc = rowc + ((size_t)g * lay.MT * 16 + row) * 5;
+            // a half with fewer than two rows of the cell, or a behaviour that is
+            // constant on it, has no z-score: NaN, as scipy's zscore(ddof=1) gives the
+            // reference (compute.py:84) and as the two-pass path produces
+            const double qnan = __builtin_nan("");
             rc[0] = c1;
-            rc[1] = (v1 > 0.0) ? 1.0 / ((n1 - 1.0) * sqrt(v1)) : 0.0;
+            rc[1] = (v1 > 0.0) ? 1.0 / ((n1 - 1.0) * sqrt(v1)) : qnan;
             rc[2] = c2;
-            rc[3] = (v2 > 0.0) ? 1.0 / ((n2 - 1.0) * sqrt(v2)) : 0.0;
+            rc[3] = (v2 > 0.0) ? 1.0 / ((n2 - 1.0) * sqrt(v2)) : qnan;
             rc[4] = (vF > 0.0) ? (len - 1.0) * sqrt(vF) : 0.0;
         }
         __syncthreads();
@@ -378,21 +382,7 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
 // Copy one fragment-ordered A stage (STAGE doubles) global -> LDS with the
 // LDS-DMA path: each wave instruction moves 64 lanes x 16 B into
 // wave-uniform-base + lane*16, i.e. a straight lane-linear memcpy.
-template <int NT, int PASSES, bool EVEN, int STAGE>
-__device__ __forceinline__ void stage_copy(const double* __restrict__ src, double* dst, int tid)
-{
-    const int wbase = (tid >> 6) * 64;
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        if (EVEN || p * NT + wbase < STAGE / 2) {
-            __builtin_amdgcn_global_load_lds(
-                (const void*)(src + (size_t)(p * NT + tid) * 2),
-                (__attribute__((address_space(3))) void*)(dst + (size_t)(p * NT + wbase) * 2), 16, 0, 0);
-        }
-    }
-}
-
-// Same copy through a buffer resource: the per-lane offset (tid * 16) never
+// The copy goes through a buffer resource: the per-lane offset (tid * 16) never
 // changes and the per-pass offset is an SGPR, so the copy costs no VALU
 // instruction at all (VALU issue between fp64 MFMAs costs matrix-pipe slots;
 // flat addressing needs 64-bit VALU adds per load).
@@ -423,7 +413,7 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 // NSQ = number of second-moment tiles; they are the LAST NSQ tiles of the block
 // (static split: no per-tile operand select in the MFMA loop -- VALU work between
 // fp64 MFMAs costs matrix-pipe issue slots on gfx950, measured 8 %).
-template <int MT, int NW, int KT, int NSQ, int DBG = 0>
+template <int MT, int NW, int KT, int NSQ, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64, 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
@@ -463,8 +453,6 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     const int kq = lane >> 4;
 
     const double* Ag = Afrag + (size_t)grp * group_stride;
-    const double* Xp = X + (size_t)kq * ldx + col;
-    constexpr bool FLAT = (DBG & 128) != 0;           // old flat-addressed loads (A/B probe)
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int xvoff = (kq * ldx + col) * 8;            // per-lane byte offset inside a 4-row k-step
 
@@ -474,12 +462,10 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     const int nkt = nks / KT;
     // prologue: stage 0 of A, first X fragments
-    if (FLAT) stage_copy<NT, PASSES, EVEN, STAGE>(Ag, smem, tid);
-    else stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
+    stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
     double xb[KT];
 #pragma unroll
-    for (int s = 0; s < KT; ++s)
-        xb[s] = FLAT ? Xp[(size_t)(s * 4) * ldx] : load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
+    for (int s = 0; s < KT; ++s) xb[s] = load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
     // Force the first X fragments to be resident before the loop: a load still
     // pending at the loop header makes hipcc place a near-draining
     // s_waitcnt vmcnt(1) right after the next stage's loads are issued.
@@ -493,42 +479,24 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         // loop body branch-free so the waits sit right before the LDS write)
         const int kn = min(kt + 1, nkt - 1);
         double xn[KT];
-        if (!(DBG & 2)) {
-            // A stage kn: global -> LDS DMA (global_load_lds_dwordx4: no staging
-            // VGPRs, no ds_write pass), into the buffer every wave finished
-            // reading before the barrier that ended the previous pass.
-            if (FLAT)
-                stage_copy<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid);
-            else
-                stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS,
-                                                        tid, swave);
+        // A stage kn: global -> LDS DMA (buffer_load ... lds: no staging VGPRs,
+        // no ds_write pass), into the buffer every wave finished reading before
+        // the barrier that ended the previous pass.
+        stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid, swave);
 #pragma unroll
-            for (int s = 0; s < KT; ++s)
-                xn[s] = FLAT ? Xp[(size_t)((kn * KT + s) * 4) * ldx]
-                             : load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
-        }
+        for (int s = 0; s < KT; ++s) xn[s] = load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const double a = (DBG & 1) ? b : sA[(s * MT + m) * 64];
-                acc[m] = mfma_f64(a, (m < MT - NSQ) ? b : bsq, acc[m]);
-            }
+            for (int m = 0; m < MT; ++m)
+                acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
         }
-        if (DBG & 64) {                   // tuning probe: 12 extra VALU ops per k-step
-            int dummy = tid;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(dummy));
-            asm volatile("" :: "v"(dummy));
-        }
-        if (!(DBG & 2)) {
-#pragma unroll
-            for (int s = 0; s < KT; ++s) xb[s] = xn[s];
-            __syncthreads();             // (drains the DMA issued one pass ago, then barrier)
-        }
+        for (int s = 0; s < KT; ++s) xb[s] = xn[s];
+        __syncthreads();             // (drains the DMA issued one pass ago, then barrier)
     }
 
     // ---- epilogue -----------------------------------------------------------
@@ -537,7 +505,6 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
     // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
-    constexpr bool SPLIT = (DBG & 2048) != 0;
     if constexpr (SPLIT && NSQ > 0) {
         // fused split-half: both halves from the first half's raw sums (see SplitEpi)
         double* w5 = smem + wave * (5 * NMOM * 16);          // u1, v1, u2, v2, sF : [5][NMOM][16] per wave
@@ -623,13 +590,6 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         __syncthreads();
     }
     double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
-    if (DBG & 4) {                       // tuning probe: skip the stores
-        double t = 0.0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) t += acc[m][0] + acc[m][1] + acc[m][2] + acc[m][3];
-        if (t == 123.456) Rg[0] = t;
-        return;
-    }
 #pragma unroll
     for (int m = 0; m < W0; ++m) {
         int orow[4];

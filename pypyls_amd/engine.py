@@ -63,6 +63,9 @@ def _load():
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
+        'plsx_kernel_timing': ([vp, i32, ctypes.POINTER(c_d), ctypes.POINTER(i32)], i32),
+        'plsx_kernel_class_name': ([i32], ctypes.c_char_p),
+        'plsx_set_perm_path': ([vp, i32], i32),
         'plsx_set_scratch': ([vp, c_d, i32], i32),
         'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
         'plsx_percentile_ci': ([vp, vp, ctypes.c_longlong, i32, i32, c_d, i32, c_d, vp, vp, vp], i32),
@@ -87,7 +90,8 @@ def exported_symbols():
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
              'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
-             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
+             'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_kernel_timing',
+             'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks']
     return [n for n in names if hasattr(lib, n)]
@@ -406,6 +410,24 @@ class Engine(object):
                                              usum.data_ptr(), usq.data_ptr(), dist_dev.data_ptr(),
                                              self._stream()))
 
+    def simpls_perm_into(self, idx_dev, out_dev):
+        """idx_dev (n, S) int32, out_dev (n, k): pctvar of the permuted Y."""
+        self._check(self.lib.plsx_simpls_perm_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
+                                                    out_dev.data_ptr(), self._stream()))
+
+    def simpls_boot_into(self, idx_dev, usum, usq, yl_dev):
+        """idx_dev (n, S) int32; usum / usq (B, k) accumulated in place; yl_dev (n, T, k)."""
+        self._check(self.lib.plsx_simpls_boot_batch(self.ctx, idx_dev.data_ptr(), None, idx_dev.shape[0],
+                                                    usum.data_ptr(), usq.data_ptr(), yl_dev.data_ptr(),
+                                                    self._stream()))
+
+    def split_half_into(self, perm_dev, masks_dev, uc_dev, vc_dev):
+        """perm_dev (np, S) int32 or None, masks_dev (np, ns, S) uint8, outputs (np, ns, L)."""
+        n_arr, ns = masks_dev.shape[0], masks_dev.shape[1]
+        self._check(self.lib.plsx_split_half_batch(
+            self.ctx, None if perm_dev is None else perm_dev.data_ptr(), n_arr, masks_dev.data_ptr(), ns,
+            uc_dev.data_ptr(), vc_dev.data_ptr(), self._stream()))
+
     def boot_rel(self, orig, usum, usq, n_boot, add_orig=False):
         """compute.boot_rel on the device; orig numpy or tensor (B, L).  With
         add_orig the original is added back first and ``n_boot`` must already
@@ -452,6 +474,28 @@ class Engine(object):
 
     def set_timing(self, enable=True):
         self._check(self.lib.plsx_set_timing(self.ctx, 1 if enable else 0))
+
+    def kernel_timing(self):
+        """{kernel class: (summed ms, launches)} since set_timing(True)."""
+        out = {}
+        k = 0
+        while True:
+            name = self.lib.plsx_kernel_class_name(k)
+            if not name:
+                break
+            ms, n = ctypes.c_double(), ctypes.c_int()
+            self._check(self.lib.plsx_kernel_timing(self.ctx, k, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[name.decode()] = (ms.value, n.value)
+            k += 1
+        return out
+
+    def set_perm_path(self, dual):
+        """Permutations through the S x S dual path (True) or the feature pass."""
+        rc = self.lib.plsx_set_perm_path(self.ctx, 1 if dual else 0)
+        if rc < 0:
+            self._check(rc)
+        return bool(rc)
 
     def last_timing(self):
         buf = (ctypes.c_double * 8)()

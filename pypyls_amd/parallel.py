@@ -11,6 +11,14 @@ collective: an all-gather of a packed per-rank buffer
 
 after which every rank concatenates the slices in rank order and adds the
 partial sums in rank order (fixed order -> deterministic).
+
+The collective deliberately lives HERE, on ``torch.distributed``, and not in
+the C ABI: one process per GPU needs a rendezvous (unique-id exchange) that the
+host launcher already provides through the process group, and PyTorch-ROCm
+bundles its own RCCL -- a second RCCL linked into libplsx.so would be a second
+copy of the runtime in the same process.  libplsx.so therefore stays free of
+any communication library; the packed buffer it fills is handed to
+``all_gather_into_tensor`` by its device pointer.
 """
 import numpy as np
 
@@ -62,78 +70,100 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _flat_layout(Lp, Tp, L, B, n_perm, n_boot, world, with_boot):
-    pmax = shard_bounds(n_perm, 0, world)[1] if n_perm else 0
-    rmax = shard_bounds(n_boot, 0, world)[1] if n_boot else 0
-    sizes = dict(perm=Lp * pmax, dist=Tp * L * rmax,
-                 usum=B * L if with_boot else 0, usq=B * L if with_boot else 0)
-    return pmax, rmax, sizes
+def gather_device(slices, sums, device=None):
+    """The one collective on device tensors.
+
+    slices: list of tensors whose LEADING axis is this rank's shard of resamples
+            (equal trailing shapes on every rank, shard sizes may differ by one);
+            each is padded to ``nmax`` rows, the largest shard, given as
+            (tensor, nmax).
+    sums:   list of tensors to be added over ranks (same shape everywhere).
+    Returns (gathered, summed): gathered[i] has shape (world, nmax, ...) --
+    the caller drops the padding rows with shard_bounds -- and summed[i] the
+    rank-ordered sum.  With no process group (or world 1 on gloo) nothing moves.
+    Everything is packed into ONE flat fp64 buffer so that exactly one
+    all_gather_into_tensor is issued (RCCL when the backend is nccl)."""
+    import torch
+    d = _dist()
+    if d is None:
+        return [_pad_rows(t, n)[None] for t, n in slices], list(sums)
+    world = d.get_world_size()
+    on_gpu = d.get_backend() == 'nccl'
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    pieces, shapes = [], []
+    for t, nmax in slices:
+        t = _pad_rows(t, nmax)
+        shapes.append(tuple(t.shape))
+        pieces.append(t.reshape(-1))
+    for t in sums:
+        shapes.append(tuple(t.shape))
+        pieces.append(t.reshape(-1))
+    homes = [p.device for p in pieces]
+    flat = torch.cat([p.to(device=device, dtype=torch.float64) for p in pieces]) if pieces else \
+        torch.zeros(0, dtype=torch.float64, device=device)
+    gathered = torch.empty((world, flat.numel()), dtype=torch.float64, device=device)
+    d.all_gather_into_tensor(gathered.view(-1), flat)
+    out_g, out_s, off = [], [], 0
+    for i, shp in enumerate(shapes):
+        n = int(np.prod(shp)) if len(shp) else 1
+        blk = gathered[:, off:off + n].reshape((world,) + shp)
+        off += n
+        if i < len(slices):
+            out_g.append(blk)
+        else:
+            acc = blk[0].clone()
+            for r in range(1, world):                   # fixed rank order -> deterministic
+                acc += blk[r]
+            out_s.append(acc.to(homes[i]) if acc.device != homes[i] else acc)
+    return out_g, out_s
+
+
+def _pad_rows(t, n):
+    import torch
+    if t.shape[0] == n:
+        return t
+    if t.shape[0] > n:
+        return t[:n]
+    pad = torch.zeros((n - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    return torch.cat([t, pad])
 
 
 def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
-    """The one collective.  local_perm (L, p_loc) ndarray or None; local_dist
-    (T', L, r_loc) ndarray or None; usum / usq torch tensors (B, L) or None.
-    Returns (perm (L, n_perm) | None, dist (T', L, n_boot) | None, usum, usq)
-    identical on every rank."""
+    """The one collective of a front-end call.  local_perm (L, p_loc) ndarray or
+    None; local_dist (T', L, r_loc) ndarray or None; usum / usq torch tensors
+    (B, L) or None.  Returns (perm (L, n_perm) | None, dist (T', L, n_boot) |
+    None, usum, usq) identical on every rank."""
     rank, world = rank_world()
-    if world == 1:
+    d = _dist()
+    if d is None:
         return local_perm, local_dist, usum, usq
     import torch
-    d = _dist()
     with_boot = usum is not None
-    home = usum.device if with_boot else None
     if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU
-        device = home if home is not None else torch.device('cuda', torch.cuda.current_device())
+        device = usum.device if with_boot else torch.device('cuda', torch.cuda.current_device())
     else:                                   # gloo (CPU tests / single-GPU dry runs)
         device = torch.device('cpu')
-        if with_boot:
-            usum, usq = usum.to(device), usq.to(device)
-    # the permutation block may carry extra rows (split-half nulls ride along)
-    Lp = local_perm.shape[0] if local_perm is not None else 0
-    L = local_dist.shape[1] if local_dist is not None else (usum.shape[1] if with_boot else 0)
-    Tp = local_dist.shape[0] if local_dist is not None else 0
-    B = usum.shape[0] if with_boot else 0
-    pmax, rmax, sizes = _flat_layout(Lp, Tp, L, B, n_perm if local_perm is not None else 0,
-                                     n_boot if local_dist is not None else 0, world, with_boot)
-    total = sum(sizes.values())
-    flat = torch.zeros(total, dtype=torch.float64, device=device)
-    off = 0
-    if sizes['perm']:
-        blk = np.zeros((Lp, pmax))
-        blk[:, :local_perm.shape[1]] = local_perm
-        flat[off:off + sizes['perm']] = torch.from_numpy(blk.ravel()).to(device)
-    off += sizes['perm']
-    if sizes['dist']:
-        blk = np.zeros((Tp, L, rmax))
-        blk[:, :, :local_dist.shape[2]] = local_dist
-        flat[off:off + sizes['dist']] = torch.from_numpy(blk.ravel()).to(device)
-    off += sizes['dist']
-    if with_boot:
-        flat[off:off + sizes['usum']] = usum.reshape(-1)
-        off += sizes['usum']
-        flat[off:off + sizes['usq']] = usq.reshape(-1)
-    gathered = torch.empty((world, total), dtype=torch.float64, device=device)
-    d.all_gather_into_tensor(gathered.view(-1), flat)
-
+    slices = []
+    if local_perm is not None:
+        pmax = shard_bounds(n_perm, 0, world)[1]
+        slices.append((torch.from_numpy(np.ascontiguousarray(local_perm.T)).to(device), pmax))
+    if local_dist is not None:
+        rmax = shard_bounds(n_boot, 0, world)[1]
+        slices.append((torch.from_numpy(np.ascontiguousarray(np.moveaxis(local_dist, -1, 0))).to(device), rmax))
+    sums = [usum, usq] if with_boot else []
+    got, summed = gather_device(slices, sums, device)
     perm = dist_out = None
-    off = 0
-    if sizes['perm']:
-        host = gathered[:, off:off + sizes['perm']].cpu().numpy().reshape(world, Lp, pmax)
-        perm = np.concatenate([host[r][:, :np.diff(shard_bounds(n_perm, r, world))[0]]
+    k = 0
+    if local_perm is not None:
+        host = got[k].cpu().numpy()                                     # (world, pmax, L)
+        k += 1
+        perm = np.concatenate([host[r][:np.diff(shard_bounds(n_perm, r, world))[0]].T
                                for r in range(world)], axis=1)
-    off += sizes['perm']
-    if sizes['dist']:
-        host = gathered[:, off:off + sizes['dist']].cpu().numpy().reshape(world, Tp, L, rmax)
-        dist_out = np.concatenate([host[r][:, :, :np.diff(shard_bounds(n_boot, r, world))[0]]
+    if local_dist is not None:
+        host = got[k].cpu().numpy()                                     # (world, rmax, T', L)
+        dist_out = np.concatenate([np.moveaxis(host[r][:np.diff(shard_bounds(n_boot, r, world))[0]], 0, -1)
                                    for r in range(world)], axis=2)
-    off += sizes['dist']
     if with_boot:
-        parts = gathered[:, off:off + sizes['usum']].reshape(world, B, L)
-        qarts = gathered[:, off + sizes['usum']:off + 2 * sizes['usum']].reshape(world, B, L)
-        usum, usq = parts[0].clone(), qarts[0].clone()
-        for r in range(1, world):                      # fixed rank order
-            usum += parts[r]
-            usq += qarts[r]
-        if home is not None and usum.device != home:
-            usum, usq = usum.to(home), usq.to(home)
+        usum, usq = summed
     return perm, dist_out, usum, usq

@@ -241,19 +241,15 @@ class _PLSCRun(object):
             if splits is None:
                 splits = resampling.gen_splits(inp.groups, inp.n_cond, inp.test_split, seed=self.rs,
                                                test_size=inp.test_size)
-            if inp.get('covariance'):
-                warnings.warn('cross-validation with covariance=True is not supported by the '
-                              'device path; cvres is left empty.')
+            lo, hi = parallel.shard_bounds(splits.shape[1], rank, world)
+            if hi > lo:
+                r, r2 = eng.crossval(splits[:, lo:hi])
+                local_cv = np.vstack([r, r2])
             else:
-                lo, hi = parallel.shard_bounds(splits.shape[1], rank, world)
-                if hi > lo:
-                    r, r2 = eng.crossval(splits[:, lo:hi])
-                    local_cv = np.vstack([r, r2])
-                else:
-                    local_cv = np.zeros((2 * Y.shape[1], 0))
-                cv, _, _, _ = parallel.collect(local_cv, splits.shape[1], None, 0, None, None)
-                Tn = Y.shape[1]
-                res['cvres'].update(dict(pearson_r=cv[:Tn], r_squared=cv[Tn:]))
+                local_cv = np.zeros((2 * Y.shape[1], 0))
+            cv, _, _, _ = parallel.collect(local_cv, splits.shape[1], None, 0, None, None)
+            Tn = Y.shape[1]
+            res['cvres'].update(dict(pearson_r=cv[:Tn], r_squared=cv[Tn:]))
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv

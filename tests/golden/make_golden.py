@@ -278,6 +278,17 @@ def main_cv():
              n_perm=5, n_boot=5, test_split=6, test_size=0.3, seed=77)
 
 
+def main_cv_cov():
+    """Cross-validation in covariance mode: the decomposition uses centred data
+    only (compute.py:86-87) while rescale_test still z-maps the test rows with the
+    training mean / std (compute.py:148), behavioral.py:126-170."""
+    rs = np.random.RandomState(515151)
+    Xs = rs.randn(56, 120) * (1.0 + rs.rand(1, 120))
+    Ys = rs.randn(56, 3) * np.array([1.0, 2.5, 0.4]) + 0.8 * Xs[:, :3]
+    run_plsc('bpls_cv_cov', pyls.behavioral_pls, Xs, Ys, groups=[12, 16], n_cond=2, n_perm=5,
+             n_boot=5, covariance=True, test_split=6, test_size=0.25, seed=31)
+
+
 def main_reg_extra():
     """pls_regression with 3-D Y (aggfunc) and with all-NaN rows
     (pyls/tests/types/test_regression.py:69-90)."""
@@ -330,7 +341,10 @@ if __name__ == '__main__':
         main_cv()
     elif len(sys.argv) > 1 and sys.argv[1] == 'reg':
         main_reg_extra()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cvcov':
+        main_cv_cov()
     else:
         main()
         main_cv()
         main_reg_extra()
+        main_cv_cov()

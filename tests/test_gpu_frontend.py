@@ -124,7 +124,7 @@ def test_behavioral_vs_reference_and_oracle(name):
     _compare_split(res, _oracle(g, 'behavioral'), keep)
     _compare_split(res, _ref_as_dict(g), keep)
     if 'cv_splits' in g:
-        spec = ref.Spec('behavioral', list(g['groups']), int(g['n_cond']))
+        spec = ref.Spec('behavioral', list(g['groups']), int(g['n_cond']), bool(g.get('covariance', False)))
         r, r2 = ref.crossval(spec, g['X'], g['Y'], g['cv_splits'])
         for got, want_o, want_r, what in ((res['cvres']['pearson_r'], r, g['ref_cvres__pearson_r'], 'pearson_r'),
                                           (res['cvres']['r_squared'], r2, g['ref_cvres__r_squared'], 'r_squared')):

@@ -104,11 +104,11 @@ def test_meancentered_vs_reference(name):
     _check(g, _run(g, 'meancentered'))
 
 
-@pytest.mark.parametrize('name', ['bpls_cv', 'bpls_2g2c_cv'])
+@pytest.mark.parametrize('name', ['bpls_cv', 'bpls_2g2c_cv', 'bpls_cv_cov'])
 def test_crossval_vs_reference(name):
     """BehavioralPLS.crossval / compute.rescale_test restatement."""
     g = load_golden(name)
-    spec = ref.Spec('behavioral', list(g['groups']), int(g['n_cond']))
+    spec = ref.Spec('behavioral', list(g['groups']), int(g['n_cond']), bool(g.get('covariance', False)))
     r, r2 = ref.crossval(spec, g['X'], g['Y'], g['cv_splits'])
     assert_close(r, g['ref_cvres__pearson_r'], 1e-9, what='pearson_r')
     assert_close(r2, g['ref_cvres__r_squared'], 1e-9, what='r_squared')

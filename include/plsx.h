@@ -52,8 +52,9 @@ enum plsx_method {
 /* Library / ABI version (major*1000 + minor). */
 int plsx_version(void);
 
-/* Largest stacked-Y dimension T' = J*T (behavioral) or J (mean-centred) the
- * on-chip Jacobi solver handles. */
+/* Largest stacked-Y dimension T' = J*T of behavioral PLS (rows of one resample;
+ * above 352 they are sliced over several cross-product blocks).  Mean-centred
+ * PLS (T' = J cells) and SIMPLS (T' = n_components) are limited to 352. */
 int plsx_max_tprime(void);
 
 /* Create / destroy the per-GPU context (streams, scratch).               */

@@ -35,8 +35,12 @@ struct plsx_ctx {
     int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, momrows = 0, Gcap = 0, Galloc = 0;
     int nks_t = 0, LT = 0;
     size_t group_stride = 0;
+    // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
+    int gps = 0;
+    Buf row_slice, row_local, slice_cell0, cell_momrow;
+    std::vector<int> h_slice_row0, h_slice_rows, h_slice_cell0, h_slice_ncell;
     // fixed-X fast path (behavioral permutations): pre-scaled features, no moment tiles
-    int fix = 0, MTf = 25, npgf = 0;
+    int fix = 0, has_Xn = 0, MTf = 25, npgf = 0;
     size_t group_stride_f = 0;
     long long strideR = 0;
     std::vector<int> h_cell_start, h_cell_len;
@@ -52,6 +56,7 @@ struct plsx_ctx {
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
     int dual = 0, dual_ok = 0;
+    int tune = 0;                                       // PLSX_TUNE (measurement switches)
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
     bool has_okx = false, has_oky = false;
@@ -163,21 +168,51 @@ struct KTimer {
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
-// Choose resamples per group so that data + moment tiles fill MT tiles.
-void plan_groups(plsx_ctx* c)
+// Physical cross-product groups of `rgroups` resample groups.
+int phys_groups(const plsx_ctx* c, int rgroups) { return c->gps > 0 ? rgroups * c->gps : rgroups; }
+
+// Choose resamples per group so that data + moment tiles fill MT tiles; when one
+// resample does not fit a block, cut its rows into slices (one group each).
+int plan_groups(plsx_ctx* c)
 {
     c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;   // mean-centred / regression: no feature scaling
     c->momrows = (c->method == PLSX_BEHAVIORAL) ? 1 : 0;
     const int Jw = c->momrows ? c->J : 0;
-    int best = 1;
+    c->gps = 0;
+    c->h_slice_row0.clear(); c->h_slice_rows.clear(); c->h_slice_cell0.clear(); c->h_slice_ncell.clear();
+    int best = 0;
     for (int n = 1; n <= 512; ++n) {
         int td = ceil_div(n * c->Tp, 16), tw = Jw ? ceil_div(n * Jw, 16) : 0;
         if (td + 2 * tw <= c->MT && tw * 16 <= 48) best = n; else break;
     }
+    int tw = Jw ? ceil_div(std::max(best, 1) * Jw, 16) : 0;
+    if (best == 0) {
+        // sliced: greedy row ranges [a, b) with their cells' moment rows
+        const int Tc = (c->method == PLSX_BEHAVIORAL) ? c->T : 1;      // rows per cell
+        int a = 0, twmax = 0;
+        while (a < c->Tp) {
+            int bsel = -1, twsel = 0;
+            for (int dt = c->MT; dt >= 1 && bsel < 0; --dt) {
+                const int b = std::min(c->Tp, a + dt * 16);
+                const int nc = Jw ? ((b - 1) / Tc - a / Tc + 1) : 0;
+                const int t2 = ceil_div(nc, 16);
+                if (ceil_div(b - a, 16) + 2 * t2 <= c->MT && t2 <= 3) { bsel = b; twsel = t2; }
+            }
+            if (bsel < 0) return -1;
+            c->h_slice_row0.push_back(a);
+            c->h_slice_rows.push_back(bsel - a);
+            c->h_slice_cell0.push_back(Jw ? a / Tc : 0);
+            c->h_slice_ncell.push_back(Jw ? ((bsel - 1) / Tc - a / Tc + 1) : 0);
+            twmax = std::max(twmax, twsel);
+            a = bsel;
+        }
+        c->gps = (int)c->h_slice_row0.size();
+        best = 1;
+        tw = twmax;
+    }
     c->npg = best;
     // tile order inside a group: data tiles, (unused tiles,) first-moment
     // (weight) tiles, second-moment tiles LAST (the kernel's static split)
-    const int tw = Jw ? ceil_div(best * Jw, 16) : 0;
     c->sq0 = c->MT - tw;
     c->w0 = c->sq0 - tw;
     c->nmom_pad = tw * 16;
@@ -192,22 +227,49 @@ void plan_groups(plsx_ctx* c)
     const double budget = c->scratch_gb * 1073741824.0;
     while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);
     c->Gcap = g;
+    return 0;
 }
 
 int upload_rowmaps(plsx_ctx* ctx)
 {
-    const int rows = ctx->MT * 16;
-    std::vector<int> out_row(rows, -1), mom_idx(rows, -1);
-    for (int rr = 0; rr < ctx->npg; ++rr)
-        for (int t = 0; t < ctx->Tp; ++t) {
-            int row = rr * ctx->Tp + t;
-            out_row[row] = rr * ctx->Tpp + t;
-            if (ctx->scaled) mom_idx[row] = rr * ctx->J + t / ctx->T;
-        }
-    if (ensure(ctx, ctx->out_row, rows * sizeof(int))) return PLSX_ERR_HIP;
-    if (ensure(ctx, ctx->mom_idx, rows * sizeof(int))) return PLSX_ERR_HIP;
-    HIPCHK(hipMemcpy(ctx->out_row.p, out_row.data(), rows * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->mom_idx.p, mom_idx.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    const int rows = ctx->MT * 16, ntab = std::max(ctx->gps, 1);
+    std::vector<int> out_row((size_t)ntab * rows, -1), mom_idx((size_t)ntab * rows, -1);
+    if (ctx->gps > 0) {
+        const int Tc = (ctx->method == PLSX_BEHAVIORAL) ? ctx->T : 1;
+        std::vector<int> row_slice(ctx->Tp), row_local(ctx->Tp), cell_momrow(std::max(ctx->J, 1), 0);
+        for (int sl = 0; sl < ctx->gps; ++sl)
+            for (int k = 0; k < ctx->h_slice_rows[sl]; ++k) {
+                const int grow = ctx->h_slice_row0[sl] + k;
+                row_slice[grow] = sl;
+                row_local[grow] = k;
+                out_row[(size_t)sl * rows + k] = grow;
+                if (ctx->scaled) mom_idx[(size_t)sl * rows + k] = grow / Tc - ctx->h_slice_cell0[sl];
+            }
+        if (ctx->momrows)
+            for (int j = 0; j < ctx->J; ++j) {
+                const int s0 = row_slice[j * Tc];
+                cell_momrow[j] = s0 * ctx->nmom_pad + (j - ctx->h_slice_cell0[s0]);
+            }
+        if (ensure(ctx, ctx->row_slice, ctx->Tp * sizeof(int))) return PLSX_ERR_HIP;
+        if (ensure(ctx, ctx->row_local, ctx->Tp * sizeof(int))) return PLSX_ERR_HIP;
+        if (ensure(ctx, ctx->slice_cell0, ctx->gps * sizeof(int))) return PLSX_ERR_HIP;
+        HIPCHK(hipMemcpy(ctx->row_slice.p, row_slice.data(), ctx->Tp * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->row_local.p, row_local.data(), ctx->Tp * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->slice_cell0.p, ctx->h_slice_cell0.data(), ctx->gps * sizeof(int), hipMemcpyHostToDevice));
+        if (ensure(ctx, ctx->cell_momrow, cell_momrow.size() * sizeof(int))) return PLSX_ERR_HIP;
+        HIPCHK(hipMemcpy(ctx->cell_momrow.p, cell_momrow.data(), cell_momrow.size() * sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        for (int rr = 0; rr < ctx->npg; ++rr)
+            for (int t = 0; t < ctx->Tp; ++t) {
+                int row = rr * ctx->Tp + t;
+                out_row[row] = rr * ctx->Tpp + t;
+                if (ctx->scaled) mom_idx[row] = rr * ctx->J + t / ctx->T;
+            }
+    }
+    if (ensure(ctx, ctx->out_row, out_row.size() * sizeof(int))) return PLSX_ERR_HIP;
+    if (ensure(ctx, ctx->mom_idx, mom_idx.size() * sizeof(int))) return PLSX_ERR_HIP;
+    HIPCHK(hipMemcpy(ctx->out_row.p, out_row.data(), out_row.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->mom_idx.p, mom_idx.data(), mom_idx.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -219,10 +281,11 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
     // resamples held at once: the fixed-X path packs more resamples per group
     const size_t nb = (size_t)groups * std::max(ctx->npg, ctx->npgf);
     const size_t astride = std::max(ctx->group_stride, ctx->group_stride_f);
-    if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * astride * 8 + 4096)) return e;
+    const size_t pg = (size_t)phys_groups(ctx, groups);
+    if (int e = ensure(ctx, ctx->Afrag, pg * astride * 8 + 4096)) return e;
     // R: rows t >= Tp of every resample stay zero forever (memset on alloc)
     if (int e = ensure(ctx, ctx->R, nb * ctx->Tpp * (size_t)ctx->Bpad * 8, true)) return e;
-    if (int e = ensure(ctx, ctx->mom_n, (size_t)groups * std::max(ctx->nmom_pad, 16) * 8, true)) return e;
+    if (int e = ensure(ctx, ctx->mom_n, pg * std::max(ctx->nmom_pad, 16) * 8, true)) return e;
     if (int e = ensure(ctx, ctx->Gm, nb * ctx->Tp * ctx->Tp * 8)) return e;
     if (int e = ensure(ctx, ctx->Pm, nb * ctx->Tp * ctx->L * 8)) return e;
     if (int e = ensure(ctx, ctx->Mfrag, nb * ctx->nks_t * ctx->LT * 64 * 8 + 1024)) return e;   // + one DMA piece of slack
@@ -273,11 +336,13 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
-                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg, SplitEpi{});
+                       std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg,
+                       SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, ctx->tune}, std::max(ctx->gps, 1));
     LAUNCHCHK();
     return 0;
 }
 
+// `groups` = physical groups (phys_groups of the resample groups)
 int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 {
     switch (ctx->MT - ctx->sq0) {          // number of second-moment tiles (0..3)
@@ -319,7 +384,7 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
                        ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->Xn), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npgf * ctx->Tpp,
                        ptr<int>(ctx->out_row_f), ptr<int>(ctx->mom_idx_f), ptr<double>(ctx->mom_n), 0,
-                       groups, ncolblk, (double*)nullptr, SplitEpi{});
+                       groups, ncolblk, (double*)nullptr, SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, ctx->tune}, 1);
     LAUNCHCHK();
     return 0;
 }
@@ -333,11 +398,16 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
     if (ctx->timing) ctx->timed_units += nres;
-    if (prebuilt) return launch_xprod(ctx, groups, st);       // A already scattered by the caller
-    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
+    const int pgroups = phys_groups(ctx, groups);
+    if (prebuilt) return launch_xprod(ctx, pgroups, st);       // A already scattered by the caller
+    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)pgroups * ctx->group_stride * 8, st));
     GroupLayout lay;
     lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT;
     lay.w0 = ctx->w0; lay.sq0 = ctx->sq0; lay.Tpp = ctx->Tpp;
+    if (ctx->gps > 0) {
+        lay.gps = ctx->gps; lay.row_slice = ptr<int>(ctx->row_slice); lay.row_local = ptr<int>(ctx->row_local);
+        lay.slice_cell0 = ptr<int>(ctx->slice_cell0);
+    }
     if (ctx->method == PLSX_REGRESSION) {
         // A (dual weights) was scattered by k_simpls_dual; nothing to build here
     } else if (ctx->method == PLSX_BEHAVIORAL) {
@@ -355,7 +425,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
                            ctx->group_stride);
     }
     LAUNCHCHK();
-    return launch_xprod(ctx, groups, st);
+    return launch_xprod(ctx, pgroups, st);
 }
 
 // Resident blocks of `kernel` (256-thread blocks) on the whole chip.
@@ -742,6 +812,7 @@ int plsx_ctx_create(int device, plsx_ctx** out)
     plsx_ctx* c = new (std::nothrow) plsx_ctx();
     if (!c) return PLSX_ERR_HIP;
     c->device = device;
+    if (const char* env = getenv("PLSX_TUNE")) c->tune = atoi(env);
     if (const char* env = getenv("PLSX_SCRATCH_GB")) {
         if (atof(env) > 0.0) { c->scratch_gb = atof(env); c->scratch_fixed = 1; }
     }
@@ -760,7 +831,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -809,10 +880,10 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
                     "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
     if ((long long)B + Tp > 2000000LL)
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
-    if (Tp > PLSX_MAX_TP) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "stacked dimension T' = %d exceeds the limit %d (one resample per 24-tile block)", Tp,
-                 PLSX_MAX_TP);
+    if (Tp > PLSX_MAX_TP || J > PLSX_MAX_CELLS || (method != PLSX_BEHAVIORAL && Tp > PLSX_BLOCK_TP)) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "stacked dimension T' = %d (cells J = %d) exceeds the limit (T' <= %d for "
+                 "behavioral PLS, %d otherwise; J <= %d)", Tp, J, PLSX_MAX_TP, PLSX_BLOCK_TP, PLSX_MAX_CELLS);
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
     ctx->has_data = ctx->has_orig = false;
@@ -868,27 +939,23 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         if (int e = ensure(ctx, ctx->Y, (size_t)S * T * 8)) return e;
         HIPCHK(hipMemcpyAsync(ctx->Y.p, d_Y, (size_t)S * T * 8, hipMemcpyDeviceToDevice, st));
     }
-    plan_groups(ctx);
-    {
-        // one resample (data rows + its moment rows) must fit the 24 tiles of a block
-        const int tw1 = ctx->momrows ? ceil_div(J, 16) : 0;
-        if (ceil_div(Tp, 16) + 2 * tw1 > ctx->MT || tw1 * 16 > 48)
-            return fail(ctx, PLSX_ERR_UNSUPPORTED,
-                        "stacked dimension T' (plus its per-cell moment rows) exceeds the 384 rows of a block");
-    }
+    if (plan_groups(ctx) != 0)
+        return fail(ctx, PLSX_ERR_UNSUPPORTED,
+                    "cannot lay out the rows of a resample (with their per-cell moment rows) over cross-product blocks");
     if (int e = upload_rowmaps(ctx)) return e;
-    ctx->fix = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
+    ctx->fix = 0; ctx->has_Xn = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
     {
         const char* nf = getenv("PLSX_NO_FIXED_X");
         if (method == PLSX_BEHAVIORAL && !ctx->cov && !(nf && atoi(nf))) {
             // fixed-X fast path for permutations
-            ctx->npgf = (ctx->MTf * 16) / ctx->Tp;
-            if (ctx->npgf >= 1) {
+            ctx->npgf = ctx->gps > 0 ? 0 : (ctx->MTf * 16) / ctx->Tp;
+            {
                 ctx->group_stride_f = (size_t)ctx->nks * ctx->MTf * 64;
                 const int rows = ctx->MTf * 16;
                 std::vector<int> orow(rows, -1), none(rows, -1);
                 for (int rr = 0; rr < ctx->npgf; ++rr)
                     for (int t = 0; t < ctx->Tp; ++t) orow[rr * ctx->Tp + t] = rr * ctx->Tpp + t;
+                if (ctx->npgf < 1) ctx->group_stride_f = 0;      // no fixed-X kernel: Xn only feeds the dual path
                 if (int e = ensure(ctx, ctx->out_row_f, rows * sizeof(int))) return e;
                 if (int e = ensure(ctx, ctx->mom_idx_f, rows * sizeof(int))) return e;
                 HIPCHK(hipMemcpy(ctx->out_row_f.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
@@ -899,14 +966,15 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
                                    ctx->Bpad, B, J, ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len),
                                    ptr<double>(ctx->Xn));
                 LAUNCHCHK();
-                ctx->fix = 1;
+                ctx->has_Xn = 1;
+                ctx->fix = ctx->npgf >= 1 ? 1 : 0;
             }
         }
     }
     {
         // dual permutation path: needs a resample-independent feature matrix
         const char* nd = getenv("PLSX_NO_DUAL_PERM");
-        ctx->dual_ok = (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->fix || ctx->cov))) ? 1 : 0;
+        ctx->dual_ok = (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->has_Xn || ctx->cov))) ? 1 : 0;
         ctx->dual = (ctx->dual_ok && !(nd && atoi(nd))) ? 1 : 0;
     }
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
@@ -1046,7 +1114,7 @@ int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, 
 {
     const int S = ctx->S, Tp = ctx->Tp, Sd = round_up(S, 8);
     if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
-    const double* Xf = ctx->fix ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
+    const double* Xf = ctx->has_Xn ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
     if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
                        ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
         return e;
@@ -1167,7 +1235,7 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_
                        st, ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
                        ptr<double>(ctx->R), ctx->Bpad, ctx->npg * 2 * ctx->Tpp, ptr<int>(ctx->out_row_s),
                        ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 0), groups,
-                       ncolblk, (double*)nullptr, se);
+                       ncolblk, (double*)nullptr, se, 1);
     LAUNCHCHK();
     return 0;
 }
@@ -1209,7 +1277,7 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
     se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
     se.cell_len = ptr<int>(ctx->cell_len);
     se.rowc = ptr<double>(ctx->rowc);
-    se.J = J; se.Tpp = ctx->Tpp;
+    se.J = J; se.Tpp = ctx->Tpp; se.tune = ctx->tune;
     switch (ctx->MT - ctx->sq0) {
         case 1: return launch_xprod_split<1>(ctx, groups, se, st);
         case 2: return launch_xprod_split<2>(ctx, groups, se, st);
@@ -1247,7 +1315,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     if (int e = ensure(ctx, ctx->Mvd, (size_t)pcmax * mstride * 8 + 1024)) return e;
     const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
     // behavioral correlation mode: only the first half of a split takes the MFMA pass
-    const bool fused = ctx->scaled && !permute_x && ctx->Gcap >= 2 && !getenv("PLSX_NO_SPLIT_FUSE");
+    const bool fused = ctx->scaled && !permute_x && ctx->gps == 0 && ctx->Gcap >= 2 && !getenv("PLSX_NO_SPLIT_FUSE");
     // splits per pass (the fused path writes two R slots per split from groups of npg splits)
     const int spp = fused ? std::max(1, std::min(nb / 2, (ctx->Gcap / 2) * ctx->npg)) : nb / 2;
     for (int p0 = 0; p0 < np; p0 += pcmax) {
@@ -1296,7 +1364,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
                 dim3 grid(nchunk, m), block(256);
                 if (int e = launch_ucorr(ctx, grid, block, st, Mvd, tpc, ptr<double>(ctx->part2), m)) return e;
                 LAUNCHCHK();
-                hipLaunchKernelGGL(k_split_final, dim3(m), dim3(256), (size_t)4 * round_up(L, 64) * 5 * 8, st,
+                hipLaunchKernelGGL(k_split_final, dim3(m), dim3(256), (size_t)4 * 256 * 5 * 8, st,
                                    ptr<double>(ctx->part2), nchunk, m,
                                    lpad, ptr<double>(ctx->Cm), Vp, dp, Tp, L, ctx->B,
                                    d_ucorr + ((size_t)p * ns + off) * L, d_vcorr + ((size_t)p * ns + off) * L);
@@ -1327,7 +1395,7 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
         if (int e = ensure(ctx, ctx->srcx, (size_t)mm * S * sizeof(int))) return e;
         hipLaunchKernelGGL(k_cv_src, dim3(ceil_div(S, 256), mm), dim3(256), 0, st, mk, S, ptr<int>(ctx->srcx));
         LAUNCHCHK();
-        if (int e = ensure(ctx, ctx->momout, (size_t)groups * ctx->nmom_pad * 2 * ctx->Bpad * 8)) return e;
+        if (int e = ensure(ctx, ctx->momout, (size_t)phys_groups(ctx, groups) * ctx->nmom_pad * 2 * ctx->Bpad * 8)) return e;
         ctx->mom_out_arg = ptr<double>(ctx->momout);
         int e = run_xprod(ctx, ptr<int>(ctx->srcx), nullptr, mm, st);
         ctx->mom_out_arg = nullptr;
@@ -1344,7 +1412,7 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
         if (int e2 = ensure(ctx, ctx->cvc, (size_t)mm * J * Tp * 8)) return e2;
         hipLaunchKernelGGL(k_cv_rescale, dim3(Tp, mm * J), dim3(256), 0, st, ptr<double>(ctx->R), ctx->strideR,
                            ctx->Bpad, ctx->B, J, ctx->npg, ctx->nmom_pad, ptr<double>(ctx->momout),
-                           ptr<double>(ctx->R2), ptr<double>(ctx->cvc), Tp);
+                           ptr<double>(ctx->R2), ptr<double>(ctx->cvc), Tp, ctx->gps, ptr<int>(ctx->cell_momrow));
         LAUNCHCHK();
         if (int e2 = ensure(ctx, ctx->Qm, (size_t)mm * J * Tp * S * 8)) return e2;
         if (int e2 = run_nt(ctx, ptr<double>(ctx->R2), ctx->strideR, ctx->Bpad, Tp, ptr<double>(ctx->Xc), 0,

@@ -30,7 +30,9 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-#define PLSX_MAX_TP 352         // largest stacked dimension T' (22 data tiles of one resample per block)
+#define PLSX_MAX_TP 1280        // largest stacked dimension T' (rows of one resample; sliced over blocks above 352)
+#define PLSX_BLOCK_TP 352       // largest T' whose rows fit ONE cross-product block (22 data tiles + moments)
+#define PLSX_MAX_CELLS 352      // largest number of group x condition cells
 #define PLSX_LDS_TP 96          // largest T' whose small solver runs out of LDS (global workspace above)
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
@@ -105,6 +107,13 @@ struct GroupLayout {
     int w0;       // first weight tile (first-moment rows), == sq0 when unscaled
     int sq0;      // first second-moment tile, == total tiles when unscaled
     int Tpp;      // T' rounded up to 4 (row pitch of R per resample)
+    // Sliced layout (T' > PLSX_BLOCK_TP): the rows of ONE resample are cut into gps
+    // slices, one cross-product group (block row range) each; every slice carries the
+    // moment rows of the cells it touches.  gps == 0: plain layout (n resamples / group).
+    int gps = 0;
+    const int* row_slice = nullptr;    // [T'] slice of resample row
+    const int* row_local = nullptr;    // [T'] row inside its slice's group
+    const int* slice_cell0 = nullptr;  // [gps] first cell a slice touches
 };
 
 // Behavioral PLS: build the A operand of resample r, cell j.
@@ -168,6 +177,7 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
     double* A = Afrag + (size_t)g * group_stride;
     const double inv_nm1 = 1.0 / (double)(cnt - 1);
     const int total = len * T;
+    const bool sliced = lay.gps > 0 && !dense_ld;
     for (int idx = tid; idx < total; idx += blockDim.x) {
         int pl = idx / T, t = idx - pl * T;
         int p = start + pl;
@@ -177,9 +187,29 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
         double v = (Y[(size_t)yi * T + t] - mean[t]) * rstd[t] * inv_nm1;
         int row = rr * lay.Tp + j * T + t;
         if (dense_ld) atomicAdd(Afrag + ((size_t)r * lay.Tp + j * T + t) * dense_ld + xi, v);
-        else atomicAdd(A + afrag_off(row, xi, lay.MT), v);
+        else if (sliced) {
+            const int grow = j * T + t;
+            atomicAdd(Afrag + ((size_t)r * lay.gps + lay.row_slice[grow]) * group_stride +
+                      afrag_off(lay.row_local[grow], xi, lay.MT), v);
+        } else atomicAdd(A + afrag_off(row, xi, lay.MT), v);
     }
-    if (scaled) {
+    if (scaled && sliced) {
+        // every slice that holds rows of cell j carries the cell's moment rows
+        const int sa = lay.row_slice[j * T], sb = lay.row_slice[j * T + T - 1];
+        for (int sl = sa; sl <= sb; ++sl) {
+            const size_t gg = (size_t)r * lay.gps + sl;
+            double* As = Afrag + gg * group_stride;
+            const int mrow = j - lay.slice_cell0[sl];
+            for (int pl = tid; pl < len; pl += blockDim.x) {
+                int p = start + pl;
+                int xi = xs ? xs[p] : p;
+                if (xi < 0) continue;
+                atomicAdd(As + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), 1.0);
+                atomicAdd(As + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), 1.0);
+            }
+            if (tid == 0) mom_n[gg * nmom_pad + mrow] = (double)cnt;
+        }
+    } else if (scaled) {
         for (int pl = tid; pl < len; pl += blockDim.x) {
             int p = start + pl;
             int xi = xs ? xs[p] : p;
@@ -200,7 +230,7 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
                              const int* __restrict__ xsrc, GroupLayout lay,
                              double* __restrict__ Afrag, size_t group_stride, int dense_ld = 0)
 {
-    __shared__ int cnt[PLSX_MAX_TP];
+    __shared__ int cnt[PLSX_MAX_CELLS];
     const int r = blockIdx.x;
     const int g = r / lay.n, rr = r % lay.n;
     const int* xs = xsrc ? xsrc + (size_t)r * S : nullptr;
@@ -273,6 +303,7 @@ struct SplitEpi {
     const int* cell_len;     // [J]
     const double* rowc;      // [groups][MT*16][5]: Sy1, 1/((n1-1) sy1), Sy2, 1/((n2-1) sy2), (nF-1) syF
     int J, Tpp;
+    int tune;                // PLSX_TUNE measurement switches (0 in production)
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
@@ -420,8 +451,10 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              double* __restrict__ R, int ldr, int rows_per_group,
              const int* __restrict__ out_row, const int* __restrict__ mom_idx,
              const double* __restrict__ mom_n, int nmom_pad,
-             int n_groups, int ncolblk, double* __restrict__ mom_out, SplitEpi se)
+             int n_groups, int ncolblk, double* __restrict__ mom_out, SplitEpi se, int ntab)
 {
+    // ntab > 1 (sliced layout): group g holds slice g % ntab of resample g / ntab; every
+    // slice has its own row tables, all slices of a resample write into its R block.
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = NW * 64;                      // threads
     constexpr int STAGE = KT * MT * 64;              // doubles per stage (global pitch)
@@ -461,6 +494,10 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nkt = nks / KT;
+    if ((se.tune & 4) && blockIdx.x < 512) {          // measurement: de-phase the first round of blocks
+        const int n = (blockIdx.x * 37 % 64) * (se.tune >> 8);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // prologue: stage 0 of A, first X fragments
     stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
     double xb[KT];
@@ -511,7 +548,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         int* s_out = reinterpret_cast<int*>(smem + NW * 5 * NMOM * 16);
         int* s_mom = s_out + MT * 16;
         double* s_rc = reinterpret_cast<double*>(s_mom + MT * 16);   // [MT*16][5]
-        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }    // (ntab == 1)
         for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
         // moments of the first half sit in the accumulators of tiles W0+j / SQ0+j
 #pragma unroll
@@ -551,10 +588,14 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const double* rc = s_rc + row * 5;
                 const int t = orow % pitch2;
                 const double c1 = acc[m][i];
-                const double cf = se.Rfull[(size_t)t * ldr + col] * rc[4] * w5[4 * NMOM * 16 + o];
-                Rg[(size_t)orow * ldr] = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * NMOM * 16 + o];
-                Rg[(size_t)(orow + se.Tpp) * ldr] =
-                    ((cf - c1) - rc[2] * w5[2 * NMOM * 16 + o]) * rc[3] * w5[3 * NMOM * 16 + o];
+                const double rf = (se.tune & 2) ? 1.0 : se.Rfull[(size_t)t * ldr + col];
+                const double cf = rf * rc[4] * w5[4 * NMOM * 16 + o];
+                const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * NMOM * 16 + o];
+                const double r2 = ((cf - c1) - rc[2] * w5[2 * NMOM * 16 + o]) * rc[3] * w5[3 * NMOM * 16 + o];
+                if (!(se.tune & 1) || r1 == 123.456) {
+                    Rg[(size_t)orow * ldr] = r1;
+                    Rg[(size_t)(orow + se.Tpp) * ldr] = r2;
+                }
             }
         return;
     }
@@ -562,7 +603,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     double* sQ = sS + NMOM * 16;                     // m2
     int* s_out = reinterpret_cast<int*>(smem + NW * 2 * NMOM * 16);   // row maps, shared
     int* s_mom = s_out + MT * 16;
-    for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+    const int tab = (ntab > 1) ? (grp % ntab) * (MT * 16) : 0;
+    for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[tab + i]; s_mom[i] = mom_idx[tab + i]; }
     if (NSQ > 0) {
 #pragma unroll
         for (int j = 0; j < NSQ; ++j)
@@ -589,7 +631,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         }
         __syncthreads();
     }
-    double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+    double* Rg = R + (size_t)(ntab > 1 ? grp / ntab : grp) * rows_per_group * ldr + col;
 #pragma unroll
     for (int m = 0; m < W0; ++m) {
         int orow[4];
@@ -603,7 +645,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (orow[i] >= 0) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
+            if (orow[i] >= 0 && (!(se.tune & 1) || acc[m][i] == 123.456)) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
     }
 }
 
@@ -1024,12 +1066,39 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
 // applied from the right; the same rotations are applied to V (mv x n).  Each
 // column pair is handled by an 8-lane group (dot products reduced with
 // wavefront shuffles); blockDim.x / 8 pairs per pass.
+// Largest squared column norm of A (m x n, pitch ld) -> every thread.  Pairs of
+// columns that are BOTH below 1e-13 of it in norm are numerically null (singular
+// values < 3e-7 of the largest, under the engine's rank tolerance PLSX_RANK_RTOL):
+// their mutual rotations would only shuffle rounding noise for many sweeps -- the
+// common case for rank-deficient designs (T' > S - J, mean-centred PLS) -- and are skipped.
+__device__ double jacobi_null2(const double* A, int m, int n, int ld, double* red /* >= 1 double of LDS */)
+{
+    if (threadIdx.x == 0) *red = 0.0;
+    __syncthreads();
+    double mx = 0.0;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) { const double x = A[(size_t)c * ld + i]; s += x * x; }
+        mx = fmax(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0 && mx > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long*>(red), (unsigned long long)__double_as_longlong(mx));
+    __syncthreads();
+    const double r = *red;
+    __syncthreads();
+    return 1e-26 * r;
+}
+
 __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag)
 {
     const int tid = threadIdx.x;
     const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
     const int np = (n + 1) >> 1, ne = np * 2;
     const double tol = 1e-15;
+    __shared__ double s_amax;
+    const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -1053,7 +1122,7 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
                     beta += __shfl_xor(beta, o);
                     gamma += __shfl_xor(gamma, o);
                 }
-                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
@@ -1092,6 +1161,8 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
     const int sub = tid % LANES, grp = tid / LANES, ngrp = blockDim.x / LANES;
     const int np = (n + 1) >> 1, ne = np * 2, mod = ne - 1;
     const double tol = 1e-15;
+    __shared__ double s_amax;
+    const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -1125,7 +1196,7 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
                     beta += __shfl_xor(beta, o);
                     gamma += __shfl_xor(gamma, o);
                 }
-                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta)) continue;
+                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
@@ -1166,7 +1237,9 @@ __device__ void jacobi_cols_big(double* A, int m, double* V, int mv, int n, int 
     else if (rows <= 152) jacobi_cols_big_t<19, 8>(A, m, V, mv, n, ld, flag);
     else if (rows <= 200) jacobi_cols_big_t<25, 8>(A, m, V, mv, n, ld, flag);
     else if (rows <= 256) jacobi_cols_big_t<16, 16>(A, m, V, mv, n, ld, flag);
-    else jacobi_cols_big_t<22, 16>(A, m, V, mv, n, ld, flag);   // <= 352 rows
+    else if (rows <= 352) jacobi_cols_big_t<22, 16>(A, m, V, mv, n, ld, flag);
+    else if (rows <= 704) jacobi_cols_big_t<22, 32>(A, m, V, mv, n, ld, flag);
+    else jacobi_cols_big_t<20, 64>(A, m, V, mv, n, ld, flag);   // <= 1280 rows
 }
 
 // Fragment-ordered M operand (T' x L) of k_urot / k_ucorr_partial: the 16-column
@@ -1724,48 +1797,52 @@ void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int 
                    int n, int L, int B, double* __restrict__ ucorr, double* __restrict__ vcorr)
 {
     // thread = (LV l, quarter q of the T' rows): partial sums of the five moments of
-    // F_h[:, l] in LDS, added in a fixed order (deterministic)
-    extern __shared__ double sm_sf[];            // [4][lpad64][5]
+    // F_h[:, l] in LDS, added in a fixed order (deterministic); L in chunks of 256
+    extern __shared__ double sm_sf[];            // [4][256][5]
+    constexpr int LC = 256;
     const int pair = blockIdx.x;
     const int lq = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int lp64 = (L + 63) / 64 * 64;
     const double* C1 = C + (size_t)(2 * pair) * n * n;
     const double* C2 = C1 + (size_t)n * n;
     const int t0 = (int)((long long)n * q / 4), t1 = (int)((long long)n * (q + 1) / 4);
-    for (int l = lq; l < L; l += 64) {
-        const double inv = 1.0 / (d[l] * d[l]);
-        double f1s = 0, f2s = 0, f11 = 0, f22 = 0, f12 = 0;
-        for (int t = t0; t < t1; ++t) {
-            double f1 = 0, f2 = 0;
-            for (int u = 0; u < n; ++u) {
-                const double vv = V[(size_t)u * L + l];
-                f1 += C1[(size_t)t * n + u] * vv;
-                f2 += C2[(size_t)t * n + u] * vv;
+    for (int l0 = 0; l0 < L; l0 += LC) {
+        const int l1 = min(L, l0 + LC);
+        __syncthreads();
+        for (int l = l0 + lq; l < l1; l += 64) {
+            const double inv = 1.0 / (d[l] * d[l]);
+            double f1s = 0, f2s = 0, f11 = 0, f22 = 0, f12 = 0;
+            for (int t = t0; t < t1; ++t) {
+                double f1 = 0, f2 = 0;
+                for (int u = 0; u < n; ++u) {
+                    const double vv = V[(size_t)u * L + l];
+                    f1 += C1[(size_t)t * n + u] * vv;
+                    f2 += C2[(size_t)t * n + u] * vv;
+                }
+                f1 *= inv; f2 *= inv;
+                f1s += f1; f2s += f2; f11 += f1 * f1; f22 += f2 * f2; f12 += f1 * f2;
             }
-            f1 *= inv; f2 *= inv;
-            f1s += f1; f2s += f2; f11 += f1 * f1; f22 += f2 * f2; f12 += f1 * f2;
+            double* o = sm_sf + ((size_t)q * LC + (l - l0)) * 5;
+            o[0] = f1s; o[1] = f2s; o[2] = f11; o[3] = f22; o[4] = f12;
         }
-        double* o = sm_sf + ((size_t)q * lp64 + l) * 5;
-        o[0] = f1s; o[1] = f2s; o[2] = f11; o[3] = f22; o[4] = f12;
-    }
-    __syncthreads();
-    for (int l = threadIdx.x; l < L; l += blockDim.x) {
-        double s[5] = {0, 0, 0, 0, 0};
-        for (int c = 0; c < nchunk; ++c)
-            for (int k = 0; k < 5; ++k) s[k] += part[(((size_t)c * npairs + pair) * 5 + k) * lpad + l];
-        const double nb = (double)B;
-        const double cov = s[4] - s[0] * s[1] / nb;
-        const double v1 = s[2] - s[0] * s[0] / nb, v2 = s[3] - s[1] * s[1] / nb;
-        double rr = cov / sqrt(v1 * v2);
-        ucorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);   // NaN stays NaN
-        double f[5] = {0, 0, 0, 0, 0};
-        for (int qq = 0; qq < 4; ++qq)
-            for (int k = 0; k < 5; ++k) f[k] += sm_sf[((size_t)qq * lp64 + l) * 5 + k];
-        const double nn = (double)n;
-        const double cv = f[4] - f[0] * f[1] / nn;
-        const double w1 = f[2] - f[0] * f[0] / nn, w2 = f[3] - f[1] * f[1] / nn;
-        rr = cv / sqrt(w1 * w2);
-        vcorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);
+        __syncthreads();
+        for (int l = l0 + threadIdx.x; l < l1; l += blockDim.x) {
+            double s[5] = {0, 0, 0, 0, 0};
+            for (int c = 0; c < nchunk; ++c)
+                for (int k = 0; k < 5; ++k) s[k] += part[(((size_t)c * npairs + pair) * 5 + k) * lpad + l];
+            const double nb = (double)B;
+            const double cov = s[4] - s[0] * s[1] / nb;
+            const double v1 = s[2] - s[0] * s[0] / nb, v2 = s[3] - s[1] * s[1] / nb;
+            double rr = cov / sqrt(v1 * v2);
+            ucorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);   // NaN stays NaN
+            double f[5] = {0, 0, 0, 0, 0};
+            for (int qq = 0; qq < 4; ++qq)
+                for (int k = 0; k < 5; ++k) f[k] += sm_sf[((size_t)qq * LC + (l - l0)) * 5 + k];
+            const double nn = (double)n;
+            const double cv = f[4] - f[0] * f[1] / nn;
+            const double w1 = f[2] - f[0] * f[0] / nn, w2 = f[3] - f[1] * f[1] / nn;
+            rr = cv / sqrt(w1 * w2);
+            vcorr[(size_t)pair * L + l] = (rr > 1.0) ? 1.0 : ((rr < -1.0) ? -1.0 : rr);
+        }
     }
 }
 
@@ -1787,13 +1864,18 @@ __global__ void k_cv_src(const uint8_t* __restrict__ masks, int S, int* __restri
 __global__ __launch_bounds__(256)
 void k_cv_rescale(const double* __restrict__ R, long long strideR, int ldr, int B, int J, int npg,
                   int nmom_pad, const double* __restrict__ mom_out,
-                  double* __restrict__ R2, double* __restrict__ cvec, int Tp)
+                  double* __restrict__ R2, double* __restrict__ cvec, int Tp, int gps,
+                  const int* __restrict__ cell_momrow)
 {
     __shared__ double red[4];
     const int t = blockIdx.x, slot = blockIdx.y;
     const int i = slot / J, j = slot % J;
     const int g = i / npg, rr = i % npg;
-    const double* mo = mom_out + ((size_t)g * nmom_pad + rr * J + j) * 2 * ldr;
+    // moment row of (split i, cell j): plain layout group g, row rr*J + j; sliced layout
+    // (gps > 0, one split per gps groups) the first slice that holds the cell
+    const size_t mrow = gps > 0 ? (size_t)i * gps * nmom_pad + cell_momrow[j]
+                                : (size_t)g * nmom_pad + rr * J + j;
+    const double* mo = mom_out + mrow * 2 * ldr;
     const double* src = R + (size_t)i * strideR + (size_t)t * ldr;
     double* dst = R2 + (size_t)slot * strideR + (size_t)t * ldr;
     double part = 0.0;

@@ -26,6 +26,13 @@ def _bind(eng, X, Y, groups, n_cond, **kw):
     (140, 600, 100, [140], 1),       # T' = 100 (the reference's own test width): global-workspace solver, LT = 7
     (200, 500, 30, [25, 25], 4),     # T' = 8 cells x 30 = 240: two chunks of L tiles, M operand from L2
     (400, 900, 352, [400], 1),       # T' = 352 = the block limit (22 data tiles + moments)
+    (420, 700, 353, [420], 1),       # T' = 353: first sliced layout (one cell cut into two row slices)
+    (100, 1000, 100, [25], 4),       # T' = 400, the reference's own test shape (pyls/tests/types/test_svd.py:87)
+    (100, 1000, 100, [25, 25], 2),   # T' = 400, two groups x two conditions (test_svd.py:95)
+    (120, 1300, 100, [10, 10, 10], 4),  # T' = 1200 = 3 groups x 4 conditions x 100 behaviours: 4 slices
+                                        # (B >= T': with L < T' the Procrustes result depends on WHICH
+                                        # null vectors the SVD returns, in the reference too)
+    (160, 520, 30, [10] * 8, 2),     # T' = 480 from 16 cells: slices share a cell, 12 + 5 moment rows
     (33, 17, 2, [33], 1),            # tiny, S not a multiple of 8, B < 128
     (603, 140, 3, [603], 1),         # S > 512
 ])
@@ -61,8 +68,8 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     from pypyls_amd import resampling as rsmp
     rs = np.random.RandomState(0)
     eng = _engine()
-    with pytest.raises(PlsxError):                       # T' = 353 > 352
-        eng.set_data(rs.randn(400, 50), rs.randn(400, 353), rsmp.cell_of_row([400], 1), 1, 1, 0)
+    with pytest.raises(PlsxError):                       # T' = 1281 > 1280
+        eng.set_data(rs.randn(400, 50), rs.randn(400, 1281), rsmp.cell_of_row([400], 1), 1, 1, 0)
     with pytest.raises(PlsxError):                       # perm before set_data / set_original
         _engine().perm(np.zeros((0, 1), int))
     X, Y = rs.randn(30, 40), rs.randn(30, 3)

@@ -181,6 +181,32 @@ def test_regression_errors():
         _reg(Y=rs.rand(RS, RT, 10), bootsamples=[[10], [10]])
 
 
+# ---- the reference's integration shapes at their real size -------------------------
+@pytest.mark.parametrize('groups,n_cond', [([100], 1), ([33, 34, 33], 1), ([25], 4), ([25, 25], 2)])
+@pytest.mark.parametrize('n_split', [None, 5])
+def test_behavioral_reference_shapes(groups, n_cond, n_split):
+    """pyls/tests/types/test_svd.py:7-9,62-96 verbatim: 100 subjects, 1000 features,
+    100 behaviours -> T' = 100 / 300 / 400 / 400 (the last two need the sliced
+    cross-product layout), n_perm 20, n_boot 10; attribute shapes as the reference
+    asserts them plus parity of the live LVs against the oracle."""
+    import pypyls_amd as pls
+    r2 = np.random.RandomState(1234)
+    Xr, Yr = r2.rand(100, 1000), r2.rand(100, 100)
+    res = pls.behavioral_pls(Xr, Yr, groups=groups, n_cond=n_cond, n_perm=20, n_boot=10,
+                             n_split=n_split or 0, test_split=0, seed=1234, verbose=False)
+    J = len(groups) * n_cond
+    L = min(1000, 100 * J)
+    for attr, shape in [('x_weights', (1000, L)), ('y_weights', (100 * J, L)), ('singvals', (L,)),
+                        ('varexp', (L,)), ('x_scores', (100, L)), ('y_scores', (100, L))]:
+        assert res[attr].shape == shape, attr
+    want = ref.run_plsc(Xr, Yr, method='behavioral', groups=groups, n_cond=n_cond,
+                        permsamples=res.permres.permsamples)
+    live = want['singvals'] > 1e-6 * want['singvals'][0]
+    assert_close(res.singvals[live], want['singvals'][live], 1e-6, what='singvals')
+    assert_close(res.permres.perm_singval[live], want['permres']['perm_singval'][live], 1e-5, what='perm')
+    assert np.all(np.isfinite(res.bootres.x_weights_normed[:, live]))
+
+
 # ---- wide behaviour matrices (the reference's tests use 100 Y columns) ----------
 @pytest.mark.parametrize('n_groups,n_cond,n_split', [(1, 1, 4), (1, 2, None), (2, 1, 3)])
 def test_behavioral_wide_y(n_groups, n_cond, n_split):

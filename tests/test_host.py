@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared <= exported, declared - exported
     lib = engine._load()
     assert lib.plsx_version() >= 1000
-    assert lib.plsx_max_tprime() == 352
+    assert lib.plsx_max_tprime() == 1280
 
 
 def test_engine_fails_loudly_without_gpu():

@@ -16,3 +16,5 @@ from .resampling import (gen_permsamp, gen_bootsamp, gen_splits, dummy_code,  # 
                          dummy_label, permute_cols)
 from .plsc import behavioral_pls, meancentered_pls  # noqa: F401
 from .regression import pls_regression  # noqa: F401
+from .matlab_io import import_matlab_result  # noqa: F401
+from .io import save_results, load_results  # noqa: F401

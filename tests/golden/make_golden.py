@@ -336,8 +336,42 @@ def main_reg_extra():
     print('wrote simpls_nan')
 
 
+def main_matimport():
+    """pyls.matlab.import_matlab_result on the reference's own .mat fixtures
+    (pyls/tests/data/*.mat, mirrored as data files under tests/golden/mat/):
+    every key of the returned PLSResults, flattened; arrays above 16 KB are
+    recorded as shape + dtype + sha256 of their bytes."""
+    import glob
+    import hashlib
+
+    def flatten(d, pre=''):
+        out = {}
+        for k, v in d.items():
+            if hasattr(v, 'items'):
+                out.update(flatten(v, pre + k + '__'))
+            elif v is not None:
+                out[pre + k] = np.asarray(v)
+        return out
+    for f in sorted(glob.glob(os.path.join(REF, 'pyls', 'tests', 'data', '*.mat'))):
+        name = os.path.basename(f)[:-4]
+        if name == 'empty':
+            continue
+        flat_res = flatten(pyls.matlab.import_matlab_result(f))
+        out = {}
+        for k, v in flat_res.items():
+            if v.nbytes <= 16384:
+                out[k] = v
+            else:
+                out['sha256:' + k] = np.array([str(v.shape), str(v.dtype),
+                                               hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()])
+        np.savez_compressed(os.path.join(HERE, 'matimport_' + name + '.npz'), **out)
+        print('wrote matimport_' + name, len(out), 'keys')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'cv':
+    if len(sys.argv) > 1 and sys.argv[1] == 'matimport':
+        main_matimport()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cv':
         main_cv()
     elif len(sys.argv) > 1 and sys.argv[1] == 'reg':
         main_reg_extra()
@@ -348,3 +382,4 @@ if __name__ == '__main__':
         main_cv()
         main_reg_extra()
         main_cv_cov()
+        main_matimport()

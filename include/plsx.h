@@ -166,6 +166,12 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np,
                           const uint8_t* d_masks, int ns,
                           double* d_ucorr, double* d_vcorr, void* stream);
+/* Same with the arrangements given as pre-permuted behaviour matrices
+ * (`permindices=False`, pyls/base.py:691-692 then :705-708): d_ystack (np, S, T),
+ * d_perm_idx must be NULL. */
+int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int np,
+                            const uint8_t* d_masks, int ns,
+                            double* d_ucorr, double* d_vcorr, void* stream);
 
 /*
  * Cross-validation -- BehavioralPLS.crossval / _single_crossval

@@ -392,9 +392,12 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
 // Build the A operands of `nres` resamples and run the cross-product kernel:
 // afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
 // [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
+// ystack: per-resample behaviour matrices (S x T each, `ystride` doubles apart; ystride 0 =
+// one matrix shared by all resamples of the call, e.g. the halves of one pre-permuted Y).
 int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
-              bool prebuilt = false, const double* ystack = nullptr)
+              bool prebuilt = false, const double* ystack = nullptr, long long ystride = -1)
 {
+    if (ystride < 0) ystride = (long long)ctx->S * ctx->T;
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
     if (ctx->timing) ctx->timed_units += nres;
@@ -414,7 +417,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
         dim3 grid(nres, ctx->J), block(256);
         const size_t lds = (size_t)2 * ctx->T * 8;
         hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ystack ? ystack : ptr<double>(ctx->Y),
-                           ystack ? (long long)ctx->S * ctx->T : 0LL, ctx->T, ctx->S,
+                           ystack ? ystride : 0LL, ctx->T, ctx->S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay,
                            ctx->cov, ctx->momrows, ptr<double>(ctx->Afrag), ctx->group_stride,
                            ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16));
@@ -1241,7 +1244,7 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_
 }
 
 int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
-                    hipStream_t st)
+                    hipStream_t st, const double* Yarr)
 {
     const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
     if (!ctx->has_cellS) {
@@ -1266,7 +1269,7 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
     GroupLayout lay;
     lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = J; lay.T = ctx->T; lay.MT = ctx->MT;
     lay.w0 = ctx->w0; lay.sq0 = ctx->sq0; lay.Tpp = ctx->Tpp;
-    hipLaunchKernelGGL(k_build_A_split, dim3(m, J), dim3(256), 0, st, ptr<double>(ctx->Y), ctx->T, S,
+    hipLaunchKernelGGL(k_build_A_split, dim3(m, J), dim3(256), 0, st, Yarr ? Yarr : ptr<double>(ctx->Y), ctx->T, S,
                        ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), perm, masks, lay,
                        ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->mom_n), ctx->nmom_pad,
                        ptr<double>(ctx->rowc));
@@ -1291,9 +1294,17 @@ extern "C" {
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, const uint8_t* d_masks,
                           int ns, double* d_ucorr, double* d_vcorr, void* stream)
 {
+    return plsx_split_half_batch_y(ctx, d_perm_idx, nullptr, np, d_masks, ns, d_ucorr, d_vcorr, stream);
+}
+
+int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int np,
+                            const uint8_t* d_masks, int ns, double* d_ucorr, double* d_vcorr, void* stream)
+{
     NEED_DATA();
-    if (!d_masks || !d_ucorr || !d_vcorr || np < 1 || ns < 1)
+    if (!d_masks || !d_ucorr || !d_vcorr || np < 1 || ns < 1 || (d_ystack && d_perm_idx))
         return fail(ctx, PLSX_ERR_ARG, "plsx_split_half_batch: bad arguments");
+    if (d_ystack && ctx->method != PLSX_BEHAVIORAL)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_split_half_batch_y: pre-permuted Y stacks need behavioral PLS");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     const int S = ctx->S, Tp = ctx->Tp, L = ctx->L;
@@ -1304,7 +1315,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     // latency-bound launches per permutation (4 ms each at c4, as much as ten of its splits).
     const size_t mstride = (size_t)ctx->nks_t * ctx->LT * 64;
     int pcmax = 1;
-    if (d_perm_idx) {
+    if (d_perm_idx || d_ystack) {
         const long long by_mem = std::max<long long>(1, (4LL << 30) / (ctx->strideR * 8));
         pcmax = (int)std::min<long long>(std::min<long long>(64, by_mem), np);
         pcmax = std::min(pcmax, std::max(1, ctx->Gcap * ctx->npg));
@@ -1321,8 +1332,11 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
     for (int p0 = 0; p0 < np; p0 += pcmax) {
         const int pc = std::min(pcmax, np - p0);
         const int* pblock = d_perm_idx ? d_perm_idx + (size_t)p0 * S : nullptr;
+        const size_t ysz = (size_t)S * ctx->T;
         // full-sample arrangements: R_p, then V_p, d_p and M = V_p / d_p (= vd, fragment order)
-        if (int e = run_xprod(ctx, permute_x ? pblock : nullptr, permute_x ? nullptr : pblock, pc, st)) return e;
+        if (int e = run_xprod(ctx, permute_x ? pblock : nullptr, permute_x ? nullptr : pblock, pc, st, false,
+                              d_ystack ? d_ystack + (size_t)p0 * ysz : nullptr))
+            return e;
         HIPCHK(hipMemcpyAsync(ctx->Rfull.p, ctx->R.p, (size_t)pc * ctx->strideR * 8, hipMemcpyDeviceToDevice, st));
         if (int e = run_gram(ctx, pc, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_DECOMP);
@@ -1335,10 +1349,11 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
             const double* Vp = ptr<double>(ctx->Vp) + (size_t)pi * Tp * L;
             const double* dp = ptr<double>(ctx->dp) + (size_t)pi * L;
             const double* Mvd = ptr<double>(ctx->Mvd) + (size_t)pi * mstride;
+            const double* Yarr = d_ystack ? d_ystack + (size_t)p * ysz : nullptr;     // this arrangement's Y
             for (int off = 0; off < ns; off += spp) {
                 const int m = std::min(spp, ns - off);               // splits in this pass
                 if (fused) {
-                    if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, Rfull, st))
+                    if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, Rfull, st, Yarr))
                         return e;
                 } else {
                     if (int e = ensure(ctx, ctx->srcx, (size_t)2 * m * S * sizeof(int))) return e;
@@ -1348,7 +1363,7 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, cons
                                        ptr<int>(ctx->srcx), ptr<int>(ctx->srcy));
                     LAUNCHCHK();
                     if (int e = run_xprod(ctx, ptr<int>(ctx->srcx), permute_x ? nullptr : ptr<int>(ctx->srcy),
-                                          2 * m, st))
+                                          2 * m, st, false, Yarr, 0))
                         return e;
                 }
                 // C_h = D_h . R_p^T  (T' x T')
@@ -1446,7 +1461,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
     a.y_stride = ystack ? (long long)S * T : 0;
     a.okx = ctx->has_okx ? ptr<uint8_t>(ctx->okx) : nullptr;
-    a.oky = (ctx->has_oky && !ystack) ? ptr<uint8_t>(ctx->oky) : nullptr;
+    a.oky = ctx->has_oky ? ptr<uint8_t>(ctx->oky) : nullptr;
     a.xsrc = xsrc; a.ysrc = ysrc;
     const int ldh = T | 1;
     a.work_stride = (size_t)S * (3 * T + 4 * k + 4) + (size_t)T * ldh;

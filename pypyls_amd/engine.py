@@ -60,6 +60,7 @@ def _load():
         'plsx_crossval_batch': ([vp, vp, i32, vp, vp, vp], i32),
         'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
         'plsx_split_half_batch': ([vp, vp, i32, vp, i32, vp, vp, vp], i32),
+        'plsx_split_half_batch_y': ([vp, vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
         'plsx_last_timing': ([vp, ctypes.POINTER(c_d), i32], i32),
         'plsx_set_timing': ([vp, i32], i32),
@@ -89,7 +90,7 @@ def exported_symbols():
     names = ['plsx_version', 'plsx_max_tprime', 'plsx_ctx_create', 'plsx_ctx_destroy',
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
-             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch',
+             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch', 'plsx_split_half_batch_y',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_kernel_timing',
              'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
@@ -294,9 +295,10 @@ class Engine(object):
         self.sync()
         return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
 
-    def split_half(self, masks, perms=None):
+    def split_half(self, masks, perms=None, ystack=None):
         """Per-split correlations.  masks (np, S, ns) bool: one (S, ns) gen_splits
-        array per arrangement; perms (S, np) index array or None (original data).
+        array per arrangement; perms (S, np) index array, or ystack (np, S, T)
+        pre-permuted behaviour matrices, or neither (original data).
         Returns ucorr, vcorr of shape (np, L, ns)."""
         torch = _torch()
         masks = np.asarray(masks)
@@ -311,10 +313,16 @@ class Engine(object):
             dp = self._index_rows(perms)
             if dp.shape[0] != n_arr:
                 raise ValueError('need one permutation per arrangement')
+        dy = None
+        if ystack is not None:
+            dy = self._dev(ystack, np.float64)
+            if tuple(dy.shape) != (n_arr, self.S, self.T) or dp is not None:
+                raise ValueError('ystack must have shape ({}, {}, {}) and excludes perms'
+                                 .format(n_arr, self.S, self.T))
         uc, vc = self._empty((n_arr, ns, self.L)), self._empty((n_arr, ns, self.L))
-        self._check(self.lib.plsx_split_half_batch(
-            self.ctx, None if dp is None else dp.data_ptr(), n_arr, dm.data_ptr(), ns,
-            uc.data_ptr(), vc.data_ptr(), self._stream()))
+        self._check(self.lib.plsx_split_half_batch_y(
+            self.ctx, None if dp is None else dp.data_ptr(), None if dy is None else dy.data_ptr(), n_arr,
+            dm.data_ptr(), ns, uc.data_ptr(), vc.data_ptr(), self._stream()))
         self.sync()
         return (np.ascontiguousarray(uc.cpu().numpy().transpose(0, 2, 1)),
                 np.ascontiguousarray(vc.cpu().numpy().transpose(0, 2, 1)))

@@ -74,7 +74,7 @@ def import_matlab_result(fname, datamat='datamat_lst'):
                 flat[name + '.' + sub] = getattr(sub_struct, sub)
         else:
             flat[name] = val
-    method = int(np.asarray(flat.get('method', 0)))
+    method = int(np.asarray(flat.get('method', 0)).reshape(-1)[0])
     table = dict(_FIELDS)
     table.update(_BEHAVIORAL if method == 3 else _MEANCENTERED)
     out, pairs = {}, {}

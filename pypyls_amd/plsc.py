@@ -118,13 +118,10 @@ class _PLSCRun(object):
                 if self.method != 'behavioral' or permsamp.ndim != 3:
                     raise ValueError('permindices=False expects `permsamples` of shape '
                                      '(n_perm, S, T) and behavioral PLS')
-                if inp.get('n_split') is not None:
-                    raise NotImplementedError('split-half with pre-permuted Y stacks is not '
-                                              'supported by the device path')
-                ystack, permsamp = permsamp, None
+                ystack, permsamp = permsamp.astype(np.float64, copy=False), None
         n_split = inp.get('n_split')
         orig_splits = None
-        if permsamp is not None and n_split is not None:
+        if (permsamp is not None or ystack is not None) and n_split is not None:
             # the reference draws the split masks of the ORIGINAL data from
             # self.rs after the permutation arrays and before the bootstrap
             # arrays (base.py:373-380); permutation i uses a fresh
@@ -160,7 +157,7 @@ class _PLSCRun(object):
                 local_dist = np.zeros((eng.Tp, L, 0))
         local_uc = local_vc = None
         if orig_splits is not None:
-            lo, hi = parallel.shard_bounds(permsamp.shape[1], rank, world)
+            lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
             pmasks = inp.get('_perm_splitsamples')
             if pmasks is None:
                 pmasks = np.stack([resampling.gen_splits(inp.groups, inp.n_cond, n_split, seed=i,
@@ -169,7 +166,10 @@ class _PLSCRun(object):
             else:
                 pmasks = np.asarray(pmasks)[lo:hi]
             if hi > lo:
-                uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi])
+                if ystack is not None:
+                    uc, vc = eng.split_half(pmasks, ystack=ystack[lo:hi])
+                else:
+                    uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi])
                 local_uc, local_vc = uc.mean(axis=-1).T, vc.mean(axis=-1).T      # (L, p_loc)
             else:
                 local_uc = local_vc = np.zeros((L, 0))

@@ -19,8 +19,8 @@ Differences from the reference at this commit, on purpose:
   * 3-D Y: the reference builds its (2, n_boot) resampling array with
     ``np.array(list(zip(s.T, c.T))).T`` (regression.py:216), which numpy >= 1.24
     rejects; here the equivalent object array is built explicitly.  The
-    combination of NaN rows and 3-D Y, and rows that are only partly NaN, raise
-    NotImplementedError.
+    Rows (or, for 3-D Y, subjects) that are only partly NaN raise
+    NotImplementedError (they poison the reference's fit as well).
 """
 import numpy as np
 
@@ -113,8 +113,12 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         except TypeError:
             raise TypeError('Provided callable `aggfun` must accept `axis` keyword argument to '
                             'condense an array along the specified axis.')
-        if np.isnan(Y).any() or np.isnan(X).any():
-            raise NotImplementedError('NaN rows together with a 3-D Y are not supported')
+        if np.isnan(Y).any():
+            # a subject is either complete or missing altogether: a value missing in SOME
+            # slices would make the aggregated row depend on the resampled third axis
+            sub_nan = np.isnan(Y).reshape(S, -1)
+            if np.any(sub_nan.any(axis=1) & ~sub_nan.all(axis=1)):
+                raise NotImplementedError('3-D Y with partly missing subjects is not supported')
     else:
         Y_agg = Y
         bootsamples_out = None
@@ -192,6 +196,8 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
                 # Y aggregated over the resampled third axis, NOT centred
                 # (the reference bootstraps the original Y, regression.py:308-310, 408)
                 ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a0, a1)])
+                if masked:
+                    ystack = np.nan_to_num(ystack)         # all-NaN rows are dropped by the row masks
             usum, usq, d = eng.simpls_boot(bootsamp[:, a0:a1], usum, usq, ystack=ystack)
             parts.append(d)
         local_dist = np.concatenate(parts, axis=-1) if parts else np.zeros((T, k, 0))

@@ -336,6 +336,30 @@ def main_reg_extra():
     print('wrote simpls_nan')
 
 
+def main_reg_3d_nan():
+    """pls_regression with 3-D Y AND all-NaN rows in X and in Y (regression.py:48-53,
+    308-313): the rows are masked per bootstrap after the third axis is aggregated."""
+    rs = np.random.RandomState(999)
+    S, B, T, C, k = 30, 50, 4, 6, 3
+    X = rs.randn(S, B)
+    Y3 = rs.randn(S, T, C) + 0.8 * X[:, :T, None]
+    X[[4, 19]] = np.nan
+    Y3[9] = np.nan
+    sb = pbase.gen_bootsamp([S], 1, 7, seed=1234, verbose=False)
+    cb = pbase.gen_bootsamp([C], 1, 7, seed=1234, verbose=False)
+    boots = np.empty((2, 7), dtype=object)
+    for i in range(7):
+        boots[0, i], boots[1, i] = sb[:, i], cb[:, i]
+    res = pyls.pls_regression(X.copy(), Y3.copy(), n_components=k, n_perm=0, n_boot=7, aggfunc='mean',
+                              bootsamples=boots, seed=1234, verbose=False)
+    out = flat(res)
+    out['boot_subjects'], out['boot_third'] = sb, cb
+    del out['ref_bootres__bootsamples']
+    out['X'], out['Y'], out['n_components'] = X, Y3, np.asarray(k)
+    np.savez_compressed(os.path.join(HERE, 'simpls_3d_nan.npz'), **out)
+    print('wrote simpls_3d_nan')
+
+
 def main_matimport():
     """pyls.matlab.import_matlab_result on the reference's own .mat fixtures
     (pyls/tests/data/*.mat, mirrored as data files under tests/golden/mat/):
@@ -371,6 +395,8 @@ def main_matimport():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'matimport':
         main_matimport()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'reg3dnan':
+        main_reg_3d_nan()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cv':
         main_cv()
     elif len(sys.argv) > 1 and sys.argv[1] == 'reg':
@@ -383,3 +409,4 @@ if __name__ == '__main__':
         main_reg_extra()
         main_cv_cov()
         main_matimport()
+        main_reg_3d_nan()

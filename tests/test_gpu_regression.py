@@ -82,6 +82,31 @@ def test_pls_regression_3d_y(agg):
         pls.pls_regression(g['X'], g['Y'], n_components=k, n_perm=0, n_boot=n, bootsamples=[[10], [10]])
 
 
+def test_pls_regression_3d_y_with_nan_rows():
+    """3-D Y plus all-NaN rows in X and a missing subject in Y vs the reference
+    (regression.py:48-53, 308-313)."""
+    import pypyls_amd as pls
+    g = load_golden('simpls_3d_nan')
+    n = g['boot_subjects'].shape[1]
+    bs = np.empty((2, n), dtype=object)
+    for i in range(n):
+        bs[0, i], bs[1, i] = g['boot_subjects'][:, i], g['boot_third'][:, i]
+    res = pls.pls_regression(g['X'], g['Y'], n_components=int(g['n_components']), n_perm=0, n_boot=n,
+                             aggfunc='mean', bootsamples=bs, seed=1234, verbose=False)
+    for key in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        np.testing.assert_array_equal(np.isnan(res[key]), np.isnan(g['ref_' + key]))
+        assert_close(np.nan_to_num(res[key]), np.nan_to_num(g['ref_' + key]), RTOL, what=key)
+    for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(res['bootres'][key], g['ref_bootres__' + key], RTOL, what=key)
+    Yp = g['Y'].copy()
+    Yp[3, 1, 2] = np.nan                                   # a subject missing in SOME slices only
+    with pytest.raises(NotImplementedError):
+        pls.pls_regression(g['X'], Yp, n_components=2, n_perm=0, n_boot=2, seed=1, verbose=False)
+    # n_boot = 0 with a 3-D Y (ADVICE r1: used to die on an unbound local)
+    r0 = pls.pls_regression(g['X'], g['Y'], n_components=2, n_perm=0, n_boot=0, verbose=False)
+    assert r0.x_weights.shape == (g['X'].shape[1], 2)
+
+
 def test_pls_regression_nan_rows():
     """All-NaN rows are masked per resample (get_mask, regression.py:48-53)."""
     import pypyls_amd as pls

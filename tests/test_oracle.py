@@ -222,3 +222,19 @@ def test_simpls_wide_is_unpinned_but_close():
     g = load_golden('simpls_t16')
     out = ref.run_regression(g['X'], g['Y'], int(g['n_components']))
     assert_close(out['varexp'], g['ref_varexp'], 5e-2, what='varexp (approximate ref)')
+
+
+def test_simpls_3d_with_nan_rows_vs_reference():
+    """3-D Y together with all-NaN rows of X and of Y (masked per bootstrap after the
+    third axis is aggregated, regression.py:308-313)."""
+    g = load_golden('simpls_3d_nan')
+    n = g['boot_subjects'].shape[1]
+    bs = np.empty((2, n), dtype=object)
+    for i in range(n):
+        bs[0, i], bs[1, i] = g['boot_subjects'][:, i], g['boot_third'][:, i]
+    out = ref.run_regression(g['X'], g['Y'], int(g['n_components']), bootsamples=bs, aggfunc='mean')
+    for k in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        np.testing.assert_array_equal(np.isnan(out[k]), np.isnan(g['ref_' + k]))
+        assert_close(np.nan_to_num(out[k]), np.nan_to_num(g['ref_' + k]), 1e-9, what=k)
+    for k in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(out['bootres'][k], g['ref_bootres__' + k], 1e-9, what=k)

@@ -327,27 +327,26 @@ class Simpls(object):
             self.legs.append(ev)
 
     def roofline(self, kt, steps, world):
-        """Dominant kernel: the dual-space solver.  Algorithmic work per resample
-        in THIS (dual) formulation: every product with K_r = Jc K[xs, xs] Jc is
-        2 S^2 flop; there are T for Z = K_r Yd plus 2 per component
-        (regression.py:56-186 restated in S dimensions), i.e. (T + 2k) 2 S^2 flop;
-        bytes: K (8 S^2) read once per resample at best.  SURVEY 8d's primal model
-        (31 passes over X, 24.8 GB per resample) is reported beside it."""
+        """Dominant kernel by summed time.  With the K products of a batch of
+        resamples done as GEMMs (plsx_simpls.h) the dual-space solver is no longer
+        it: the bootstrap's B-long weights x_weights = X0_r^T Wd (k x B per
+        bootstrap, 2 S k B flop, the only pass over the features) are -- k_xprod,
+        MFMA bound.  The solver's own algorithmic work in this formulation,
+        (T + 1 + k) products with K of 2 S^2 flop each per resample, is reported
+        beside it, and SURVEY 8d's primal model (1 + 2k passes over X) for scale."""
         S, T, k, B = self.S, self.T, self.k, self.B
-        ms, n = kt.get('k_simpls_dual', (0.0, 0))
-        units = steps * (self.perms + self.boots)
-        fl = (T + 2.0 * k) * 2.0 * S * S * units
-        by = 8.0 * S * S * units
+        dom = max(kt, key=lambda n: kt[n][0]) if kt else 'k_xprod'
+        ms, n = kt.get('k_xprod', (0.0, 0))
+        fl = 2.0 * S * k * B * steps * self.boots
         tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        tb = by / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        f_m, f_h = tf / PEAK_FP64_MFMA_TFLOPS, tb / PEAK_HBM_TBS
-        mf = f_m >= f_h
-        primal_bytes = (1 + 2 * k) * 8.0 * S * B
-        return {'bound': 'mfma' if mf else 'hbm', 'kernel': 'k_simpls_dual',
-                'achieved': tf if mf else tb * 1e3, 'peak': PEAK_FP64_MFMA_TFLOPS if mf else PEAK_HBM_TBS * 1e3,
-                'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': max(f_m, f_h), 'frac_mfma': f_m,
-                'frac_hbm_algorithmic': f_h, 'avg_launch_ms': ms / max(n, 1), 'launches': n,
-                'primal_model_hbm_resamples_per_s': PEAK_HBM_TBS * 1e12 / primal_bytes}
+        sms = kt.get('k_simpls_dual', (0.0, 0))[0] + kt.get('k_nt_gemm', (0.0, 0))[0]
+        sfl = (T + 1.0 + k) * 2.0 * S * S * steps * (self.perms + self.boots)
+        return {'bound': 'mfma', 'kernel': 'k_xprod<24> (bootstrap x_weights = X0_r^T Wd)',
+                'dominant_by_time': dom, 'achieved': tf, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf / PEAK_FP64_MFMA_TFLOPS, 'avg_launch_ms': ms / max(n, 1), 'launches': n,
+                'dual_solver_ms_per_resample': sms / max(steps * (self.perms + self.boots), 1),
+                'dual_solver_tflops': sfl / (sms * 1e-3) / 1e12 if sms > 0 else 0.0,
+                'primal_model_hbm_resamples_per_s': PEAK_HBM_TBS * 1e12 / ((1 + 2 * k) * 8.0 * S * B)}
 
     def pipeline(self, ms_per_step, primal):
         return None, None

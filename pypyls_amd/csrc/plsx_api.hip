@@ -878,9 +878,9 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: mean_centering must be 0, 1 or 2");
     const int J = n_groups * n_cond;
     const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
-    if (method == PLSX_REGRESSION && (size_t)T * (T | 1) * 8 + 20 * (size_t)S + 16 * T + 256 > 160 * 1024)
+    if (method == PLSX_REGRESSION && ((size_t)T * (T | 1) + 2 * T + ncomp + 32 + (size_t)S) * 8 > 160 * 1024)
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
-                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
+                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 (T^2 + S) bytes must fit 160 KB)");
     if ((long long)B + Tp > 2000000LL)
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
     if (Tp > PLSX_MAX_TP || J > PLSX_MAX_CELLS || (method != PLSX_BEHAVIORAL && Tp > PLSX_BLOCK_TP)) {
@@ -1454,19 +1454,39 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     const int S = ctx->S, T = ctx->T, k = ctx->ncomp;
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
-    SimplsArgs a;
+    SdArgs a;
     memset(&a, 0, sizeof(a));
     a.S = S; a.T = T; a.k = k;
-    a.K = ptr<double>(ctx->Kmat);
     a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
     a.y_stride = ystack ? (long long)S * T : 0;
     a.okx = ctx->has_okx ? ptr<uint8_t>(ctx->okx) : nullptr;
     a.oky = ctx->has_oky ? ptr<uint8_t>(ctx->oky) : nullptr;
     a.xsrc = xsrc; a.ysrc = ysrc;
-    const int ldh = T | 1;
-    a.work_stride = (size_t)S * (3 * T + 4 * k + 4) + (size_t)T * ldh;
-    if (int e = ensure(ctx, ctx->swork, (size_t)nres * a.work_stride * 8)) return e;
-    a.work = ptr<double>(ctx->swork);
+    // per-resample state, carved out of one scratch buffer (doubles)
+    const size_t n = (size_t)nres;
+    const size_t per = (size_t)S /* xs, ys as ints share one S-double slot */ + 2 * (size_t)S * T + 4 * (size_t)k * S +
+                       3 * (size_t)S + 2 * (size_t)T * T + 2 * (size_t)k * T + 4;
+    const size_t gemm_rows = n * (T + 1);
+    if (int e = ensure(ctx, ctx->swork, (n * per + 2 * gemm_rows * S + 64) * 8)) return e;
+    double* w = ptr<double>(ctx->swork);
+    a.xs = reinterpret_cast<int*>(w);            w += n * S / 2 + 1;
+    a.ys = reinterpret_cast<int*>(w);            w += n * S / 2 + 1;
+    a.Y0 = w; w += n * S * T;
+    a.Z0 = w; w += n * S * T;
+    a.BT = w; w += n * k * S;
+    a.KB = w; w += n * k * S;
+    a.XW = w; w += n * k * S;
+    a.WD = w; w += n * k * S;
+    a.va = w; w += n * S;
+    a.vt = w; w += n * S;
+    a.kcpos = w; w += n * S;
+    a.H = w; w += n * T * T;
+    a.H0 = w; w += n * T * T;
+    a.G = w; w += n * k * T;
+    a.gY0 = w; w += n * k * T;
+    a.scal = w; w += n * 4;
+    a.Wt = w; w += gemm_rows * S;
+    a.Zt = w;
     a.pctvar = pctvar; a.yload = yload; a.cvec = cvec;
     if (scatter) {
         HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
@@ -1474,14 +1494,49 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         a.lay.n = ctx->npg; a.lay.Tp = ctx->Tp; a.lay.J = 1; a.lay.T = T; a.lay.MT = ctx->MT;
         a.lay.w0 = ctx->w0; a.lay.sq0 = ctx->sq0; a.lay.Tpp = ctx->Tpp;
     }
-    const size_t lds = ((size_t)S + (size_t)T * ldh + 2 * T + 16) * 8 + (size_t)3 * S * 4 + 64;
-    if (lds > 160 * 1024)
-        return fail(ctx, PLSX_ERR_UNSUPPORTED,
-                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 T^2 + 20 S bytes must fit 160 KB)");
-    HIPCHK(set_lds(k_simpls_dual, lds));
-    KTimer tm(ctx, KC_SIMPLS, st);
-    hipLaunchKernelGGL(k_simpls_dual, dim3(nres), dim3(512), lds, st, a);
-    LAUNCHCHK();
+    const double* K = ptr<double>(ctx->Kmat);
+    {
+        const int CH = std::max(1, std::min(T + 1, 6144 / S));
+        const size_t lds = ((size_t)CH * S + 32) * 8;
+        HIPCHK(set_lds(k_sd_init, lds));
+        KTimer tm(ctx, KC_SIMPLS, st);
+        hipLaunchKernelGGL(k_sd_init, dim3(nres), dim3(256), lds, st, a, CH);
+        LAUNCHCHK();
+    }
+    // GEMM 0: (T + 1) subject-space vectors per resample against K (symmetric)
+    if (int e = run_nt(ctx, a.Wt, 0, S, (int)gemm_rows, K, 0, S, S, nullptr, 0, 0, 0, S, 1, a.Zt, 0, S,
+                       nullptr, 0, 0, st))
+        return e;
+    {
+        KTimer tm(ctx, KC_SIMPLS, st);
+        hipLaunchKernelGGL(k_sd_post0, dim3(nres), dim3(256), 0, st, a);
+        LAUNCHCHK();
+    }
+    const size_t lds_a = ((size_t)T * (T | 1) + 2 * T + k + 32 + S) * 8;
+    const size_t lds_b = ((size_t)4 * T + k + 32) * 8;
+    HIPCHK(set_lds(k_sd_comp_a, lds_a));
+    for (int c = 0; c < k; ++c) {
+        a.c = c;
+        {
+            KTimer tm(ctx, KC_SIMPLS, st);
+            hipLaunchKernelGGL(k_sd_comp_a, dim3(nres), dim3(256), lds_a, st, a);
+            LAUNCHCHK();
+        }
+        // GEMM c: K beta for every resample of the batch
+        if (int e = run_nt(ctx, a.Wt, 0, S, nres, K, 0, S, S, nullptr, 0, 0, 0, S, 1, a.Zt, 0, S,
+                           nullptr, 0, 0, st))
+            return e;
+        {
+            KTimer tm(ctx, KC_SIMPLS, st);
+            hipLaunchKernelGGL(k_sd_comp_b, dim3(nres), dim3(256), lds_b, st, a);
+            LAUNCHCHK();
+        }
+    }
+    {
+        KTimer tm(ctx, KC_SIMPLS, st);
+        hipLaunchKernelGGL(k_sd_final, dim3(nres), dim3(256), 0, st, a);
+        LAUNCHCHK();
+    }
     return 0;
 }
 }  // namespace

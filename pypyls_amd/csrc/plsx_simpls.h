@@ -13,29 +13,28 @@
 // B-sized; a bootstrap needs x_weights = X0_r^T Wd (B x k), obtained by
 // scattering the dual weights into the A operand of k_xprod.
 //
-// One block per resample; S-long work vectors live in global scratch (L2),
-// K rows are read coalesced (K is symmetric: z[p] = sum_q K[xs_q][xs_p] v[q]).
+// Batched formulation.  Every product with K_r is gather(K . scatter(v)): with
+// P_r the S x S selection matrix of the resample (row p picks xs_p),
+//     K_r v = Jc P_r K P_r^T Jc v,
+// i.e. the SAME K for every resample once the centred vector is scattered to
+// subject space (w[i] = sum over positions p with xs_p = i).  The products of a
+// whole batch of resamples are therefore ONE GEMM against K per step
+// (k_nt_gemm, MFMA) instead of one pass over K per resample and product
+// (round 1: a GEMV per product, 63 % of the solver streaming K through the fabric):
+//     Z_0 = K_r Yd_0     T columns per resample, plus K . cnt for the mean of the
+//                        un-centred scores: (T + 1) x nres columns       GEMM 0
+//     K_r beta_c         one column per resample and component          GEMM c
+// The other product of the classical recursion, t_c = K_r a_c with
+// a_c = Yd c / s, is free: t_c = (K_r Yd) c / s = Z c / s, and Z = K_r Yd is
+// carried along.  Deflation is kept in factored form --
+//     Yd = Y0 - sum_j beta_j g_j^T,  Z = Z0 - sum_j (K beta_j) g_j^T,  H -= g g^T
+// -- so Y0 / Z0 are written once.  (The reference re-applies the deflation
+// against the earlier basis vectors, regression.py:148-150; in exact
+// arithmetic those coefficients vanish and they are not re-applied here.)
+// Kernels, one block per resample:
+//   k_sd_init -> [GEMM 0] -> k_sd_post0 -> { k_sd_comp_a -> [GEMM c] -> k_sd_comp_b } x k -> k_sd_final
 #pragma once
 #include "plsx_kernels.h"
-
-struct SimplsArgs {
-    int S, T, k;
-    const double* K;        // S x S
-    const double* Yc;       // S x T, globally centred Y (or per-resample stack, y_stride != 0)
-    long long y_stride;     // doubles between the Y matrices of consecutive resamples (0: shared)
-    const uint8_t* okx;     // [S] 1 = X row usable (not an all-NaN row), or nullptr
-    const uint8_t* oky;     // [S] 1 = Y row usable, or nullptr
-    const int* xsrc;        // [nres][S] or nullptr (identity)
-    const int* ysrc;        // [nres][S] or nullptr
-    double* work;           // per-resample scratch
-    size_t work_stride;     // doubles per resample
-    double* pctvar;         // [nres][k]   sum(y_loadings^2) / sum(Y0^2)
-    double* yload;          // [nres][T][k]  Y[ys]^T (X[xs] W), signs not yet aligned
-    double* cvec;           // [nres][T][k]  right singular vectors c_c (sign rule when B <= T)
-    double* Afrag;          // dual weights scattered into k_xprod's A operand (or nullptr)
-    size_t group_stride;
-    GroupLayout lay;
-};
 
 __device__ __forceinline__ double block_sum(double v, double* red)
 {
@@ -51,261 +50,331 @@ __device__ __forceinline__ double block_sum(double v, double* red)
     return s;
 }
 
-// z = Jc . K[xs, xs] . Jc . v over the INCLUDED positions (inc[p] != 0; ninc of
-// them; excluded positions -- all-NaN rows, regression.py:48-53 -- read and
-// produce zeros); optionally also returns the value before the final centring
-// (zu).  v, z, zu: S-long global arrays; vc: S doubles of LDS.
-__device__ void kop(const double* __restrict__ K, int S, const int* xs, const int* inc, double ninc,
-                    const double* v, double* z, double* zu, double* vc, double* red)
-{
-    const int tid = threadIdx.x, NT = blockDim.x;
-    double part = 0.0;
-    for (int p = tid; p < S; p += NT) if (inc[p]) part += v[p];
-    const double mean = block_sum(part, red) / ninc;
-    for (int p = tid; p < S; p += NT) vc[p] = inc[p] ? v[p] - mean : 0.0;
-    __syncthreads();
-    double zpart = 0.0;
-    for (int p = tid; p < S; p += NT) {
-        double acc = 0.0;
-        if (inc[p]) {
-            const int col = xs[p];
-            for (int q = 0; q < S; ++q) acc += K[(size_t)xs[q] * S + col] * vc[q];
-        }
-        if (zu) zu[p] = acc;
-        z[p] = acc;
-        zpart += acc;
-    }
-    const double zmean = block_sum(zpart, red) / ninc;
-    for (int p = tid; p < S; p += NT) if (inc[p]) z[p] -= zmean;
-    __syncthreads();
-}
+struct SdArgs {
+    int S, T, k, c;             // c: current component
+    const double* Yc;           // S x T globally centred Y (or a stack, y_stride != 0)
+    long long y_stride;
+    const uint8_t* okx;         // [S] usable X rows or nullptr
+    const uint8_t* oky;         // [S] usable Y rows or nullptr
+    const int* xsrc;            // [nres][S] or nullptr (identity)
+    const int* ysrc;            // [nres][S] or nullptr
+    // per-resample state (library scratch)
+    int* xs;                    // [nres][S] X source of position p, -1 = position excluded
+    int* ys;                    // [nres][S]
+    double* Y0;                 // [nres][S][T]  resample-centred Y
+    double* Z0;                 // [nres][S][T]  K_r Y0
+    double* BT;                 // [nres][k][S]  beta_j (centred, normalised)
+    double* KB;                 // [nres][k][S]  K_r beta_j
+    double* XW;                 // [nres][k][S]  X[xs] w_j (un-centred)
+    double* WD;                 // [nres][k][S]  dual weights (centred)
+    double* va;                 // [nres][S]  work vector
+    double* vt;                 // [nres][S]  work vector
+    double* kcpos;              // [nres][S]  (K cnt)[xs_p]
+    double* H;                  // [nres][T][T]
+    double* H0;                 // [nres][T][T]
+    double* G;                  // [nres][k][T]  deflation coefficients g_j
+    double* gY0;                // [nres][k][T]  (K beta_j)^T Y0
+    double* scal;               // [nres][4]: n included, sum Y0^2
+    double* Wt;                 // GEMM operand rows (vectors in subject space), S doubles each
+    double* Zt;                 // GEMM result rows
+    double* pctvar;             // [nres][k]   sum(y_loadings^2) / sum(Y0^2)
+    double* yload;              // [nres][T][k]  Y[ys]^T (X[xs] W), signs not yet aligned
+    double* cvec;               // [nres][T][k]  right singular vectors c_c (sign rule when B <= T)
+    double* Afrag;              // dual weights scattered into k_xprod's A operand (or nullptr)
+    size_t group_stride;
+    GroupLayout lay;
+};
 
-__global__ __launch_bounds__(512)
-void k_simpls_dual(SimplsArgs a)
+// Resample setup: sources, masks, Y0 = Jc Y[ys], sum of squares, and the T + 1
+// subject-space vectors scatter(Y0[:, t]), cnt for GEMM 0.
+// dynamic LDS: CH * S doubles (CH vectors scattered per pass) + 32 doubles.
+__global__ __launch_bounds__(256)
+void k_sd_init(SdArgs a, int CH)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm_p[];
-    const int S = a.S, T = a.T, k = a.k;
-    const int tid = threadIdx.x, NT = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
+    double* buf = sm_sd;                               // [CH][S]
+    double* red = sm_sd + (size_t)CH * a.S;            // [32]
+    const int S = a.S, T = a.T, tid = threadIdx.x, NT = blockDim.x;
     const int r = blockIdx.x;
-    const int ldh = T | 1;
-    // LDS carve
-    double* vc = sm_p;                       // [S]
-    double* Hw = vc + S;                     // T x ldh (Jacobi working copy of H)
-    double* gv = Hw + (size_t)T * ldh;       // [T]
-    double* cv = gv + T;                     // [T]
-    double* red = cv + T;                    // [16]
-    int* xs = reinterpret_cast<int*>(red + 16);   // [S]
-    int* ys = xs + S;                             // [S]
-    int* inc = ys + S;                            // [S] position included
-    __shared__ int s_flag;
-
-    // global scratch carve
-    double* W = a.work + (size_t)r * a.work_stride;
-    double* Y0 = W;                          // S x T  (resample-centred Y)
-    double* Yd = Y0 + (size_t)S * T;         // S x T  (deflated)
-    double* Z = Yd + (size_t)S * T;          // S x T  = K_r Yd
-    double* BT = Z + (size_t)S * T;          // S x k  beta_j
-    double* KB = BT + (size_t)S * k;         // S x k  K_r beta_j
-    double* XW = KB + (size_t)S * k;         // S x k  X[xs] W
-    double* WD = XW + (size_t)S * k;         // S x k  dual weights (centred)
-    double* va = WD + (size_t)S * k;         // [S]
-    double* vz = va + S;                     // [S]
-    double* vu = vz + S;                     // [S]
-    double* vb = vu + S;                     // [S]
-    double* H = vb + S;                      // T x ldh  = Yd^T K_r Yd (kept in L2; only Hw is on chip)
-
+    int* xs = a.xs + (size_t)r * S;
+    int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
+    double* Y0 = a.Y0 + (size_t)r * S * T;
     double cnt = 0.0;
     for (int p = tid; p < S; p += NT) {
         const int x = a.xsrc ? a.xsrc[(size_t)r * S + p] : p;
         const int y = a.ysrc ? a.ysrc[(size_t)r * S + p] : p;
-        xs[p] = x; ys[p] = y;
         const int ok = (!a.okx || a.okx[x]) && (!a.oky || a.oky[y]);
-        inc[p] = ok;
+        xs[p] = ok ? x : -1;
+        ys[p] = y;
         cnt += ok;
     }
     const double ninc = block_sum(cnt, red);
-    // Y0 = Jc Y[ys] over the included rows
-    double ssy_part = 0.0;
+    double ssy = 0.0;
     for (int t = 0; t < T; ++t) {
         double part = 0.0;
-        for (int p = tid; p < S; p += NT) if (inc[p]) part += Ysrc[(size_t)ys[p] * T + t];
+        for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Ysrc[(size_t)ys[p] * T + t];
         const double mean = block_sum(part, red) / ninc;
         for (int p = tid; p < S; p += NT) {
-            const double y = inc[p] ? Ysrc[(size_t)ys[p] * T + t] - mean : 0.0;
+            const double y = xs[p] >= 0 ? Ysrc[(size_t)ys[p] * T + t] - mean : 0.0;
             Y0[(size_t)p * T + t] = y;
-            Yd[(size_t)p * T + t] = y;
-            ssy_part += y * y;
+            ssy += y * y;
         }
     }
-    const double ssY = block_sum(ssy_part, red);
-    // Z = K_r Yd.  K (S x S) does not fit an XCD's L2, so every pass over it is
-    // paid in fabric bandwidth (the kernel's bottleneck): the T columns are done
-    // in tiles of ZT with one pass per tile instead of one per column.  Yd is
-    // already centred over the included rows (excluded rows are zero), so only the
-    // output centring of kop() remains.
-    {
-        constexpr int ZT = 10;
+    const double ssY = block_sum(ssy, red);
+    if (tid == 0) { a.scal[(size_t)r * 4] = ninc; a.scal[(size_t)r * 4 + 1] = ssY; }
+    __syncthreads();
+    // subject-space operands of GEMM 0: vectors 0..T-1 = columns of Y0, vector T = counts
+    double* Wt = a.Wt + (size_t)r * (T + 1) * S;
+    for (int t0 = 0; t0 <= T; t0 += CH) {
+        const int nv = min(CH, T + 1 - t0);
+        for (int i = tid; i < nv * S; i += NT) buf[i] = 0.0;
         __syncthreads();
-        for (int t0 = 0; t0 < T; t0 += ZT) {
-            const int nt = min(ZT, T - t0);
-            for (int p = tid; p < S; p += NT) {
-                double acc[ZT];
-#pragma unroll
-                for (int t = 0; t < ZT; ++t) acc[t] = 0.0;
-                if (inc[p]) {
-                    const int col = xs[p];
-                    for (int q = 0; q < S; ++q) {
-                        if (!inc[q]) continue;
-                        const double kv = a.K[(size_t)xs[q] * S + col];
-                        const double* yq = Yd + (size_t)q * T + t0;
-#pragma unroll
-                        for (int t = 0; t < ZT; ++t)
-                            if (t < nt) acc[t] += kv * yq[t];
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < ZT; ++t)
-                    if (t < nt) Z[(size_t)p * T + t0 + t] = acc[t];
-            }
+        for (int idx = tid; idx < nv * S; idx += NT) {
+            const int v = idx / S, p = idx - v * S;
+            const int x = xs[p];
+            if (x < 0) continue;
+            const int t = t0 + v;
+            atomicAdd(&buf[(size_t)v * S + x], t < T ? Y0[(size_t)p * T + t] : 1.0);
         }
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
-            double part = 0.0;
-            for (int p = tid; p < S; p += NT) if (inc[p]) part += Z[(size_t)p * T + t];
-            const double zmean = block_sum(part, red) / ninc;
-            for (int p = tid; p < S; p += NT) if (inc[p]) Z[(size_t)p * T + t] -= zmean;
-        }
+        for (int i = tid; i < nv * S; i += NT) Wt[(size_t)t0 * S + i] = buf[i];
         __syncthreads();
     }
-    // H = Yd^T Z
+}
+
+// After GEMM 0: Z0 = Jc gather(K scatter(Y0)), kcpos, H = H0 = Y0^T Z0.
+__global__ __launch_bounds__(256)
+void k_sd_post0(SdArgs a)
+{
+    __shared__ double red[32];
+    const int S = a.S, T = a.T, tid = threadIdx.x, NT = blockDim.x;
+    const int r = blockIdx.x;
+    const int* xs = a.xs + (size_t)r * S;
+    const double* Zt = a.Zt + (size_t)r * (T + 1) * S;
+    const double* Y0 = a.Y0 + (size_t)r * S * T;
+    double* Z0 = a.Z0 + (size_t)r * S * T;
+    const double ninc = a.scal[(size_t)r * 4];
+    for (int t = 0; t < T; ++t) {
+        double part = 0.0;
+        for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Zt[(size_t)t * S + xs[p]];
+        const double mean = block_sum(part, red) / ninc;
+        for (int p = tid; p < S; p += NT)
+            Z0[(size_t)p * T + t] = xs[p] >= 0 ? Zt[(size_t)t * S + xs[p]] - mean : 0.0;
+    }
+    for (int p = tid; p < S; p += NT)
+        a.kcpos[(size_t)r * S + p] = xs[p] >= 0 ? Zt[(size_t)T * S + xs[p]] : 0.0;
+    __syncthreads();
+    double* H = a.H + (size_t)r * T * T;
+    double* H0 = a.H0 + (size_t)r * T * T;
     for (int idx = tid; idx < T * T; idx += NT) {
-        const int t1 = idx / T, t2 = idx % T;
+        const int t1 = idx / T, t2 = idx - t1 * T;
         double s = 0.0;
-        for (int p = 0; p < S; ++p) s += Yd[(size_t)p * T + t1] * Z[(size_t)p * T + t2];
-        H[t2 * ldh + t1] = s;
+        for (int p = 0; p < S; ++p) s += Y0[(size_t)p * T + t1] * Z0[(size_t)p * T + t2];
+        H[idx] = s;
+        H0[idx] = s;
+    }
+}
+
+// Component c, first half: leading eigenpair of H, a = Yd c / s, t = Z c / s, dual
+// weights, scores, pctvar, new basis vector (MGS x 2) scattered for GEMM c.
+// dynamic LDS: T*(T|1) + 2 T + k + 32 + S doubles.
+__global__ __launch_bounds__(256)
+void k_sd_comp_a(SdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
+    const int S = a.S, T = a.T, k = a.k, c = a.c, tid = threadIdx.x, NT = blockDim.x;
+    const int ldh = T | 1;
+    double* Hw = sm_sd;                       // T x ldh
+    double* gv = Hw + (size_t)T * ldh;        // [T]
+    double* cv = gv + T;                      // [T]
+    double* gc = cv + T;                      // [k]
+    double* red = gc + k;                     // [32]
+    double* buf = red + 32;                   // [S]
+    __shared__ int s_flag;
+    const int r = blockIdx.x;
+    const int* xs = a.xs + (size_t)r * S;
+    const double* Y0 = a.Y0 + (size_t)r * S * T;
+    const double* Z0 = a.Z0 + (size_t)r * S * T;
+    const double* BT = a.BT + (size_t)r * k * S;
+    const double* KB = a.KB + (size_t)r * k * S;
+    double* va = a.va + (size_t)r * S;
+    double* vt = a.vt + (size_t)r * S;
+    const double* kcpos = a.kcpos + (size_t)r * S;
+    const double* H = a.H + (size_t)r * T * T;
+    const double* H0 = a.H0 + (size_t)r * T * T;
+    const double* G = a.G + (size_t)r * k * T;
+    const double* gY0 = a.gY0 + (size_t)r * k * T;
+    const double ninc = a.scal[(size_t)r * 4], ssY = a.scal[(size_t)r * 4 + 1];
+
+    // leading eigenpair of H (symmetric PSD) by one-sided Jacobi on a copy.  The
+    // rotations need not be accumulated: at convergence column j of the copy is
+    // H v_j = lambda_j v_j, so the eigenvector is that column normalised.
+    for (int idx = tid; idx < T * T; idx += NT) Hw[(idx % T) * ldh + idx / T] = H[idx];
+    __syncthreads();
+    jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag);
+    for (int col = tid; col < T; col += NT) {
+        double s = 0.0;
+        for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }
+        gv[col] = sqrt(s);
     }
     __syncthreads();
-
-    for (int c = 0; c < k; ++c) {
-        // ---- leading eigenpair of H (T x T, symmetric PSD) by one-sided Jacobi on a
-        // copy.  The rotations need not be accumulated: at convergence column j
-        // of the copy is H v_j = lambda_j v_j, so the eigenvector is that column
-        // normalised (same sign as v_j, lambda_j > 0).
-        for (int idx = tid; idx < T * ldh; idx += NT) Hw[idx] = H[idx];
-        __syncthreads();
-        jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag);
-        // eigenvalues = column norms of (H V); pick the largest
-        for (int col = tid; col < T; col += NT) {
-            double s = 0.0;
-            for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }
-            gv[col] = sqrt(s);
-        }
-        __syncthreads();
-        int best = 0;
-        for (int col = 1; col < T; ++col) if (gv[col] > gv[best]) best = col;
-        const double lam = gv[best];
-        const double si = sqrt(lam);
-        for (int t = tid; t < T; t += NT) {
-            cv[t] = Hw[best * ldh + t] / lam;
-            a.cvec[((size_t)r * T + t) * k + c] = cv[t];
-        }
-        __syncthreads();
-        // ---- a = Yd c / s ; t = K_r a ; normalise
-        for (int p = tid; p < S; p += NT) {
-            double s = 0.0;
-            for (int t = 0; t < T; ++t) s += Yd[(size_t)p * T + t] * cv[t];
-            va[p] = s / si;
-        }
-        __syncthreads();
-        kop(a.K, S, xs, inc, ninc, va, vz, vu, vc, red);   // vz = t (unnormalised), vu = X[xs] r
-        double np = 0.0;
-        for (int p = tid; p < S; p += NT) np += vz[p] * vz[p];
-        const double normt = sqrt(block_sum(np, red));
-        // dual weights (centred, as scattered), scores, X[xs] W
-        {
-            double mpart = 0.0;
-            for (int p = tid; p < S; p += NT) if (inc[p]) mpart += va[p];
-            const double amean = block_sum(mpart, red) / ninc;
-            for (int p = tid; p < S; p += NT) {
-                WD[(size_t)c * S + p] = inc[p] ? (va[p] - amean) / normt : 0.0;
-                XW[(size_t)c * S + p] = vu[p] / normt;
-                vz[p] /= normt;                        // t_c
-            }
-        }
-        __syncthreads();
-        // y_loadings q = Y0^T t  -> pctvar
-        double q2 = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double part = 0.0;
-            for (int p = tid; p < S; p += NT) part += Y0[(size_t)p * T + t] * vz[p];
-            const double q = block_sum(part, red);
-            q2 += q * q;
-        }
-        if (tid == 0) a.pctvar[(size_t)r * k + c] = q2 / ssY;
-        // ---- basis: beta = t, MGS x2 against previous (v_j^T v = (K beta_j)^T beta), normalise
-        for (int p = tid; p < S; p += NT) vb[p] = vz[p];
-        __syncthreads();
-        for (int rep = 0; rep < 2; ++rep)
-            for (int j = 0; j < c; ++j) {
-                double part = 0.0;
-                for (int p = tid; p < S; p += NT) part += KB[(size_t)j * S + p] * vb[p];
-                const double coef = block_sum(part, red);
-                for (int p = tid; p < S; p += NT) vb[p] -= coef * BT[(size_t)j * S + p];
-                __syncthreads();
-            }
-        kop(a.K, S, xs, inc, ninc, vb, vz, nullptr, vc, red);   // vz = K_r beta
-        // note: kop centres its input; beta enters only through K_r, so use the centred beta
-        {
-            double mpart = 0.0;
-            for (int p = tid; p < S; p += NT) if (inc[p]) mpart += vb[p];
-            const double bmean = block_sum(mpart, red) / ninc;
-            double part = 0.0;
-            for (int p = tid; p < S; p += NT) if (inc[p]) part += (vb[p] - bmean) * vz[p];
-            const double nrm = sqrt(block_sum(part, red));
-            for (int p = tid; p < S; p += NT) {
-                BT[(size_t)c * S + p] = inc[p] ? (vb[p] - bmean) / nrm : 0.0;
-                KB[(size_t)c * S + p] = vz[p] / nrm;
-            }
-        }
-        __syncthreads();
-        // ---- deflate against the new basis vector, then against the previous ones
-        for (int pass = 0; pass <= c; ++pass) {
-            const int j = (pass == 0) ? c : pass - 1;
-            for (int t = 0; t < T; ++t) {
-                double part = 0.0;
-                for (int p = tid; p < S; p += NT) part += KB[(size_t)j * S + p] * Yd[(size_t)p * T + t];
-                const double g = block_sum(part, red);
-                if (tid == 0) gv[t] = g;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < S * T; idx += NT) {
-                const int p = idx / T, t = idx % T;
-                Yd[idx] -= BT[(size_t)j * S + p] * gv[t];
-                Z[idx] -= KB[(size_t)j * S + p] * gv[t];
-            }
-            for (int idx = tid; idx < T * T; idx += NT) {
-                const int t1 = idx / T, t2 = idx % T;
-                H[t2 * ldh + t1] -= gv[t1] * gv[t2];
-            }
-            __syncthreads();
-        }
+    int best = 0;
+    for (int col = 1; col < T; ++col) if (gv[col] > gv[best]) best = col;
+    const double lam = gv[best], si = sqrt(lam);
+    for (int t = tid; t < T; t += NT) {
+        cv[t] = Hw[best * ldh + t] / lam;
+        a.cvec[((size_t)r * T + t) * k + c] = cv[t];
     }
-
-    // ---- outputs for the bootstrap -------------------------------------------
-    // y_loadings (unsigned): Y[ys]^T (X[xs] W), Y NOT re-centred (regression.py:325)
-    for (int idx = tid; idx < T * k; idx += NT) {
-        const int t = idx / k, c = idx % k;
+    __syncthreads();
+    for (int j = tid; j < c; j += NT) {
         double s = 0.0;
-        for (int p = 0; p < S; ++p) if (inc[p]) s += Ysrc[(size_t)ys[p] * T + t] * XW[(size_t)c * S + p];
+        for (int t = 0; t < T; ++t) s += G[(size_t)j * T + t] * cv[t];
+        gc[j] = s;
+    }
+    __syncthreads();
+    // a = Yd c / s, t = Z c / s in factored form
+    double n2 = 0.0, asum = 0.0;
+    for (int p = tid; p < S; p += NT) {
+        double ya = 0.0, za = 0.0;
+        for (int t = 0; t < T; ++t) { ya += Y0[(size_t)p * T + t] * cv[t]; za += Z0[(size_t)p * T + t] * cv[t]; }
+        for (int j = 0; j < c; ++j) { ya -= BT[(size_t)j * S + p] * gc[j]; za -= KB[(size_t)j * S + p] * gc[j]; }
+        ya /= si; za /= si;
+        va[p] = ya; vt[p] = za;
+        n2 += za * za;
+        if (xs[p] >= 0) asum += ya;
+    }
+    const double normt = sqrt(block_sum(n2, red));
+    const double amean = block_sum(asum, red) / ninc;
+    double mu = 0.0;
+    for (int p = tid; p < S; p += NT) {
+        const double ac = xs[p] >= 0 ? va[p] - amean : 0.0;
+        a.WD[((size_t)r * k + c) * S + p] = ac / normt;
+        mu += ac * kcpos[p];
+    }
+    mu = block_sum(mu, red) / ninc;            // mean over positions of the un-centred product X[xs] r
+    for (int p = tid; p < S; p += NT) {
+        a.XW[((size_t)r * k + c) * S + p] = xs[p] >= 0 ? (vt[p] + mu) / normt : 0.0;
+        vt[p] /= normt;                        // t_c, then beta
+    }
+    // y_loadings q = Y0^T t = (H0 c - sum_j gY0_j gc_j) / (s |t|)  -> pctvar
+    double q2 = 0.0;
+    for (int t = tid; t < T; t += NT) {
+        double s = 0.0;
+        for (int u = 0; u < T; ++u) s += H0[(size_t)t * T + u] * cv[u];
+        for (int j = 0; j < c; ++j) s -= gY0[(size_t)j * T + t] * gc[j];
+        s /= si * normt;
+        q2 += s * s;
+    }
+    q2 = block_sum(q2, red);
+    if (tid == 0) a.pctvar[(size_t)r * k + c] = q2 / ssY;
+    // basis: beta = t, MGS x 2 against the previous (v_j^T v = (K beta_j)^T beta), centre
+    for (int rep = 0; rep < 2; ++rep)
+        for (int j = 0; j < c; ++j) {
+            double part = 0.0;
+            for (int p = tid; p < S; p += NT) part += KB[(size_t)j * S + p] * vt[p];
+            const double coef = block_sum(part, red);
+            for (int p = tid; p < S; p += NT) vt[p] -= coef * BT[(size_t)j * S + p];
+        }
+    double bs = 0.0;
+    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) bs += vt[p];
+    const double bmean = block_sum(bs, red) / ninc;
+    for (int i = tid; i < S; i += NT) buf[i] = 0.0;
+    __syncthreads();
+    for (int p = tid; p < S; p += NT) {
+        const double bc = xs[p] >= 0 ? vt[p] - bmean : 0.0;
+        va[p] = bc;                            // centred beta, consumed by k_sd_comp_b
+        if (xs[p] >= 0) atomicAdd(&buf[xs[p]], bc);
+    }
+    __syncthreads();
+    for (int i = tid; i < S; i += NT) a.Wt[(size_t)r * S + i] = buf[i];
+}
+
+// Component c, second half (after GEMM c): K beta gathered and centred, the new
+// basis pair, deflation coefficients g = (K beta)^T Yd, H -= g g^T.
+// dynamic LDS: 4 T + k + 32 doubles.
+__global__ __launch_bounds__(256)
+void k_sd_comp_b(SdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
+    const int S = a.S, T = a.T, k = a.k, c = a.c, tid = threadIdx.x, NT = blockDim.x;
+    double* gq = sm_sd;                       // [4][T] quarter sums
+    double* mj = gq + 4 * T;                  // [k]
+    double* red = mj + k;                     // [32]
+    const int r = blockIdx.x;
+    const int* xs = a.xs + (size_t)r * S;
+    const double* Y0 = a.Y0 + (size_t)r * S * T;
+    const double* Zt = a.Zt + (size_t)r * S;
+    double* BT = a.BT + (size_t)r * k * S;
+    double* KB = a.KB + (size_t)r * k * S;
+    const double* bcv = a.va + (size_t)r * S;
+    double* G = a.G + (size_t)r * k * T;
+    double* gY0 = a.gY0 + (size_t)r * k * T;
+    double* H = a.H + (size_t)r * T * T;
+    const double ninc = a.scal[(size_t)r * 4];
+    double part = 0.0;
+    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Zt[xs[p]];
+    const double zmean = block_sum(part, red) / ninc;
+    part = 0.0;
+    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += bcv[p] * (Zt[xs[p]] - zmean);
+    const double nrm = sqrt(block_sum(part, red));
+    for (int p = tid; p < S; p += NT) {
+        BT[(size_t)c * S + p] = bcv[p] / nrm;
+        KB[(size_t)c * S + p] = xs[p] >= 0 ? (Zt[xs[p]] - zmean) / nrm : 0.0;
+    }
+    __syncthreads();
+    // gY0_c[t] = sum_p KB_c[p] Y0[p][t]: four quarters of the rows per column, fixed order
+    for (int idx = tid; idx < 4 * T; idx += NT) {
+        const int q = idx / T, t = idx - q * T;
+        const int p0 = (int)((long long)S * q / 4), p1 = (int)((long long)S * (q + 1) / 4);
+        double s = 0.0;
+        for (int p = p0; p < p1; ++p) s += KB[(size_t)c * S + p] * Y0[(size_t)p * T + t];
+        gq[idx] = s;
+    }
+    for (int j = tid; j < c; j += NT) {
+        double s = 0.0;
+        for (int p = 0; p < S; ++p) s += KB[(size_t)c * S + p] * BT[(size_t)j * S + p];
+        mj[j] = s;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += NT) {
+        const double gy = gq[t] + gq[T + t] + gq[2 * T + t] + gq[3 * T + t];
+        gY0[(size_t)c * T + t] = gy;
+        double g = gy;
+        for (int j = 0; j < c; ++j) g -= mj[j] * G[(size_t)j * T + t];
+        G[(size_t)c * T + t] = g;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * T; idx += NT) {
+        const int t1 = idx / T, t2 = idx - t1 * T;
+        H[idx] -= G[(size_t)c * T + t1] * G[(size_t)c * T + t2];
+    }
+}
+
+// Outputs for the bootstrap: y_loadings (unsigned) = Y[ys]^T (X[xs] W), Y NOT
+// re-centred (regression.py:325); dual weights scattered into k_xprod's A operand.
+__global__ __launch_bounds__(256)
+void k_sd_final(SdArgs a)
+{
+    const int S = a.S, T = a.T, k = a.k, tid = threadIdx.x, NT = blockDim.x;
+    const int r = blockIdx.x;
+    const int* xs = a.xs + (size_t)r * S;
+    const int* ys = a.ys + (size_t)r * S;
+    const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
+    const double* XW = a.XW + (size_t)r * k * S;
+    const double* WD = a.WD + (size_t)r * k * S;
+    for (int idx = tid; idx < T * k; idx += NT) {
+        const int t = idx / k, c = idx - t * k;
+        double s = 0.0;
+        for (int p = 0; p < S; ++p) if (xs[p] >= 0) s += Ysrc[(size_t)ys[p] * T + t] * XW[(size_t)c * S + p];
         a.yload[((size_t)r * T + t) * k + c] = s;
     }
     if (a.Afrag) {
         const int g = r / a.lay.n, rr = r % a.lay.n;
         double* A = a.Afrag + (size_t)g * a.group_stride;
         for (int idx = tid; idx < S * k; idx += NT) {
-            const int c = idx / S, p = idx % S;
-            if (inc[p]) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
+            const int c = idx / S, p = idx - c * S;
+            if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
         }
     }
 }

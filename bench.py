@@ -557,6 +557,7 @@ def main():
     if isinstance(wl, PLSC) and dual and not args.no_primal:
         eng.set_perm_path(False)
         elapsed_primal = timed_region()
+        kt_p = eng.kernel_timing()
         legs_p = [[e[j].elapsed_time(e[j + 1]) for j in range(3)] for e in wl.legs]
         eng.set_timing(False)
         eng.set_perm_path(True)
@@ -596,6 +597,7 @@ def main():
                 out['value_primal'] = units * args.steps / elapsed_primal
                 out['ms_per_step_primal'] = 1e3 * elapsed_primal / args.steps
                 cfgd['perm_ms_per_step_primal'] = float(np.mean([l[0] for l in legs_p]))
+                cfgd['kernel_ms_per_step_primal'] = {k: v[0] / args.steps for k, v in kt_p.items()}
                 pm, ph = wl.pipeline(out['ms_per_step_primal'], primal=True)
                 roof['pipeline_frac_mfma_primal'], roof['pipeline_frac_hbm_primal'] = pm, ph
             elif not dual:

@@ -509,10 +509,11 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
 // E (Erows x B, leading dimension Bpad) is shared by all resamples (U0^T for the
 // bootstrap, the full-sample R for split-half).  T' <= 64 uses the
 // register-streamed k_gram, larger T' the generic tiled k_nt_gemm.
-template <int NB, bool WG>
+// NLB = 0: the Gram matrix alone (permutations through the feature pass, decompositions).
+template <int NB, int NLB, bool WG>
 int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Pout, hipStream_t st)
 {
-    const void* kfn = reinterpret_cast<const void*>(k_gram4<NB, NB, WG>);
+    const void* kfn = reinterpret_cast<const void*>(k_gram4<NB, NLB, WG>);
     const int nblk = ceil_div(nres, 4);
     const int maxchunk = std::max(1, ctx->B / 512);
     int nchunk = std::max(1, ceil_div(2048, nblk));
@@ -523,9 +524,9 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
     nchunk = ceil_div(ctx->B, cols);
     if (int e = ensure(ctx, ctx->part, (size_t)nchunk * nres * 2 * 4096 * 8)) return e;
     double* part = ptr<double>(ctx->part);
-    constexpr size_t lds = (size_t)2 * (NB + (NB + 3) / 4) * 128 * 8;
+    constexpr size_t lds = (size_t)2 * (NB + (NLB + 3) / 4) * 128 * 8;
     KTimer tm(ctx, KC_GRAM, st);
-    hipLaunchKernelGGL((k_gram4<NB, NB, WG>), dim3(nchunk, nblk), dim3(256), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_gram4<NB, NLB, WG>), dim3(nchunk, nblk), dim3(256), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres);
     LAUNCHCHK();
     const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
@@ -535,7 +536,7 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
                            sG, ctx->Tp, ctx->Tp, ctx->Tp, 2);
         LAUNCHCHK();
     }
-    {
+    if (NLB > 0) {
         dim3 g(ceil_div(ctx->Tp * Erows, 256), nres);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, part, nchunk, nres, 1, 1, 1, Pout, sP, Erows,
                            ctx->Tp, Erows, 0);
@@ -544,12 +545,14 @@ int launch_gram4(plsx_ctx* ctx, int nres, const double* E, int Erows, double* Po
     return 0;
 }
 
-int run_gram4(plsx_ctx* ctx, int nres, int nb4, bool with_g, const double* E, int Erows, double* Pout,
+// mode 0: G only, 1: G and P, 2: P only
+int run_gram4(plsx_ctx* ctx, int nres, int nb4, int mode, const double* E, int Erows, double* Pout,
               hipStream_t st)
 {
     switch (nb4) {
-#define G4CASE(N) case N: return with_g ? launch_gram4<N, true>(ctx, nres, E, Erows, Pout, st) \
-                                      : launch_gram4<N, false>(ctx, nres, E, Erows, Pout, st);
+#define G4CASE(N) case N: return mode == 0 ? launch_gram4<N, 0, true>(ctx, nres, nullptr, 0, nullptr, st) \
+                               : mode == 1 ? launch_gram4<N, N, true>(ctx, nres, E, Erows, Pout, st)         \
+                                           : launch_gram4<N, N, false>(ctx, nres, E, Erows, Pout, st);
     G4CASE(1) G4CASE(2) G4CASE(3) G4CASE(4) G4CASE(5) G4CASE(6) G4CASE(7) G4CASE(8)
     G4CASE(9) G4CASE(10) G4CASE(11) G4CASE(12) G4CASE(13)
 #undef G4CASE
@@ -577,9 +580,9 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
         const bool no4 = getenv("PLSX_NO_GRAM4") != nullptr;
         const int nb4 = ceil_div(ctx->Tp, 4);
         // (14+ row blocks would spill at two waves per SIMD: T' > 52 keeps the 16x16x4 kernel)
-        if (!no4 && mode != 0 && nb4 <= 13 && ceil_div(Erows, 4) == nb4 && 4 * ctx->strideR * 8 < (1LL << 31) &&
+        if (!no4 && nb4 <= 13 && (mode == 0 || ceil_div(Erows, 4) == nb4) && 4 * ctx->strideR * 8 < (1LL << 31) &&
             (long long)Erows * ctx->Bpad * 8 < (1LL << 31))
-            return run_gram4(ctx, nres, nb4, mode == 1, E, Erows, Pout, st);
+            return run_gram4(ctx, nres, nb4, mode, E, Erows, Pout, st);
     }
     const void* kfn = (mode == 0) ? reinterpret_cast<const void*>(k_gram<0>)
                     : (mode == 1) ? reinterpret_cast<const void*>(k_gram<1>)

@@ -1228,12 +1228,19 @@ namespace {
 // First halves of m splits through the cross-product kernel as raw sums; its
 // epilogue writes both halves of split i to R slots 2i and 2i + 1 (see SplitEpi).
 template <int NSQ>
-int launch_xprod_split(plsx_ctx* ctx, int groups, const SplitEpi& se, hipStream_t st)
+int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
 {
-    constexpr int MT = 24, NW = 4, KT = 1, NMOM = NSQ * 16;
-    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
-    const size_t epi = (size_t)NW * 5 * NMOM * 16 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
-    const size_t lds = std::max(stage, epi);
+    constexpr int MT = 24, NW = 4, KT = 1;
+    // LDS (doubles): region 0 = the two A stages, reused by the epilogue for its per-wave
+    // column tables [NW][5][nmu][16] and the row maps; then, when it fits next to a second
+    // resident block, the DMA-prefetched tile of Rfull [Tpp][64] and the row constants.
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128;
+    se.nmu = ctx->npg * ctx->J;
+    const size_t epi0 = (size_t)NW * 5 * se.nmu * 16 + (size_t)MT * 16;
+    const size_t pre0 = round_up((int)std::max(stage, epi0), 128);
+    const size_t pre_total = pre0 + (size_t)ctx->Tpp * NW * 16 + (size_t)MT * 16 * 5;
+    se.off_pre = (pre_total * 8 <= 80 * 1024 && !(ctx->tune & 16)) ? (int)pre0 : 0;
+    const size_t lds = se.off_pre ? pre_total * 8 : std::max(stage, epi0 + (size_t)MT * 16 * 5) * 8;
     HIPCHK(set_lds(k_xprod<MT, NW, KT, NSQ, true>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
     KTimer tm(ctx, KC_XPROD, st);

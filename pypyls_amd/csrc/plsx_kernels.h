@@ -304,6 +304,9 @@ struct SplitEpi {
     const double* rowc;      // [groups][MT*16][5]: Sy1, 1/((n1-1) sy1), Sy2, 1/((n2-1) sy2), (nF-1) syF
     int J, Tpp;
     int tune;                // PLSX_TUNE measurement switches (0 in production)
+    int nmu;                 // moment rows in use (splits per group x cells)
+    int off_pre;             // > 0: doubles offset of the LDS region that receives this block's tile of
+                             // Rfull ([Tpp][64]) and its row constants by DMA at kernel start
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
@@ -498,6 +501,29 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         const int n = (blockIdx.x * 37 % 64) * (se.tune >> 8);
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    if constexpr (SPLIT) {
+        // Fused split-half: the epilogue needs this block's (Tpp x 64) tile of the
+        // arrangement's full-sample R and the group's row constants.  Fetched here by
+        // LDS-DMA (they land during the main loop), the epilogue then has NO global
+        // load between its stores: on gfx950 loads and stores share vmcnt, so a load
+        // waited for in the store loop drains every store before it (measured: the
+        // interleaved form cost 20 % of the kernel).
+        if (se.off_pre > 0 && NW == 4) {
+            double* sRf = smem + se.off_pre;
+            double* sRc = sRf + se.Tpp * (NW * 16);
+            __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(se.Rfull + (size_t)colblk * (NW * 16)), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+            const int vo = ((lane >> 5) * ldr + (lane & 31) * 2) * 8;
+            for (int j = swave; j < se.Tpp / 2; j += NW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsF, (__attribute__((address_space(3))) void*)(sRf + j * 128), 16, vo, j * 2 * ldr * 8, 0, 0);
+            __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(se.rowc + (size_t)grp * MT * 16 * 5), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+            for (int pc = swave; pc < MT * 16 * 5 / 128; pc += NW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsC, (__attribute__((address_space(3))) void*)(sRc + pc * 128), 16, lane * 16, pc * 1024, 0, 0);
+        }
+    }
     // prologue: stage 0 of A, first X fragments
     stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
     double xb[KT];
@@ -544,18 +570,31 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
     if constexpr (SPLIT && NSQ > 0) {
         // fused split-half: both halves from the first half's raw sums (see SplitEpi)
-        double* w5 = smem + wave * (5 * NMOM * 16);          // u1, v1, u2, v2, sF : [5][NMOM][16] per wave
-        int* s_out = reinterpret_cast<int*>(smem + NW * 5 * NMOM * 16);
+        const int nmu = se.nmu;
+        const bool pre = se.off_pre > 0 && NW == 4;
+        double* w5 = smem + wave * (5 * nmu * 16);           // u1, v1, u2, v2, sF : [5][nmu][16] per wave
+        int* s_out = reinterpret_cast<int*>(smem + NW * 5 * nmu * 16);
         int* s_mom = s_out + MT * 16;
-        double* s_rc = reinterpret_cast<double*>(s_mom + MT * 16);   // [MT*16][5]
-        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }    // (ntab == 1)
-        for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
+        const double* sRf = smem + se.off_pre;               // [Tpp][64] tile of Rfull (pre)
+        double* s_rc = pre ? smem + se.off_pre + se.Tpp * (NW * 16)
+                           : reinterpret_cast<double*>(s_mom + MT * 16);   // [MT*16][5]
+        // row maps (ntab == 1); the R row inside the arrangement (orow mod 2 Tpp) rides in the
+        // upper half of the word so the store loop does no integer division
+        const int pitch2 = 2 * se.Tpp;
+        for (int i = tid; i < MT * 16; i += NT) {
+            const int orw = out_row[i];
+            s_out[i] = orw < 0 ? -1 : (orw | ((orw % pitch2) << 20));
+            s_mom[i] = mom_idx[i];
+        }
+        if (!pre)
+            for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
         // moments of the first half sit in the accumulators of tiles W0+j / SQ0+j
 #pragma unroll
         for (int j = 0; j < NSQ; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int mr = j * 16 + kq + 4 * i;
+                if (mr >= nmu) continue;
                 const int o = mr * 16 + (lane & 15);
                 const double n1 = mom_n[(size_t)grp * nmom_pad + mr];
                 const double m1 = acc[W0 + j][i], m2 = acc[SQ0 + j][i];
@@ -568,33 +607,34 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const double s2x = SF - m1, s2xx = SFF - m2;
                 const double var2 = ok ? (s2xx - s2x * s2x / n2) / (n2 - 1.0) : 0.0;
                 const double varF = (SFF - SF * SF / nF) / (nF - 1.0);
-                w5[0 * NMOM * 16 + o] = ok ? m1 / n1 : 0.0;
-                w5[1 * NMOM * 16 + o] = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
-                w5[2 * NMOM * 16 + o] = ok ? s2x / n2 : 0.0;
-                w5[3 * NMOM * 16 + o] = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
-                w5[4 * NMOM * 16 + o] = (varF > 0.0) ? sqrt(varF) : 0.0;
+                w5[0 * nmu * 16 + o] = ok ? m1 / n1 : 0.0;
+                w5[1 * nmu * 16 + o] = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
+                w5[2 * nmu * 16 + o] = ok ? s2x / n2 : 0.0;
+                w5[3 * nmu * 16 + o] = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
+                w5[4 * nmu * 16 + o] = (varF > 0.0) ? sqrt(varF) : 0.0;
             }
         __syncthreads();
         double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
-        const int pitch2 = 2 * se.Tpp;
 #pragma unroll
         for (int m = 0; m < W0; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = m * 16 + kq + 4 * i;
-                const int orow = s_out[row];
-                if (orow < 0) continue;
+                const int packed = s_out[row];
+                if (packed < 0) continue;
+                const int orow = packed & 0xfffff, t = packed >> 20;
                 const int o = s_mom[row] * 16 + (lane & 15);
                 const double* rc = s_rc + row * 5;
-                const int t = orow % pitch2;
                 const double c1 = acc[m][i];
-                const double rf = (se.tune & 2) ? 1.0 : se.Rfull[(size_t)t * ldr + col];
-                const double cf = rf * rc[4] * w5[4 * NMOM * 16 + o];
-                const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * NMOM * 16 + o];
-                const double r2 = ((cf - c1) - rc[2] * w5[2 * NMOM * 16 + o]) * rc[3] * w5[3 * NMOM * 16 + o];
+                const double rf = pre ? sRf[t * (NW * 16) + wave * 16 + (lane & 15)]
+                                      : ((se.tune & 2) ? 1.0 : se.Rfull[(size_t)t * ldr + col]);
+                const double cf = rf * rc[4] * w5[4 * nmu * 16 + o];
+                const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * nmu * 16 + o];
+                const double r2 = ((cf - c1) - rc[2] * w5[2 * nmu * 16 + o]) * rc[3] * w5[3 * nmu * 16 + o];
+                // non-temporal: the 2 x 83 MB per split are read back from HBM by later kernels
                 if (!(se.tune & 1) || r1 == 123.456) {
-                    Rg[(size_t)orow * ldr] = r1;
-                    Rg[(size_t)(orow + se.Tpp) * ldr] = r2;
+                    __builtin_nontemporal_store(r1, &Rg[(size_t)orow * ldr]);
+                    __builtin_nontemporal_store(r2, &Rg[(size_t)(orow + se.Tpp) * ldr]);
                 }
             }
         return;

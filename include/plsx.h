@@ -281,6 +281,29 @@ const char* plsx_kernel_class_name(int kernel_class);
  * Equivalent environment switch at bind time: PLSX_NO_DUAL_PERM=1. */
 int plsx_set_perm_path(plsx_ctx* ctx, int dual);
 
+/*
+ * Host-side index generators -- gen_permsamp / gen_bootsamp / gen_splits
+ * (pyls/base.py:10-79, 82-159, 162-229), draw-for-draw compatible with the
+ * reference's numpy.random.RandomState so a seed gives the same arrays.  No
+ * device and no context involved.  The generator state travels as numpy's
+ * `RandomState.get_state()` pair: mt_key (624 words, in/out) and *mt_pos
+ * (in/out).  groups (n_groups,) subjects per group; output one resample per
+ * ROW: (n, S) int32 indices / (n_split, S) uint8 masks (1 = first half /
+ * training row).  Return 0, 1 when the 500-try duplicate limit was hit (the
+ * reference warns, base.py:70-74), or a negative status.
+ * plsx_gen_splits_seeded draws the masks of n_seeds independent
+ * RandomState(seeds[i]) streams (what permutation i uses, base.py:705-708):
+ * out (n_seeds, n_split, S).
+ */
+int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
+                      int32_t* out);
+int plsx_gen_bootsamp(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
+                      int32_t* out);
+int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
+                    uint32_t* mt_key, int* mt_pos, uint8_t* out);
+int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
+                           const uint32_t* seeds, int n_seeds, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'plsx_api.hip')
 DEPS = [SRC, os.path.join(HERE, 'csrc', 'plsx_kernels.h'), os.path.join(HERE, 'csrc', 'plsx_simpls.h'),
+        os.path.join(HERE, 'csrc', 'plsx_resample.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')]
 LIB = os.path.join(HERE, 'libplsx.so')
 
@@ -29,7 +30,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libplsx.so')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-munsafe-fp-atomics', SRC, '-o', LIB]
+           '-munsafe-fp-atomics', '-pthread', SRC, '-o', LIB]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)

@@ -2,6 +2,7 @@
 // C ABI declared in include/plsx.h.  gfx950 only.
 #include "plsx_kernels.h"
 #include "plsx_simpls.h"
+#include "plsx_resample.h"
 #include <chrono>
 #include "../../include/plsx.h"
 
@@ -11,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1779,6 +1781,84 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual)
     NEED_DATA();
     ctx->dual = (dual && ctx->dual_ok) ? 1 : 0;
     return ctx->dual;
+}
+
+// ---- host-side index generators (no device, no context) ------------------------
+namespace {
+int load_mt(plsx_rs::MT& rs, const uint32_t* key, int pos)
+{
+    if (!key || pos < 0 || pos > 624) return PLSX_ERR_ARG;
+    memcpy(rs.key, key, sizeof(rs.key));
+    rs.pos = pos;
+    return 0;
+}
+bool bad_design(const int* groups, int n_groups, int n_cond)
+{
+    if (!groups || n_groups < 1 || n_cond < 1) return true;
+    for (int i = 0; i < n_groups; ++i) if (groups[i] < 1) return true;
+    return false;
+}
+}  // namespace
+
+int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
+                      int32_t* out)
+{
+    plsx_rs::MT rs;
+    if (bad_design(groups, n_groups, n_cond) || n_perm < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
+        return PLSX_ERR_ARG;
+    const int w = plsx_rs::gen_permsamp(plsx_rs::Design(groups, n_groups, n_cond), n_perm, rs, out);
+    memcpy(mt_key, rs.key, sizeof(rs.key));
+    *mt_pos = rs.pos;
+    return w;
+}
+
+int plsx_gen_bootsamp(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
+                      int32_t* out)
+{
+    plsx_rs::MT rs;
+    if (bad_design(groups, n_groups, n_cond) || n_boot < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
+        return PLSX_ERR_ARG;
+    const int w = plsx_rs::gen_bootsamp(plsx_rs::Design(groups, n_groups, n_cond), n_boot, rs, out);
+    memcpy(mt_key, rs.key, sizeof(rs.key));
+    *mt_pos = rs.pos;
+    return w;
+}
+
+int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, double test_size, uint32_t* mt_key,
+                    int* mt_pos, uint8_t* out)
+{
+    plsx_rs::MT rs;
+    if (bad_design(groups, n_groups, n_cond) || n_split < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
+        return PLSX_ERR_ARG;
+    const int w = plsx_rs::gen_splits(plsx_rs::Design(groups, n_groups, n_cond), n_split, test_size, rs, out);
+    memcpy(mt_key, rs.key, sizeof(rs.key));
+    *mt_pos = rs.pos;
+    return w;
+}
+
+int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
+                           const uint32_t* seeds, int n_seeds, uint8_t* out)
+{
+    if (bad_design(groups, n_groups, n_cond) || n_split < 0 || n_seeds < 0 || !out || (n_seeds && !seeds))
+        return PLSX_ERR_ARG;
+    const plsx_rs::Design d(groups, n_groups, n_cond);
+    // independent streams: spread over host threads
+    const int nth = (int)std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)((n_seeds + 15) / 16)}));
+    std::vector<int> warn(nth, 0);
+    auto work = [&](int t) {
+        for (int i = t; i < n_seeds; i += nth) {
+            plsx_rs::MT rs;
+            rs.seed(seeds[i]);
+            warn[t] |= plsx_rs::gen_splits(d, n_split, test_size, rs, out + (size_t)i * n_split * d.n_rows);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    int w = 0;
+    for (int v : warn) w |= v;
+    return w;
 }
 
 }  // extern "C"

@@ -75,6 +75,10 @@ def _load():
         'plsx_simpls_perm_batch': ([vp, vp, i32, vp, vp], i32),
         'plsx_simpls_boot_batch': ([vp, vp, vp, i32, vp, vp, vp, vp], i32),
         'plsx_simpls_set_row_masks': ([vp, vp, vp, vp], i32),
+        'plsx_gen_permsamp': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp], i32),
+        'plsx_gen_bootsamp': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp], i32),
+        'plsx_gen_splits': ([vp, i32, i32, i32, c_d, vp, ctypes.POINTER(i32), vp], i32),
+        'plsx_gen_splits_seeded': ([vp, i32, i32, i32, c_d, vp, i32, vp], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -94,7 +98,8 @@ def exported_symbols():
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_kernel_timing',
              'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
-             'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks']
+             'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
+             'plsx_gen_splits', 'plsx_gen_splits_seeded']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -295,7 +300,7 @@ class Engine(object):
         self.sync()
         return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
 
-    def split_half(self, masks, perms=None, ystack=None):
+    def split_half(self, masks, perms=None, ystack=None, mask_rows=False):
         """Per-split correlations.  masks (np, S, ns) bool: one (S, ns) gen_splits
         array per arrangement; perms (S, np) index array, or ystack (np, S, T)
         pre-permuted behaviour matrices, or neither (original data).
@@ -304,10 +309,16 @@ class Engine(object):
         masks = np.asarray(masks)
         if masks.ndim == 2:
             masks = masks[None]
-        n_arr, S, ns = masks.shape
+        if mask_rows:                                   # (np, ns, S) uint8 as the device consumes them
+            n_arr, ns, S = masks.shape
+        else:
+            n_arr, S, ns = masks.shape
         if S != self.S:
             raise ValueError('split masks must have S = {} rows'.format(self.S))
-        dm = torch.from_numpy(np.ascontiguousarray(masks.transpose(0, 2, 1), dtype=np.uint8)).to(self.device)
+        if mask_rows:
+            dm = torch.from_numpy(np.ascontiguousarray(masks, dtype=np.uint8)).to(self.device)
+        else:
+            dm = torch.from_numpy(np.ascontiguousarray(masks.transpose(0, 2, 1), dtype=np.uint8)).to(self.device)
         dp = None
         if perms is not None:
             dp = self._index_rows(perms)

@@ -160,16 +160,16 @@ class _PLSCRun(object):
             lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
             pmasks = inp.get('_perm_splitsamples')
             if pmasks is None:
-                pmasks = np.stack([resampling.gen_splits(inp.groups, inp.n_cond, n_split, seed=i,
-                                                         test_size=0.5) for i in range(lo, hi)]) \
-                    if hi > lo else np.zeros((0, len(X), n_split), bool)
+                pmasks = resampling.gen_splits_seeded(inp.groups, inp.n_cond, n_split, np.arange(lo, hi),
+                                                      test_size=0.5, rows=True)
+                rows = True
             else:
-                pmasks = np.asarray(pmasks)[lo:hi]
+                pmasks, rows = np.asarray(pmasks)[lo:hi], False
             if hi > lo:
                 if ystack is not None:
-                    uc, vc = eng.split_half(pmasks, ystack=ystack[lo:hi])
+                    uc, vc = eng.split_half(pmasks, ystack=ystack[lo:hi], mask_rows=rows)
                 else:
-                    uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi])
+                    uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi], mask_rows=rows)
                 local_uc, local_vc = uc.mean(axis=-1).T, vc.mean(axis=-1).T      # (L, p_loc)
             else:
                 local_uc = local_vc = np.zeros((L, 0))

@@ -101,3 +101,59 @@ def test_dummy_coding():
     np.testing.assert_array_equal(rsmp.cell_of_row([2], 2), [0, 0, 1, 1])
     with pytest.raises(ValueError):
         rsmp.check_random_state('nope')
+
+
+DESIGNS = [([6], 1), ([20], 1), ([5, 7], 1), ([4, 6, 5], 2), ([9], 3), ([3, 3], 4), ([500], 1), ([25, 25, 25, 25], 2)]
+
+
+@pytest.mark.parametrize('groups,n_cond', DESIGNS)
+def test_native_generators_equal_python_loops(groups, n_cond, monkeypatch):
+    """csrc/plsx_resample.h (MT19937 + numpy's legacy sampling, C++) against the Python
+    loops on numpy's own RandomState: same arrays AND the same stream position
+    afterwards (the stream is shared with later draws, pyls/base.py:362-380)."""
+    from pypyls_amd import resampling as rsmp
+    if rsmp._native() is None:
+        pytest.skip('libplsx.so not built')
+    n = 40 if sum(groups) > 100 else 25
+    for seed in (0, 1234, 2 ** 31 + 5):
+        for fn, py, kw in ((rsmp.gen_permsamp, rsmp._py_gen_permsamp, {}),
+                           (rsmp.gen_bootsamp, rsmp._py_gen_bootsamp, {}),
+                           (rsmp.gen_splits, rsmp._py_gen_splits, dict(test_size=0.5)),
+                           (rsmp.gen_splits, rsmp._py_gen_splits, dict(test_size=0.25))):
+            if py is rsmp._py_gen_permsamp and len(groups) == 1 and n_cond == 1 and groups[0] < 6:
+                continue
+            a_rs, b_rs = np.random.RandomState(seed), np.random.RandomState(seed)
+            a_rs.normal(size=3)                          # odd number of normals: a cached gaussian rides along
+            b_rs.normal(size=3)
+            nn = min(n, 8) if (py is rsmp._py_gen_splits and sum(groups) < 8) else n
+            got = fn(groups, n_cond, nn, seed=a_rs, **kw)
+            want = py(groups, n_cond, nn, b_rs, **kw)
+            assert got.shape == want.shape and got.dtype.kind == want.dtype.kind
+            np.testing.assert_array_equal(got, want)
+            np.testing.assert_array_equal(a_rs.random_sample(5), b_rs.random_sample(5))
+            assert a_rs.normal() == b_rs.normal()
+
+
+def test_native_seeded_splits_equal_per_seed_calls():
+    from pypyls_amd import resampling as rsmp
+    groups, n_cond = [7, 9], 2
+    seeds = np.array([0, 1, 2, 77, 4000000000])
+    got = rsmp.gen_splits_seeded(groups, n_cond, 6, seeds)
+    assert got.shape == (5, 32, 6) and got.dtype == bool
+    for i, sd in enumerate(seeds):
+        np.testing.assert_array_equal(got[i], rsmp._py_gen_splits(groups, n_cond, 6, int(sd)))
+    assert rsmp.gen_splits_seeded(groups, n_cond, 6, []).shape == (0, 32, 6)
+
+
+def test_native_generators_are_fast():
+    """10 000 index vectors of 500 subjects in well under a second (the Python loops
+    need ~0.5 s each; the point of the native path is multi-GPU strong scaling)."""
+    import time
+    from pypyls_amd import resampling as rsmp
+    if rsmp._native() is None:
+        pytest.skip('libplsx.so not built')
+    t0 = time.perf_counter()
+    p = rsmp.gen_permsamp([500], 1, 10000, seed=1)
+    b = rsmp.gen_bootsamp([500], 1, 10000, seed=2)
+    dt = time.perf_counter() - t0
+    assert p.shape == b.shape == (500, 10000) and dt < 1.0, dt

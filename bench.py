@@ -72,6 +72,8 @@ def self_launch(args):
     """--gpus N > 1 outside a launcher: spawn the N ranks."""
     import torch
     have = torch.cuda.device_count()
+    if os.environ.get('PLSX_BENCH_SHARE_GPU'):
+        have = max(have, args.gpus) if have else 0        # dry run: ranks share the visible GPU(s) (gloo only)
     if have < args.gpus:
         sys.stderr.write('bench.py: --gpus {} requested but only {} GPU(s) are visible\n'
                          .format(args.gpus, have))
@@ -494,7 +496,7 @@ def main():
     if args.gpus != world and rank == 0:
         sys.stderr.write('bench.py: --gpus {} but the launcher started {} rank(s); using {}\n'
                          .format(args.gpus, world, world))
-    if torch.cuda.device_count() < (world if world > 1 else 1):
+    if torch.cuda.device_count() < (world if world > 1 and not os.environ.get('PLSX_BENCH_SHARE_GPU') else 1):
         sys.stderr.write('bench.py: {} rank(s) but {} visible GPU(s)\n'.format(world, torch.cuda.device_count()))
         sys.exit(2)
     backend = os.environ.get('PLSX_BENCH_BACKEND', 'nccl')   # 'gloo' only for single-GPU dry runs

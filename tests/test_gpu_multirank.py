@@ -127,3 +127,33 @@ def test_collective_on_rccl_two_ranks(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
     _run_nccl(tmp_path, 2, 29552)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`bench.py --gpus 2` outside a launcher spawns two ranks itself and reports the
+    group's world size.  Dry run on one GPU: the ranks share it over gloo
+    (PLSX_BENCH_SHARE_GPU; RCCL refuses two ranks on one device)."""
+    import json
+    env = dict(os.environ, PLSX_BENCH_SHARE_GPU='1', PLSX_BENCH_BACKEND='gloo', PLSX_SCRATCH_GB='4')
+    env.pop('WORLD_SIZE', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+           '--B', '20000', '--perms', '56', '--boots', '56', '--cpu-sample', '0']
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    line = [l for l in proc.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['value_primal'] > 0
+    assert out['roofline']['bound'] in ('mfma', 'hbm') and out['config']['perms_per_step'] == 56
+    # strong mode: one analysis split over the two ranks, index generation inside the clock
+    proc = subprocess.run(cmd + ['--mode', 'strong', '--perms', '120', '--boots', '112', '--no-primal'], env=env,
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    # more ranks than GPUs without the dry-run switch: refused loudly
+    env2 = dict(env)
+    env2.pop('PLSX_BENCH_SHARE_GPU')
+    import torch
+    if torch.cuda.device_count() < 2:
+        proc = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
+        assert proc.returncode != 0 and 'visible' in proc.stderr

@@ -631,12 +631,16 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
     const int n = a.n, ld = n | 1;
     KTimer tm(ctx, KC_SMALL, st);
+    a.nres = nres;
     if (n > PLSX_LDS_TP) {
-        // work matrices in a global workspace (L2), bookkeeping vectors in LDS
-        if (int e = ensure(ctx, ctx->gws, (size_t)nres * 2 * n * ld * 8)) return e;
+        // work matrices in a global workspace, bookkeeping vectors in LDS.  Persistent
+        // blocks, one per CU (1024 threads each), walk the resamples.
+        const size_t ws = (size_t)2 * n * ld * 8;
+        const int nblk = std::min(nres, 256);
+        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e;
         a.gws = ptr<double>(ctx->gws);
         const size_t lds = (size_t)2 * n * 8 + (size_t)2 * n * 4 + 64;
-        hipLaunchKernelGGL(k_small<true>, dim3(nres), dim3(1024), lds, st, a);
+        hipLaunchKernelGGL(k_small<true>, dim3(nblk), dim3(1024), lds, st, a);
         LAUNCHCHK();
         return 0;
     }

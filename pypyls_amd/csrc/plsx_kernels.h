@@ -1314,17 +1314,16 @@ struct SmallArgs {
     double* out_d;     // DECOMP: (L)
     double* Mfrag;     // BOOT / DECOMP: [nres][nks_t][LT][64] fragment-ordered M (T' x L)
     int nks_t, LT;
-    double* gws;       // GWS: global workspace, 2 n (n|1) doubles per resample (T' > PLSX_LDS_TP)
+    double* gws;       // GWS: global workspace, 2 n (n|1) doubles per BLOCK (T' > PLSX_LDS_TP)
+    int nres;          // resamples of the launch (GWS: blocks are persistent and walk them)
 };
 
 // GWS = false: both n x n work matrices live in LDS (n <= PLSX_LDS_TP).
 // GWS = true: they live in a per-resample global workspace (L2); same code,
 // latency bound but one block per resample keeps the chip busy.
 template <bool GWS>
-__global__ __launch_bounds__(GWS ? 1024 : 256)
-void k_small(SmallArgs a)
+__device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm_s[];
     const int n = a.n, L = a.L;
     const int ld = n | 1;
     double* bufA = GWS ? a.gws + (size_t)blockIdx.x * 2 * n * ld : sm_s;     // n x ld
@@ -1336,7 +1335,6 @@ void k_small(SmallArgs a)
     __shared__ int s_flag;
     __shared__ double s_dmax;
     const int tid = threadIdx.x;
-    const int r = blockIdx.x;
     const double* G = a.G + (size_t)r * n * n;
 
     for (int idx = tid; idx < n * n; idx += blockDim.x) {
@@ -1470,6 +1468,25 @@ void k_small(SmallArgs a)
                     if (sig[c] > smin) s += bufV[c * ld + t] * bufA[c * ld + l] / sig[c];
             a.Mfrag[(size_t)r * tot + idx] = s;
         }
+    }
+}
+
+// GWS = false: one block per resample, work matrices in LDS.
+// GWS = true: the work matrices (2 n (n|1) doubles) live in global memory; one
+// resident 1024-thread block per CU walks the resamples (workspace per block, not
+// per resample).  The solver is LATENCY bound there, not bandwidth bound: with the
+// grid cut to 16 / 40 / 64 / 128 blocks so that the matrices stay inside the XCDs'
+// L2, T' = 200 took 6.9 / 3.5 / 2.1 / 1.1 ms per resample against 1.1 ms with all
+// 256 CUs busy -- time per block hardly moves, so every CU gets a block.
+template <bool GWS>
+__global__ __launch_bounds__(GWS ? 1024 : 256)
+void k_small(SmallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_s[];
+    if (!GWS) { small_solve<false>(a, blockIdx.x, sm_s); return; }
+    for (int r = blockIdx.x; r < a.nres; r += gridDim.x) {
+        small_solve<true>(a, r, sm_s);
+        __syncthreads();
     }
 }
 

@@ -800,16 +800,30 @@ void k_nt_gemm(NtArgs a)
 // bootstraps -- the per-wave imbalance costs more than the 19 % MFMA saved.)
 // ---------------------------------------------------------------------------
 // MODE 0: G only; 1: G and P; 2: P only (cross-Gram against a shared matrix).
+// T' > 64 (or L > 64): the outputs are tiled in 64 x 64 blocks, blockIdx.z = block
+// (tm, tn) of an nt_m x nt_n block grid (`tiles_n` = nt_n; 1 x 1 for T' <= 64): the A
+// operand takes rows 64 tm.. of R, the B operands rows 64 tn.. of R (G) / of U0^T (P).
+// z enumerates enum_n blocks per block row; `upper` = 1: the blocks tm <= tn < enum_n only
+// (k_reduce_part mirrors G with sym = 6); `upper` = 2: the blocks tm > tn (P of the lower part).
 template <int MODE>
 __global__ __launch_bounds__(256)
 void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
             const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
-            double* __restrict__ part, int nres)
+            double* __restrict__ part, int nres, int tiles_n = 1, int tiles_total = 1, int enum_n = 1,
+            int upper = 0)
 {
     constexpr bool WITH_P = (MODE != 0), WITH_G = (MODE != 2);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int chunk = blockIdx.x, r = blockIdx.y;
+    int tm = 0, tn = 0;
+    if (tiles_total > 1) {
+        int z = blockIdx.z;
+        if (upper == 1) { while (z >= enum_n - tm) { z -= enum_n - tm; ++tm; } tn = tm + z; }
+        else if (upper == 2) { tm = 1; while (z >= tm) { z -= tm; ++tm; } tn = z; }      // strictly lower blocks
+        else { tm = z / enum_n; tn = z - tm * enum_n; }
+    }
+    const int ra0 = 64 * tm, rb0 = 64 * tn;
     const int cbeg = chunk * cols_per_chunk;
     const int cend = min(B, cbeg + cols_per_chunk);
     const double* Rr = R + (size_t)r * strideR;
@@ -820,9 +834,9 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
     // which the reduction never reads.
     const double* pa[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) pa[a] = Rr + (size_t)min(16 * a + m, Tp - 1) * ldr + 2 * q;
-    const double* pb = Rr + (size_t)min(16 * w + m, Tp - 1) * ldr + 2 * q;
-    const double* pu = WITH_P ? U0T + (size_t)min(16 * w + m, L - 1) * ldu + 2 * q : nullptr;
+    for (int a = 0; a < 4; ++a) pa[a] = Rr + (size_t)min(ra0 + 16 * a + m, Tp - 1) * ldr + 2 * q;
+    const double* pb = Rr + (size_t)min(rb0 + 16 * w + m, Tp - 1) * ldr + 2 * q;
+    const double* pu = WITH_P ? U0T + (size_t)min(rb0 + 16 * w + m, L - 1) * ldu + 2 * q : nullptr;
     d4 accG[4], accP[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
@@ -885,15 +899,16 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
                 }
             }
     }
-    // partial tiles: [chunk][resample][which][64 x 64]
-    double* out = part + (((size_t)chunk * nres + r) * 2) * 4096;
+    // partial tiles: [chunk][resample][which][tile][64 x 64]
+    const size_t tt = (size_t)tiles_total;
+    double* out = part + (((size_t)chunk * nres + r) * 2) * tt * 4096 + (size_t)(tm * tiles_n + tn) * 4096;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 16 * a + q + 4 * i, col = 16 * w + m;
             if (WITH_G) out[row * 64 + col] = accG[a][i];
-            if (WITH_P) out[4096 + row * 64 + col] = accP[a][i];
+            if (WITH_P) out[tt * 4096 + row * 64 + col] = accP[a][i];
         }
 }
 

@@ -684,6 +684,17 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     const int n = a.n, ld = n | 1;
     KTimer tm(ctx, KC_SMALL, st);
     a.nres = nres;
+    // A (n x ld) + bookkeeping in LDS, V in a global workspace: up to n = 141
+    const size_t lds_mixed = ((size_t)n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
+    if (n > PLSX_LDS_TP && lds_mixed <= 160 * 1024 && !getenv("PLSX_SMALL_GWS")) {
+        const int nblk = std::min(nres, 512);
+        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * n * ld * 8)) return e;
+        a.gws = ptr<double>(ctx->gws);
+        HIPCHK(set_lds(k_small<SMALL_MIXED>, lds_mixed));
+        hipLaunchKernelGGL(k_small<SMALL_MIXED>, dim3(nblk), dim3(512), lds_mixed, st, a);
+        LAUNCHCHK();
+        return 0;
+    }
     if (n > PLSX_LDS_TP) {
         // work matrices in a global workspace, bookkeeping vectors in LDS.  Persistent
         // blocks, one per CU (1024 threads each), walk the resamples.
@@ -692,13 +703,13 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
         if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e;
         a.gws = ptr<double>(ctx->gws);
         const size_t lds = (size_t)2 * n * 8 + (size_t)2 * n * 4 + 64;
-        hipLaunchKernelGGL(k_small<true>, dim3(nblk), dim3(1024), lds, st, a);
+        hipLaunchKernelGGL(k_small<SMALL_GWS>, dim3(nblk), dim3(1024), lds, st, a);
         LAUNCHCHK();
         return 0;
     }
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
-    HIPCHK(set_lds(k_small<false>, lds));
-    hipLaunchKernelGGL(k_small<false>, dim3(nres), dim3(256), lds, st, a);
+    HIPCHK(set_lds(k_small<SMALL_LDS>, lds));
+    hipLaunchKernelGGL(k_small<SMALL_LDS>, dim3(nres), dim3(256), lds, st, a);
     LAUNCHCHK();
     return 0;
 }

@@ -1201,6 +1201,74 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
     }
 }
 
+// A in LDS, V in global memory (SMALL_MIXED).  The V columns of a pair are requested
+// BEFORE the dot products over A, so their L2 round trip runs under the on-chip work of
+// the same step; only the write-back is left in front of the step's barrier.
+template <int IT>
+__device__ void jacobi_cols_mixed(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+{
+    const int tid = threadIdx.x;
+    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
+    const int np = (n + 1) >> 1, ne = np * 2;
+    const double tol = 1e-15;
+    __shared__ double s_amax;
+    const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int step = 0; step < ne - 1; ++step) {
+            for (int pr = grp; pr < np; pr += ngrp) {
+                int p, q;
+                if (pr == 0) { p = step; q = ne - 1; }
+                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= n) continue;
+                double* vp = V + (size_t)p * ld + sub;
+                double* vq = V + (size_t)q * ld + sub;
+                double vx[IT], vy[IT];
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const bool ok = sub + 8 * i < mv;
+                    vx[i] = ok ? vp[8 * i] : 0.0;
+                    vy[i] = ok ? vq[8 * i] : 0.0;
+                }
+                double* ap = A + (size_t)p * ld;
+                double* aq = A + (size_t)q * ld;
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = sub; i < m; i += 8) {
+                    double x = ap[i], y = aq[i];
+                    alpha += x * x; beta += y * y; gamma += x * y;
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    alpha += __shfl_xor(alpha, o);
+                    beta += __shfl_xor(beta, o);
+                    gamma += __shfl_xor(gamma, o);
+                }
+                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = sub; i < m; i += 8) {
+                    double x = ap[i], y = aq[i];
+                    ap[i] = c * x - s * y; aq[i] = s * x + c * y;
+                }
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+                    if (sub + 8 * i < mv) {
+                        vp[8 * i] = c * vx[i] - s * vy[i];
+                        vq[8 * i] = s * vx[i] + c * vy[i];
+                    }
+                if (sub == 0) *flag = 1;
+            }
+            __syncthreads();
+        }
+        const int any = *flag;
+        __syncthreads();
+        if (!any) break;
+    }
+}
+
 // Same algorithm for work matrices in GLOBAL memory (T' > PLSX_LDS_TP).  Every
 // access is an L2 round trip (~2 us when the same lines were just written), so
 // the step time is (passes over the pairs) x (round trips per pass): the block
@@ -1333,17 +1401,23 @@ struct SmallArgs {
     int nres;          // resamples of the launch (GWS: blocks are persistent and walk them)
 };
 
-// GWS = false: both n x n work matrices live in LDS (n <= PLSX_LDS_TP).
-// GWS = true: they live in a per-resample global workspace (L2); same code,
-// latency bound but one block per resample keeps the chip busy.
-template <bool GWS>
+// Where the two n x (n|1) work matrices live:
+//   SMALL_LDS   both in LDS (n <= PLSX_LDS_TP = 96)
+//   SMALL_MIXED the rotated matrix A in LDS, the accumulator V in a global workspace
+//               (n <= 141): every dot product and rotation of the convergence-critical
+//               matrix stays on chip, V only receives the same rotations (one global
+//               read-modify-write per pair and step, off the dependence chain)
+//   SMALL_GWS   both in the global workspace (any n); latency bound
+enum { SMALL_LDS = 0, SMALL_GWS = 1, SMALL_MIXED = 2 };
+template <int MEM>
 __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 {
+    constexpr bool GWS = (MEM == SMALL_GWS);
     const int n = a.n, L = a.L;
     const int ld = n | 1;
     double* bufA = GWS ? a.gws + (size_t)blockIdx.x * 2 * n * ld : sm_s;     // n x ld
-    double* bufV = bufA + (size_t)n * ld;    // n x ld
-    double* lam = GWS ? sm_s : bufV + (size_t)n * ld;     // [n] eigenvalues of G (unsorted)
+    double* bufV = MEM == SMALL_MIXED ? a.gws + (size_t)blockIdx.x * n * ld : bufA + (size_t)n * ld;    // n x ld
+    double* lam = GWS ? sm_s : (MEM == SMALL_MIXED ? sm_s + (size_t)n * ld : bufV + (size_t)n * ld);   // [n] eigenvalues of G (unsorted)
     double* sig = lam + n;                   // [n] singular values of temp
     int* rank = reinterpret_cast<int*>(sig + n);   // [n] rank of physical column (0 = largest)
     int* order = rank + n;                         // [n] physical column of rank k
@@ -1359,6 +1433,8 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     }
     __syncthreads();
     if (GWS) jacobi_cols_big(bufA, n, bufV, n, n, ld, &s_flag);
+    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<13>(bufA, n, bufV, n, n, ld, &s_flag);
+                                   else jacobi_cols_mixed<18>(bufA, n, bufV, n, n, ld, &s_flag); }
     else jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
     // eigenvalues = column norms of G.V (G is PSD)
     for (int c = tid; c < n; c += blockDim.x) {
@@ -1443,6 +1519,8 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     }
     __syncthreads();
     if (GWS) jacobi_cols_big(bufA, L, bufV, n, n, ld, &s_flag);
+    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<13>(bufA, L, bufV, n, n, ld, &s_flag);
+                                   else jacobi_cols_mixed<18>(bufA, L, bufV, n, n, ld, &s_flag); }
     else jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
@@ -1493,14 +1571,14 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 // grid cut to 16 / 40 / 64 / 128 blocks so that the matrices stay inside the XCDs'
 // L2, T' = 200 took 6.9 / 3.5 / 2.1 / 1.1 ms per resample against 1.1 ms with all
 // 256 CUs busy -- time per block hardly moves, so every CU gets a block.
-template <bool GWS>
-__global__ __launch_bounds__(GWS ? 1024 : 256)
+template <int MEM>
+__global__ __launch_bounds__(MEM == SMALL_GWS ? 1024 : (MEM == SMALL_MIXED ? 512 : 256))
 void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];
-    if (!GWS) { small_solve<false>(a, blockIdx.x, sm_s); return; }
+    if (MEM == SMALL_LDS) { small_solve<SMALL_LDS>(a, blockIdx.x, sm_s); return; }
     for (int r = blockIdx.x; r < a.nres; r += gridDim.x) {
-        small_solve<true>(a, r, sm_s);
+        small_solve<MEM>(a, r, sm_s);
         __syncthreads();
     }
 }

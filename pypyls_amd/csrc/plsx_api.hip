@@ -681,9 +681,13 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
 
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
-    const int n = a.n, ld = n | 1;
+    const int n = a.n;
+    int ld = n | 1;
     KTimer tm(ctx, KC_SMALL, st);
     a.nres = nres;
+    auto lds_both = [&](int pitch) { return ((size_t)2 * n * pitch + 2 * n) * 8 + (size_t)2 * n * 4 + 64; };
+    if (n <= PLSX_LDS_TP && lds_both(ld) > 160 * 1024 && lds_both(n) <= 160 * 1024) ld = n;   // n = 100: unpadded pitch
+    a.ld = ld;
     // A (n x ld) + bookkeeping in LDS, V in a global workspace: up to n = 141
     const size_t lds_mixed = ((size_t)n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
     if (n > PLSX_LDS_TP && lds_mixed <= 160 * 1024 && !getenv("PLSX_SMALL_GWS")) {
@@ -691,7 +695,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
         if (int e = ensure(ctx, ctx->gws, (size_t)nblk * n * ld * 8)) return e;
         a.gws = ptr<double>(ctx->gws);
         HIPCHK(set_lds(k_small<SMALL_MIXED>, lds_mixed));
-        hipLaunchKernelGGL(k_small<SMALL_MIXED>, dim3(nblk), dim3(512), lds_mixed, st, a);
+        hipLaunchKernelGGL(k_small<SMALL_MIXED>, dim3(nblk), dim3(1024), lds_mixed, st, a);
         LAUNCHCHK();
         return 0;
     }
@@ -707,7 +711,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
         LAUNCHCHK();
         return 0;
     }
-    const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
+    const size_t lds = lds_both(ld);
     HIPCHK(set_lds(k_small<SMALL_LDS>, lds));
     hipLaunchKernelGGL(k_small<SMALL_LDS>, dim3(nres), dim3(256), lds, st, a);
     LAUNCHCHK();

@@ -33,7 +33,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_MAX_TP 1280        // largest stacked dimension T' (rows of one resample; sliced over blocks above 352)
 #define PLSX_BLOCK_TP 352       // largest T' whose rows fit ONE cross-product block (22 data tiles + moments)
 #define PLSX_MAX_CELLS 352      // largest number of group x condition cells
-#define PLSX_LDS_TP 96          // largest T' whose small solver runs out of LDS (global workspace above)
+#define PLSX_LDS_TP 100         // largest T' whose small solver runs out of LDS: 2 n ld + bookkeeping <= 160 KB
+                                // (column pitch ld = n | 1, or n itself when only that fits: n = 100)
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
 
@@ -1204,11 +1205,11 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
 // A in LDS, V in global memory (SMALL_MIXED).  The V columns of a pair are requested
 // BEFORE the dot products over A, so their L2 round trip runs under the on-chip work of
 // the same step; only the write-back is left in front of the step's barrier.
-template <int IT>
+template <int IT, int LANES>
 __device__ void jacobi_cols_mixed(double* A, int m, double* V, int mv, int n, int ld, int* flag)
 {
     const int tid = threadIdx.x;
-    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
+    const int sub = tid % LANES, grp = tid / LANES, ngrp = blockDim.x / LANES;
     const int np = (n + 1) >> 1, ne = np * 2;
     const double tol = 1e-15;
     __shared__ double s_amax;
@@ -1228,19 +1229,19 @@ __device__ void jacobi_cols_mixed(double* A, int m, double* V, int mv, int n, in
                 double vx[IT], vy[IT];
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + 8 * i < mv;
-                    vx[i] = ok ? vp[8 * i] : 0.0;
-                    vy[i] = ok ? vq[8 * i] : 0.0;
+                    const bool ok = sub + LANES * i < mv;
+                    vx[i] = ok ? vp[LANES * i] : 0.0;
+                    vy[i] = ok ? vq[LANES * i] : 0.0;
                 }
                 double* ap = A + (size_t)p * ld;
                 double* aq = A + (size_t)q * ld;
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int i = sub; i < m; i += 8) {
+                for (int i = sub; i < m; i += LANES) {
                     double x = ap[i], y = aq[i];
                     alpha += x * x; beta += y * y; gamma += x * y;
                 }
 #pragma unroll
-                for (int o = 1; o < 8; o <<= 1) {
+                for (int o = 1; o < LANES; o <<= 1) {
                     alpha += __shfl_xor(alpha, o);
                     beta += __shfl_xor(beta, o);
                     gamma += __shfl_xor(gamma, o);
@@ -1249,15 +1250,15 @@ __device__ void jacobi_cols_mixed(double* A, int m, double* V, int mv, int n, in
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = sub; i < m; i += 8) {
+                for (int i = sub; i < m; i += LANES) {
                     double x = ap[i], y = aq[i];
                     ap[i] = c * x - s * y; aq[i] = s * x + c * y;
                 }
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
-                    if (sub + 8 * i < mv) {
-                        vp[8 * i] = c * vx[i] - s * vy[i];
-                        vq[8 * i] = s * vx[i] + c * vy[i];
+                    if (sub + LANES * i < mv) {
+                        vp[LANES * i] = c * vx[i] - s * vy[i];
+                        vq[LANES * i] = s * vx[i] + c * vy[i];
                     }
                 if (sub == 0) *flag = 1;
             }
@@ -1399,10 +1400,11 @@ struct SmallArgs {
     int nks_t, LT;
     double* gws;       // GWS: global workspace, 2 n (n|1) doubles per BLOCK (T' > PLSX_LDS_TP)
     int nres;          // resamples of the launch (GWS: blocks are persistent and walk them)
+    int ld;            // column pitch of the work matrices (n | 1; n when only that fits LDS)
 };
 
 // Where the two n x (n|1) work matrices live:
-//   SMALL_LDS   both in LDS (n <= PLSX_LDS_TP = 96)
+//   SMALL_LDS   both in LDS (n <= PLSX_LDS_TP = 100)
 //   SMALL_MIXED the rotated matrix A in LDS, the accumulator V in a global workspace
 //               (n <= 141): every dot product and rotation of the convergence-critical
 //               matrix stays on chip, V only receives the same rotations (one global
@@ -1414,7 +1416,7 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 {
     constexpr bool GWS = (MEM == SMALL_GWS);
     const int n = a.n, L = a.L;
-    const int ld = n | 1;
+    const int ld = a.ld;
     double* bufA = GWS ? a.gws + (size_t)blockIdx.x * 2 * n * ld : sm_s;     // n x ld
     double* bufV = MEM == SMALL_MIXED ? a.gws + (size_t)blockIdx.x * n * ld : bufA + (size_t)n * ld;    // n x ld
     double* lam = GWS ? sm_s : (MEM == SMALL_MIXED ? sm_s + (size_t)n * ld : bufV + (size_t)n * ld);   // [n] eigenvalues of G (unsorted)
@@ -1433,8 +1435,8 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     }
     __syncthreads();
     if (GWS) jacobi_cols_big(bufA, n, bufV, n, n, ld, &s_flag);
-    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<13>(bufA, n, bufV, n, n, ld, &s_flag);
-                                   else jacobi_cols_mixed<18>(bufA, n, bufV, n, n, ld, &s_flag); }
+    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<7, 16>(bufA, n, bufV, n, n, ld, &s_flag);
+                                   else jacobi_cols_mixed<9, 16>(bufA, n, bufV, n, n, ld, &s_flag); }
     else jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
     // eigenvalues = column norms of G.V (G is PSD)
     for (int c = tid; c < n; c += blockDim.x) {
@@ -1519,8 +1521,8 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     }
     __syncthreads();
     if (GWS) jacobi_cols_big(bufA, L, bufV, n, n, ld, &s_flag);
-    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<13>(bufA, L, bufV, n, n, ld, &s_flag);
-                                   else jacobi_cols_mixed<18>(bufA, L, bufV, n, n, ld, &s_flag); }
+    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<7, 16>(bufA, L, bufV, n, n, ld, &s_flag);
+                                   else jacobi_cols_mixed<9, 16>(bufA, L, bufV, n, n, ld, &s_flag); }
     else jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
@@ -1572,7 +1574,7 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 // L2, T' = 200 took 6.9 / 3.5 / 2.1 / 1.1 ms per resample against 1.1 ms with all
 // 256 CUs busy -- time per block hardly moves, so every CU gets a block.
 template <int MEM>
-__global__ __launch_bounds__(MEM == SMALL_GWS ? 1024 : (MEM == SMALL_MIXED ? 512 : 256))
+__global__ __launch_bounds__(MEM == SMALL_LDS ? 256 : 1024)
 void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];

@@ -756,8 +756,12 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     int nsplit = 1;
     if (!out && nres >= 64) {
-        nsplit = pick_parts(nblk, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)), 1, 8);
-        nsplit = std::min(nsplit, nres / 32);
+        const int slots = chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>));
+        // many feature blocks: cut the resamples so that the grid ends in a full round;
+        // few (small B): cut them so that the grid fills the chip at all -- every block
+        // walks its resamples one after the other
+        nsplit = nblk >= slots ? pick_parts(nblk, slots, 1, 8) : std::min(32, ceil_div(2 * slots, nblk));
+        nsplit = std::max(1, std::min(nsplit, nres / 32));
     }
     const int rps = ceil_div(nres, std::max(nsplit, 1));
     nsplit = ceil_div(nres, rps);

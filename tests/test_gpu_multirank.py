@@ -157,3 +157,23 @@ def test_bench_launches_its_own_ranks(tmp_path):
     if torch.cuda.device_count() < 2:
         proc = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
         assert proc.returncode != 0 and 'visible' in proc.stderr
+
+
+@pytest.mark.parametrize('config', ['c2'])
+def test_bench_config_lines(config):
+    """`bench.py --config` lines carry the contract's keys (roofline, cpu_baseline, kernel split)."""
+    import json
+    env = dict(os.environ, PLSX_SCRATCH_GB='8')
+    env.pop('WORLD_SIZE', None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', config, '--steps', '2',
+                           '--warmup', '1'], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                       # ONE JSON line, nothing after it
+    out = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in out, key
+    assert out['dtype'] == 'f64' and out['roofline']['bound'] in ('hbm', 'mfma')
+    assert 0 < out['roofline']['frac'] <= 1.0 and out['cpu_baseline']['kind'] == 'port'
+    assert out['value_primal'] > 0 and 'k_xprod' in out['config']['kernel_ms_per_step']

@@ -34,7 +34,8 @@ def one_case(rs, idx):
     groups = per
     S = sum(per) * n_cond
     B = int(rs.choice([3, 17, 64, 129, 500, 1500]))
-    T = int(rs.choice([1, 2, 5, 11, 24])) if method == 'behavioral' else 0
+    # (occasionally wide: T' = J T beyond one cross-product block -> sliced layout, global-memory solvers)
+    T = int(rs.choice([1, 2, 5, 11, 24, 24, 60, 110])) if method == 'behavioral' else 0
     cov = bool(method == 'behavioral' and rs.rand() < 0.25)
     mc = int(rs.randint(0, 3))
     if method == 'meancentered':
@@ -52,7 +53,7 @@ def one_case(rs, idx):
         Y[:, :k] += 0.5 * X[:, :k]
     global LAST
     LAST = desc = dict(i=idx, method=method, groups=groups, n_cond=n_cond, S=S, B=B, T=T, cov=cov, mc=mc, rotate=rotate)
-    if method == 'behavioral' and n_groups * n_cond * T > 352:
+    if method == 'behavioral' and n_groups * n_cond * T > 1280:
         return desc, 'skipped'
     eng = Engine()
     eng.set_data(X, Y if method == 'behavioral' else None, rsmp.cell_of_row(groups, n_cond), n_groups, n_cond,

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'plsx_api.hip')
 DEPS = [SRC, os.path.join(HERE, 'csrc', 'plsx_kernels.h'), os.path.join(HERE, 'csrc', 'plsx_simpls.h'),
         os.path.join(HERE, 'csrc', 'plsx_resample.h'),
+        os.path.join(HERE, 'csrc', 'plsx_symeig.h'),
         os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')]
 LIB = os.path.join(HERE, 'libplsx.so')
 

@@ -54,7 +54,7 @@ struct plsx_ctx {
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
-    Buf gws;                                            // small-solver workspace (T' > PLSX_LDS_TP)
+    Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
     int dual = 0, dual_ok = 0;
@@ -314,11 +314,11 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     if (ctx->scratch_fixed) return cap;
     const double gb_per_group = (double)std::max(ctx->npg, ctx->npgf) * ctx->Tpp * (double)ctx->Bpad * 8.0 /
                                 1073741824.0;
-    // per-launch cost: one wave of the small solver -- 2.5 ms out of LDS, but ~150 ms
-    // x (T'/200)^3 out of the global workspace (T' > PLSX_LDS_TP, latency bound, one
-    // block per resample: only a large batch keeps the chip busy)
+    // per-launch cost: one wave of the small solver -- 2.5 ms for the LDS Jacobi variant, ~25 ms
+    // x (T'/200)^3 for Householder + QL (T' > PLSX_JACOBI_TP; one block per resample, latency
+    // bound: only a large batch keeps the chip busy)
     const double tn = ctx->Tp / 200.0;
-    const double c_group = 40.0 * gb_per_group, c_launch = ctx->Tp > PLSX_LDS_TP ? 150.0 * tn * tn * tn : 2.5;
+    const double c_group = 40.0 * gb_per_group, c_launch = ctx->Tp > PLSX_JACOBI_TP ? std::max(2.5, 25.0 * tn * tn * tn) : 2.5;
     int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
     g = std::max(g, ctx->Galloc);
     return std::max(1, std::min(g, cap));
@@ -682,38 +682,42 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 {
     const int n = a.n;
-    int ld = n | 1;
+    const int ld = n | 1;
     KTimer tm(ctx, KC_SMALL, st);
     a.nres = nres;
-    auto lds_both = [&](int pitch) { return ((size_t)2 * n * pitch + 2 * n) * 8 + (size_t)2 * n * 4 + 64; };
-    if (n <= PLSX_LDS_TP && lds_both(ld) > 160 * 1024 && lds_both(n) <= 160 * 1024) ld = n;   // n = 100: unpadded pitch
     a.ld = ld;
-    // A (n x ld) + bookkeeping in LDS, V in a global workspace: up to n = 141
-    const size_t lds_mixed = ((size_t)n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
-    if (n > PLSX_LDS_TP && lds_mixed <= 160 * 1024 && !getenv("PLSX_SMALL_GWS")) {
-        const int nblk = std::min(nres, 512);
-        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * n * ld * 8)) return e;
-        a.gws = ptr<double>(ctx->gws);
-        HIPCHK(set_lds(k_small<SMALL_MIXED>, lds_mixed));
-        hipLaunchKernelGGL(k_small<SMALL_MIXED>, dim3(nblk), dim3(1024), lds_mixed, st, a);
+    a.jtol = 1e-15;
+    if (n > PLSX_JACOBI_TP) {
+        // Householder + implicit QL (plsx_symeig.h): persistent blocks, a global workspace of 4 n ld
+        // doubles per block, and whatever LDS is left behind the bookkeeping vectors for the leading
+        // block of the matrix being reduced (the whole matrix up to T' ~ 135)
+        const size_t ws = (size_t)4 * n * ld * 8;
+        const size_t lds_vec = (size_t)(7 * n + PLSX_SE_THREADS + 18) * 8 + (size_t)(2 * n + 2) * 4 + 64;
+        const size_t lds = std::min((size_t)160 * 1024 - 256, lds_vec + (size_t)n * n * 8);
+        a.lds_cap = (int)((lds - lds_vec) / 8);
+        int nblk = 0;
+#define SMALL_QL_LAUNCH(RPT, CH) { HIPCHK(set_lds(k_small_ql<RPT, CH>, lds)); int per = 1; \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_small_ql<RPT, CH>, PLSX_SE_THREADS, lds); \
+        nblk = std::min(nres, 256 * std::max(1, per)); \
+        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e; \
+        a.gws = ptr<double>(ctx->gws); \
+        hipLaunchKernelGGL((k_small_ql<RPT, CH>), dim3(nblk), dim3(PLSX_SE_THREADS), lds, st, a); }
+        if (n <= 192) SMALL_QL_LAUNCH(1, 16)          // rows of the eigenvector matrix per rotating thread, prefetch depth
+        else if (n <= 384) SMALL_QL_LAUNCH(2, 8)
+        else if (n <= 576) SMALL_QL_LAUNCH(3, 8)
+        else SMALL_QL_LAUNCH(7, 4)
+#undef SMALL_QL_LAUNCH
         LAUNCHCHK();
         return 0;
     }
-    if (n > PLSX_LDS_TP) {
-        // work matrices in a global workspace, bookkeeping vectors in LDS.  Persistent
-        // blocks, one per CU (1024 threads each), walk the resamples.
-        const size_t ws = (size_t)2 * n * ld * 8;
-        const int nblk = std::min(nres, 256);
-        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e;
-        a.gws = ptr<double>(ctx->gws);
-        const size_t lds = (size_t)2 * n * 8 + (size_t)2 * n * 4 + 64;
-        hipLaunchKernelGGL(k_small<SMALL_GWS>, dim3(nblk), dim3(1024), lds, st, a);
-        LAUNCHCHK();
-        return 0;
-    }
-    const size_t lds = lds_both(ld);
-    HIPCHK(set_lds(k_small<SMALL_LDS>, lds));
-    hipLaunchKernelGGL(k_small<SMALL_LDS>, dim3(nres), dim3(256), lds, st, a);
+    // one-sided Jacobi out of LDS, one block per resample, 8 lanes per column pair
+    const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
+#define SMALL_LDS_LAUNCH(ITL, THREADS) { HIPCHK(set_lds(k_small<ITL>, lds)); \
+        hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), lds, st, a); }
+    if (n <= 32) SMALL_LDS_LAUNCH(4, 128)
+    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256)
+    else SMALL_LDS_LAUNCH(8, 256)
+#undef SMALL_LDS_LAUNCH
     LAUNCHCHK();
     return 0;
 }

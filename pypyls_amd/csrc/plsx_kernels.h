@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "plsx_symeig.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -33,8 +34,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_MAX_TP 1280        // largest stacked dimension T' (rows of one resample; sliced over blocks above 352)
 #define PLSX_BLOCK_TP 352       // largest T' whose rows fit ONE cross-product block (22 data tiles + moments)
 #define PLSX_MAX_CELLS 352      // largest number of group x condition cells
-#define PLSX_LDS_TP 100         // largest T' whose small solver runs out of LDS: 2 n ld + bookkeeping <= 160 KB
-                                // (column pitch ld = n | 1, or n itself when only that fits: n = 100)
+#define PLSX_JACOBI_TP 64       // largest T' of the LDS Jacobi small solver; above it Householder + QL (plsx_symeig.h)
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
 
@@ -1147,12 +1147,11 @@ __device__ double jacobi_null2(const double* A, int m, int n, int ld, double* re
     return 1e-26 * r;
 }
 
-__device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+__device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag, double tol)
 {
     const int tid = threadIdx.x;
     const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
     const int np = (n + 1) >> 1, ne = np * 2;
-    const double tol = 1e-15;
     __shared__ double s_amax;
     const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -1202,91 +1201,22 @@ __device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, 
     }
 }
 
-// A in LDS, V in global memory (SMALL_MIXED).  The V columns of a pair are requested
-// BEFORE the dot products over A, so their L2 round trip runs under the on-chip work of
-// the same step; only the write-back is left in front of the step's barrier.
+// Register-blocked pair update for work matrices in LDS: both columns of A and of V
+// are fetched up front (IT values per lane each, clamped addresses + select so that the
+// loads carry no control flow), then dots, rotation, stores.  The row-at-a-time loops of
+// jacobi_cols pay one LDS round trip per row (the stores of a row may alias the loads
+// of the next, so the compiler cannot overlap them): 140 cycles per row measured.
 template <int IT, int LANES>
-__device__ void jacobi_cols_mixed(double* A, int m, double* V, int mv, int n, int ld, int* flag)
-{
-    const int tid = threadIdx.x;
-    const int sub = tid % LANES, grp = tid / LANES, ngrp = blockDim.x / LANES;
-    const int np = (n + 1) >> 1, ne = np * 2;
-    const double tol = 1e-15;
-    __shared__ double s_amax;
-    const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        for (int step = 0; step < ne - 1; ++step) {
-            for (int pr = grp; pr < np; pr += ngrp) {
-                int p, q;
-                if (pr == 0) { p = step; q = ne - 1; }
-                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
-                if (p > q) { int t = p; p = q; q = t; }
-                if (q >= n) continue;
-                double* vp = V + (size_t)p * ld + sub;
-                double* vq = V + (size_t)q * ld + sub;
-                double vx[IT], vy[IT];
-#pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + LANES * i < mv;
-                    vx[i] = ok ? vp[LANES * i] : 0.0;
-                    vy[i] = ok ? vq[LANES * i] : 0.0;
-                }
-                double* ap = A + (size_t)p * ld;
-                double* aq = A + (size_t)q * ld;
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int i = sub; i < m; i += LANES) {
-                    double x = ap[i], y = aq[i];
-                    alpha += x * x; beta += y * y; gamma += x * y;
-                }
-#pragma unroll
-                for (int o = 1; o < LANES; o <<= 1) {
-                    alpha += __shfl_xor(alpha, o);
-                    beta += __shfl_xor(beta, o);
-                    gamma += __shfl_xor(gamma, o);
-                }
-                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = sub; i < m; i += LANES) {
-                    double x = ap[i], y = aq[i];
-                    ap[i] = c * x - s * y; aq[i] = s * x + c * y;
-                }
-#pragma unroll
-                for (int i = 0; i < IT; ++i)
-                    if (sub + LANES * i < mv) {
-                        vp[LANES * i] = c * vx[i] - s * vy[i];
-                        vq[LANES * i] = s * vx[i] + c * vy[i];
-                    }
-                if (sub == 0) *flag = 1;
-            }
-            __syncthreads();
-        }
-        const int any = *flag;
-        __syncthreads();
-        if (!any) break;
-    }
-}
-
-// Same algorithm for work matrices in GLOBAL memory (T' > PLSX_LDS_TP).  Every
-// access is an L2 round trip (~2 us when the same lines were just written), so
-// the step time is (passes over the pairs) x (round trips per pass): the block
-// has 1024 threads so that all pairs of a step are in flight at once (LANES
-// lanes per pair, IT = rows / LANES values per lane, loaded before the first
-// use: one round trip for the two A columns, one for the two V columns).
-// The row-at-a-time loop of jacobi_cols took 0.31 s for n = 200; this, 8 lanes x
-// 256-thread blocks 0.15 s.
-template <int IT, int LANES>
-__device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, int ld, int* flag)
+__device__ void jacobi_cols_reg(double* A, int m, double* V, int mv, int n, int ld, int* flag, double tol)
 {
     const int tid = threadIdx.x;
     const int sub = tid % LANES, grp = tid / LANES, ngrp = blockDim.x / LANES;
     const int np = (n + 1) >> 1, ne = np * 2, mod = ne - 1;
-    const double tol = 1e-15;
     __shared__ double s_amax;
     const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
+    int ra[IT], rv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { ra[i] = min(sub + LANES * i, m - 1); rv[i] = min(sub + LANES * i, mv - 1); }
     for (int sweep = 0; sweep < 60; ++sweep) {
         if (tid == 0) *flag = 0;
         __syncthreads();
@@ -1300,19 +1230,21 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
                 }
                 if (p > q) { int t = p; p = q; q = t; }
                 if (q >= n) continue;
-                double* ap = A + (size_t)p * ld + sub;
-                double* aq = A + (size_t)q * ld + sub;
-                double x[IT], y[IT];
+                double* ap = A + (size_t)p * ld;
+                double* aq = A + (size_t)q * ld;
+                double* vp = V + (size_t)p * ld;
+                double* vq = V + (size_t)q * ld;
+                double x[IT], y[IT], vx[IT], vy[IT];
 #pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + LANES * i < m;
-                    x[i] = ok ? ap[LANES * i] : 0.0;
-                    y[i] = ok ? aq[LANES * i] : 0.0;
-                }
+                for (int i = 0; i < IT; ++i) { x[i] = ap[ra[i]]; y[i] = aq[ra[i]]; }
+#pragma unroll
+                for (int i = 0; i < IT; ++i) { vx[i] = vp[rv[i]]; vy[i] = vq[rv[i]]; }
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
 #pragma unroll
                 for (int i = 0; i < IT; ++i) {
-                    alpha += x[i] * x[i]; beta += y[i] * y[i]; gamma += x[i] * y[i];
+                    const bool ok = sub + LANES * i < m;
+                    const double xx = ok ? x[i] : 0.0, yy = ok ? y[i] : 0.0;
+                    alpha += xx * xx; beta += yy * yy; gamma += xx * yy;
                 }
 #pragma unroll
                 for (int o = 1; o < LANES; o <<= 1) {
@@ -1327,22 +1259,14 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
                     if (sub + LANES * i < m) {
-                        ap[LANES * i] = c * x[i] - sn * y[i];
-                        aq[LANES * i] = sn * x[i] + c * y[i];
+                        ap[ra[i]] = c * x[i] - sn * y[i];
+                        aq[ra[i]] = sn * x[i] + c * y[i];
                     }
-                double* vp = V + (size_t)p * ld + sub;
-                double* vq = V + (size_t)q * ld + sub;
-#pragma unroll
-                for (int i = 0; i < IT; ++i) {
-                    const bool ok = sub + LANES * i < mv;
-                    x[i] = ok ? vp[LANES * i] : 0.0;
-                    y[i] = ok ? vq[LANES * i] : 0.0;
-                }
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
                     if (sub + LANES * i < mv) {
-                        vp[LANES * i] = c * x[i] - sn * y[i];
-                        vq[LANES * i] = sn * x[i] + c * y[i];
+                        vp[rv[i]] = c * vx[i] - sn * vy[i];
+                        vq[rv[i]] = sn * vx[i] + c * vy[i];
                     }
                 if (sub == 0) *flag = 1;
             }
@@ -1352,18 +1276,6 @@ __device__ void jacobi_cols_big_t(double* A, int m, double* V, int mv, int n, in
         __syncthreads();
         if (!any) break;
     }
-}
-
-__device__ void jacobi_cols_big(double* A, int m, double* V, int mv, int n, int ld, int* flag)
-{
-    const int rows = max(m, mv);
-    if (rows <= 104) jacobi_cols_big_t<13, 8>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 152) jacobi_cols_big_t<19, 8>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 200) jacobi_cols_big_t<25, 8>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 256) jacobi_cols_big_t<16, 16>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 352) jacobi_cols_big_t<22, 16>(A, m, V, mv, n, ld, flag);
-    else if (rows <= 704) jacobi_cols_big_t<22, 32>(A, m, V, mv, n, ld, flag);
-    else jacobi_cols_big_t<20, 64>(A, m, V, mv, n, ld, flag);   // <= 1280 rows
 }
 
 // Fragment-ordered M operand (T' x L) of k_urot / k_ucorr_partial: the 16-column
@@ -1398,28 +1310,23 @@ struct SmallArgs {
     double* out_d;     // DECOMP: (L)
     double* Mfrag;     // BOOT / DECOMP: [nres][nks_t][LT][64] fragment-ordered M (T' x L)
     int nks_t, LT;
-    double* gws;       // GWS: global workspace, 2 n (n|1) doubles per BLOCK (T' > PLSX_LDS_TP)
-    int nres;          // resamples of the launch (GWS: blocks are persistent and walk them)
-    int ld;            // column pitch of the work matrices (n | 1; n when only that fits LDS)
+    double* gws;       // QL solver: global workspace, 4 n ld doubles per BLOCK (T' > PLSX_JACOBI_TP)
+    int nres;          // resamples of the launch (QL: blocks are persistent and walk them)
+    int ld;            // column pitch of the work matrices (n | 1)
+    int lds_cap;       // QL: doubles of LDS behind the bookkeeping vectors
+    double jtol;       // Jacobi stopping threshold on |a_p.a_q| / (|a_p| |a_q|)
 };
 
-// Where the two n x (n|1) work matrices live:
-//   SMALL_LDS   both in LDS (n <= PLSX_LDS_TP = 100)
-//   SMALL_MIXED the rotated matrix A in LDS, the accumulator V in a global workspace
-//               (n <= 141): every dot product and rotation of the convergence-critical
-//               matrix stays on chip, V only receives the same rotations (one global
-//               read-modify-write per pair and step, off the dependence chain)
-//   SMALL_GWS   both in the global workspace (any n); latency bound
-enum { SMALL_LDS = 0, SMALL_GWS = 1, SMALL_MIXED = 2 };
-template <int MEM>
+// LDS Jacobi variant (T' <= PLSX_JACOBI_TP): both n x (n|1) work matrices in LDS, one block per
+// resample; ITL = values per lane and column of the register-blocked pair update (8 lanes per pair).
+template <int ITL>
 __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 {
-    constexpr bool GWS = (MEM == SMALL_GWS);
     const int n = a.n, L = a.L;
     const int ld = a.ld;
-    double* bufA = GWS ? a.gws + (size_t)blockIdx.x * 2 * n * ld : sm_s;     // n x ld
-    double* bufV = MEM == SMALL_MIXED ? a.gws + (size_t)blockIdx.x * n * ld : bufA + (size_t)n * ld;    // n x ld
-    double* lam = GWS ? sm_s : (MEM == SMALL_MIXED ? sm_s + (size_t)n * ld : bufV + (size_t)n * ld);   // [n] eigenvalues of G (unsorted)
+    double* bufA = sm_s;                           // n x ld
+    double* bufV = bufA + (size_t)n * ld;          // n x ld
+    double* lam = bufV + (size_t)n * ld;           // [n] eigenvalues of G (unsorted)
     double* sig = lam + n;                   // [n] singular values of temp
     int* rank = reinterpret_cast<int*>(sig + n);   // [n] rank of physical column (0 = largest)
     int* order = rank + n;                         // [n] physical column of rank k
@@ -1434,10 +1341,7 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
         bufV[c * ld + i] = (i == c) ? 1.0 : 0.0;
     }
     __syncthreads();
-    if (GWS) jacobi_cols_big(bufA, n, bufV, n, n, ld, &s_flag);
-    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<7, 16>(bufA, n, bufV, n, n, ld, &s_flag);
-                                   else jacobi_cols_mixed<9, 16>(bufA, n, bufV, n, n, ld, &s_flag); }
-    else jacobi_cols(bufA, n, bufV, n, n, ld, &s_flag);
+    jacobi_cols_reg<ITL, 8>(bufA, n, bufV, n, n, ld, &s_flag, a.jtol);
     // eigenvalues = column norms of G.V (G is PSD)
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
@@ -1520,10 +1424,7 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
         }
     }
     __syncthreads();
-    if (GWS) jacobi_cols_big(bufA, L, bufV, n, n, ld, &s_flag);
-    else if (MEM == SMALL_MIXED) { if (n <= 104) jacobi_cols_mixed<7, 16>(bufA, L, bufV, n, n, ld, &s_flag);
-                                   else jacobi_cols_mixed<9, 16>(bufA, L, bufV, n, n, ld, &s_flag); }
-    else jacobi_cols(bufA, L, bufV, n, n, ld, &s_flag);
+    jacobi_cols_reg<ITL, 8>(bufA, L, bufV, n, n, ld, &s_flag, a.jtol);
     for (int c = tid; c < n; c += blockDim.x) {
         double s = 0.0;
         for (int i = 0; i < L; ++i) { double x = bufA[c * ld + i]; s += x * x; }
@@ -1566,23 +1467,163 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     }
 }
 
-// GWS = false: one block per resample, work matrices in LDS.
-// GWS = true: the work matrices (2 n (n|1) doubles) live in global memory; one
-// resident 1024-thread block per CU walks the resamples (workspace per block, not
-// per resample).  The solver is LATENCY bound there, not bandwidth bound: with the
-// grid cut to 16 / 40 / 64 / 128 blocks so that the matrices stay inside the XCDs'
-// L2, T' = 200 took 6.9 / 3.5 / 2.1 / 1.1 ms per resample against 1.1 ms with all
-// 256 CUs busy -- time per block hardly moves, so every CU gets a block.
-template <int MEM>
-__global__ __launch_bounds__(MEM == SMALL_LDS ? 256 : 1024)
+// ---------------------------------------------------------------------------
+// The same small problem for T' > PLSX_JACOBI_TP without Jacobi sweeps: the
+// work matrices live in a global workspace (4 n ld doubles per BLOCK), and both
+// decompositions are symmetric eigenproblems solved by sym_eig (plsx_symeig.h):
+//   G = V diag(lam) V^T                                   (T' x T')
+//   H = temp temp^T = W diag(sig^2) W^T                   (L x L),  temp as in small_solve
+// The Procrustes factor of pyls/compute.py:240-264 is the polar factor of temp^T:
+//   Q = temp^T H^(-1/2) = temp^T W diag(1/sig) W^T   (pseudo-inverse over dead directions)
+// and the outputs are (accumulator) . Q exactly as in small_solve: rows d_c Q[c][:] for a
+// permutation, M = V Q for a bootstrap.  Forming H squares the condition number of temp
+// (cosines of the principal angles between the original and the resampled weight spaces):
+// directions with sig < 1e-6 sig_max count as dead here (1e-12 in the Jacobi solver).
+// ---------------------------------------------------------------------------
+template <int RPT, int CH>
+__device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, double* sm)
+{
+    const int n = a.n, L = a.L, ld = a.ld;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* Wa = a.gws + (size_t)blockIdx.x * 4 * n * ld;      // G -> V
+    double* Wb = Wa + (size_t)n * ld;                          // temp (L x n, column c at c * ld), later acc . Q
+    double* Wc = Wb + (size_t)n * ld;                          // H -> W, then F = acc . temp^T (n x L)
+    double* Wd = Wc + (size_t)n * ld;                          // H^(-1/2) (L x L)
+    double* lam = sm;                 // [n] eigenvalues of G
+    double* sig = lam + n;            // [n] 1 / sig (0 where dead)
+    double* dd = sig + n;             // sym_eig work vectors
+    double* ee = dd + n;
+    double* hh = ee + n;
+    double* uu = hh + n;
+    double* pp = uu + n;
+    double* ps = pp + n;              // [blockDim.x]
+    double* red = ps + nt;            // [18]
+    int* rank = reinterpret_cast<int*>(red + 18);
+    int* order = rank + n;
+    double* lmat = reinterpret_cast<double*>(order + n);     // rest of the LDS: leading block of the eigen-solver
+    const int lcap = a.lds_cap;
+    __shared__ double s_dmax;
+    const double* G = a.G + (size_t)r * n * n;
+
+    for (int idx = tid; idx < n * n; idx += nt) {
+        const int i = idx % n, c = idx / n;
+        Wa[(size_t)c * ld + i] = 0.5 * (G[(size_t)i * n + c] + G[(size_t)c * n + i]);
+    }
+    __syncthreads();
+    sym_eig<RPT, CH>(Wa, n, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap);
+    for (int c = tid; c < n; c += nt) lam[c] = fmax(dd[c], 0.0);
+    __syncthreads();
+    for (int c = tid; c < n; c += nt) {
+        int rk = 0;
+        const double lc = lam[c];
+        for (int o = 0; o < n; ++o) {
+            const double lo = lam[o];
+            rk += (lo > lc) || (lo == lc && o < c);
+        }
+        rank[c] = rk;
+        order[rk] = c;
+    }
+    __syncthreads();
+    if (tid == 0) s_dmax = sqrt(lam[order[0]]);
+    __syncthreads();
+    const double dmax = s_dmax;
+
+    if (a.mode == SMALL_DECOMP) {
+        for (int idx = tid; idx < n * L; idx += nt) {
+            const int t = idx / L, k = idx % L;
+            a.out_V[(size_t)r * n * L + (size_t)t * L + k] = Wa[(size_t)order[k] * ld + t];
+        }
+        for (int k = tid; k < L; k += nt) a.out_d[(size_t)r * L + k] = sqrt(lam[order[k]]);
+        const int tot = a.nks_t * a.LT * 64;
+        for (int idx = tid; idx < tot; idx += nt) {
+            int lane, lt, ks;
+            mfrag_decode(idx, a.nks_t, a.LT, ks, lt, lane);
+            const int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
+            double v = 0.0;
+            if (t < n && l < L) {
+                const double d = sqrt(lam[order[l]]);
+                if (d > PLSX_RANK_RTOL * dmax) v = Wa[(size_t)order[l] * ld + t] / d;
+            }
+            a.Mfrag[(size_t)r * tot + idx] = v;
+        }
+        return;
+    }
+    if (a.mode == SMALL_PERM && !a.rotate) {
+        for (int k = tid; k < L; k += nt) a.out_sv[(size_t)r * L + k] = sqrt(lam[order[k]]);
+        return;
+    }
+
+    // temp (L x n): column c = coordinates of eigenvector c in the original weight basis
+    // (pyls/compute.py:260; bootstrap: (U0^T U_b), live LVs only)
+    const bool perm = (a.mode == SMALL_PERM);
+    const double* Pm = perm ? a.V0 : a.P + (size_t)r * n * L;          // (n x L) row-major = (L x n) column-major
+    const double d0max = perm ? 0.0 : a.d0[0];
+    se_block_gemm<false>(Wb, ld, Pm, L, Wa, ld, L, n, n, nullptr);
+    for (int idx = tid; idx < L * n; idx += nt) {
+        const int aa = idx % L, c = idx / L;
+        const double dc = sqrt(lam[c]);
+        const bool live = perm ? (rank[c] < L)
+                               : (rank[c] < L && dc > PLSX_RANK_RTOL * dmax && a.d0[aa] > PLSX_RANK_RTOL * d0max);
+        double v = 0.0;
+        if (live) v = perm ? Wb[(size_t)c * ld + aa] : Wb[(size_t)c * ld + aa] / dc;
+        Wb[(size_t)c * ld + aa] = v;
+    }
+    __syncthreads();
+    se_block_gemm<true>(Wc, ld, Wb, ld, Wb, ld, L, L, n, nullptr);     // H = temp temp^T
+    sym_eig<RPT, CH>(Wc, L, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap);
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int c = 0; c < L; ++c) mx = fmax(mx, dd[c]);
+        s_dmax = mx;
+    }
+    __syncthreads();
+    const double s2min = 1e-12 * s_dmax;              // sig > 1e-6 sig_max
+    for (int c = tid; c < L; c += nt) sig[c] = dd[c] > s2min ? 1.0 / sqrt(dd[c]) : 0.0;
+    __syncthreads();
+    se_block_gemm<true>(Wd, ld, Wc, ld, Wc, ld, L, L, L, sig);         // H^(-1/2) = W diag(1/sig) W^T
+    // F = acc . temp^T (n x L) over Wc
+    if (perm) {
+        for (int idx = tid; idx < n * L; idx += nt) {
+            const int k = idx % n, aa = idx / n;
+            Wc[(size_t)aa * ld + k] = (rank[k] < L) ? sqrt(lam[k]) * Wb[(size_t)k * ld + aa] : 0.0;
+        }
+        __syncthreads();
+    } else se_block_gemm<true>(Wc, ld, Wa, ld, Wb, ld, n, L, n, nullptr);
+    se_block_gemm<false>(Wb, ld, Wc, ld, Wd, ld, n, L, L, nullptr);     // acc . Q
+    if (perm) {
+        for (int l = tid; l < L; l += nt) {           // ssd_l = || (diag(d) Q)[:, l] ||
+            double ss = 0.0;
+            for (int k = 0; k < n; ++k) { const double v = Wb[(size_t)l * ld + k]; ss += v * v; }
+            a.out_sv[(size_t)r * L + l] = sqrt(ss);
+        }
+    } else {
+        const int tot = a.nks_t * a.LT * 64;
+        for (int idx = tid; idx < tot; idx += nt) {
+            int lane, lt, ks;
+            mfrag_decode(idx, a.nks_t, a.LT, ks, lt, lane);
+            const int t = ks * 4 + (lane >> 4), l = lt * 16 + (lane & 15);
+            a.Mfrag[(size_t)r * tot + idx] = (t < n && l < L) ? Wb[(size_t)l * ld + t] : 0.0;
+        }
+    }
+}
+
+template <int RPT, int CH>
+__global__ __launch_bounds__(PLSX_SE_THREADS)
+void k_small_ql(SmallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_s[];
+    for (int r = blockIdx.x; r < a.nres; r += gridDim.x) {
+        small_solve_ql<RPT, CH>(a, r, sm_s);
+        __syncthreads();
+    }
+}
+
+template <int ITL>
+__global__ __launch_bounds__(256)
 void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];
-    if (MEM == SMALL_LDS) { small_solve<SMALL_LDS>(a, blockIdx.x, sm_s); return; }
-    for (int r = blockIdx.x; r < a.nres; r += gridDim.x) {
-        small_solve<MEM>(a, r, sm_s);
-        __syncthreads();
-    }
+    small_solve<ITL>(a, blockIdx.x, sm_s);
 }
 
 // ---------------------------------------------------------------------------

@@ -212,7 +212,7 @@ void k_sd_comp_a(SdArgs a)
     // H v_j = lambda_j v_j, so the eigenvector is that column normalised.
     for (int idx = tid; idx < T * T; idx += NT) Hw[(idx % T) * ldh + idx / T] = H[idx];
     __syncthreads();
-    jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag);
+    jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag, 1e-15);
     for (int col = tid; col < T; col += NT) {
         double s = 0.0;
         for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }

@@ -729,7 +729,7 @@ int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* u
 {
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
-    const size_t lds = NKS < 0 ? 0 : (size_t)2 * ceil_div(ctx->nks_t * LT, 2) * 1024;
+    const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
     HIPCHK(set_lds(k_urot<LT, NKS>, lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
     hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),

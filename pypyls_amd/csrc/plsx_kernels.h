@@ -35,6 +35,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_BLOCK_TP 352       // largest T' whose rows fit ONE cross-product block (22 data tiles + moments)
 #define PLSX_MAX_CELLS 352      // largest number of group x condition cells
 #define PLSX_JACOBI_TP 64       // largest T' of the LDS Jacobi small solver; above it Householder + QL (plsx_symeig.h)
+#define PLSX_UROT_KC 20         // k-steps (of 4 rows of T') per LDS stage of the rotation operand when it is staged in pieces
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
 
@@ -1637,8 +1638,8 @@ void k_small(SmallArgs a)
 // multiplied (full software pipeline across resamples; with the loads issued
 // right before use a wave idles for an HBM latency every 16 MFMAs).
 // NKS == 0: generic k-step count, fragments fetched four k-steps ahead.
-// NKS < 0: as NKS == 0 but the M operand is read from global memory / L2 (T' so
-// large that two LDS stages of it do not fit).
+// NKS < 0: as NKS == 0 but the M operand goes through LDS in stages of PLSX_UROT_KC k-steps
+// (T' so large that two copies of the whole operand do not fit).
 // LT = tiles of this launch's chunk of L (PLSX_LT_CHUNK at most), k0 = its first
 // column, mstride = doubles between the M operands of consecutive resamples.
 template <int LT, int NKS>
@@ -1722,39 +1723,61 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NKS) : "memory");
         }
     } else {
+        // generic k-step count: the M operand goes through LDS in stages of KC k-steps (the whole
+        // operand when two copies of it fit, NKS == 0; PLSX_UROT_KC k-steps otherwise, NKS < 0),
+        // stage q + 1 copied while stage q is multiplied
+        const int KC = (NKS < 0) ? PLSX_UROT_KC : nks_t;
+        const int nch = (nks_t + KC - 1) / KC;
+        const int stage_c = ((KC * LT + 1) / 2) * 128;     // doubles
+        const int nq = (r_end - r_beg) * nch;
+        auto issue_c = [&](int q, double* buf) {
+            const int r = r_beg + q / nch, ks0 = (q % nch) * KC;
+            const int pcs = (min(KC, nks_t - ks0) * LT + 1) / 2;
+            __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(Mfrag + (size_t)r * mstride + (size_t)ks0 * LT * 64), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+            for (int p = swave; p < pcs; p += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsM, (__attribute__((address_space(3))) void*)(buf + p * 128), 16, lane * 16, p * 1024, 0, 0);
+        };
+        if (NKS < 0) issue_c(0, sm_u);                     // (NKS == 0: issue() above did it)
         __syncthreads();
-        for (int r = r_beg; r < r_end; ++r) {
-            const double* sM = (NKS < 0) ? Mfrag + (size_t)r * mstride + lane
-                                         : sm_u + ((r - r_beg) & 1) * stage + lane;
-            if (r + 1 < r_end) issue(r + 1, sm_u + ((r - r_beg + 1) & 1) * stage);
-            d4 acc[LT];
+        d4 acc[LT];
+        for (int q = 0; q < nq; ++q) {
+            const int r = r_beg + q / nch, c = q % nch;
+            const int ks0 = c * KC, len = min(KC, nks_t - ks0);
+            const double* sM = sm_u + (q & 1) * stage_c + lane;
+            if (q + 1 < nq) issue_c(q + 1, sm_u + ((q + 1) & 1) * stage_c);
+            if (c == 0) {
 #pragma unroll
-            for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
+                for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
+            }
             __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
             int ks = 0;
-            for (; ks + 4 <= nks_t; ks += 4) {
+            for (; ks + 4 <= len; ks += 4) {
                 double a[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks + u) * rstep, 0));
+                    a[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks0 + ks + u) * rstep, 0));
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int l = 0; l < LT; ++l)
                         acc[l] = mfma_f64(a[u], sM[((ks + u) * LT + l) * 64], acc[l]);
             }
-            for (; ks < nks_t; ++ks) {
-                const double a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
+            for (; ks < len; ++ks) {
+                const double a = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, (ks0 + ks) * rstep, 0));
 #pragma unroll
                 for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a, sM[(ks * LT + l) * 64], acc[l]);
             }
+            if (c == nch - 1) {
 #pragma unroll
-            for (int l = 0; l < LT; ++l) {
-                sum[l] += acc[l];
-                sq[l] += acc[l] * acc[l];
+                for (int l = 0; l < LT; ++l) {
+                    sum[l] += acc[l];
+                    sq[l] += acc[l] * acc[l];
+                }
             }
-            __syncthreads();         // drains the copy of the next M, frees this buffer
+            __syncthreads();         // drains the copy of the next stage, frees this buffer
         }
     }
     if (!live) return;

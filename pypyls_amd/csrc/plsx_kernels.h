@@ -826,6 +826,9 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
         else { tm = z / enum_n; tn = z - tm * enum_n; }
     }
     const int ra0 = 64 * tm, rb0 = 64 * tn;
+    // edge blocks of a tiled product: a wave whose column tile lies beyond T' (G) and beyond L (P) has
+    // nothing to contribute (its outputs are never read) and leaves its SIMD to the other blocks
+    if (tiles_total > 1 && !(WITH_G && rb0 + 16 * w < Tp) && !(WITH_P && rb0 + 16 * w < L)) return;
     const int cbeg = chunk * cols_per_chunk;
     const int cend = min(B, cbeg + cols_per_chunk);
     const double* Rr = R + (size_t)r * strideR;

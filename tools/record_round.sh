@@ -11,4 +11,8 @@ run c5 --config c5 --steps 5 --warmup 2
 run c5_full --config c5 --perms 5000 --boots 5000 --steps 2 --warmup 1 --cpu-sample 0
 run c4split --config c4split --steps 3 --warmup 1
 python tools/bench_configs.py c2 c3 c5 c4 c4split c4cv > gpurun_out/${tag}_frontend_walltimes.jsonl 2>/dev/null; cat gpurun_out/${tag}_frontend_walltimes.jsonl
-python tools/bench_wide.py 400 50000 100 1 1 512 > gpurun_out/${tag}_wide.jsonl 2>/dev/null; python tools/bench_wide.py 400 50000 200 1 1 256 >> gpurun_out/${tag}_wide.jsonl 2>/dev/null; cat gpurun_out/${tag}_wide.jsonl | cut -c1-300
+rm -f gpurun_out/${tag}_wide.jsonl
+for cfg in "400 50000 72 1 1 1024" "400 50000 100 1 1 512" "420 50000 140 1 1 512" "400 50000 200 1 1 256" "100 1000 100 1 4 64"; do
+  python tools/bench_wide.py $cfg >> gpurun_out/${tag}_wide.jsonl 2>/dev/null
+done
+cut -c1-300 gpurun_out/${tag}_wide.jsonl

@@ -21,10 +21,16 @@ def _bind(eng, X, Y, groups, n_cond, **kw):
 
 
 @pytest.mark.parametrize('S,B,T,groups,n_cond', [
-    (90, 333, 80, [90], 1),          # T' = 80 > 64: generic tiled Gram path, LT = 5
-    (96, 211, 24, [24, 24], 2),      # T' = J*T = 4*24 = 96 = the LDS solver limit, ragged B
-    (140, 600, 100, [140], 1),       # T' = 100 (the reference's own test width): global-workspace solver, LT = 7
-    (200, 500, 30, [25, 25], 4),     # T' = 8 cells x 30 = 240: two chunks of L tiles, M operand from L2
+    (90, 333, 80, [90], 1),          # T' = 80 > 64: generic tiled Gram path, LT = 5, Householder + QL solver
+    (96, 211, 24, [24, 24], 2),      # T' = J*T = 4*24 = 96, ragged B
+    (100, 300, 64, [100], 1),        # T' = 64: the last size of the LDS Jacobi solver
+    (100, 300, 65, [100], 1),        # T' = 65: the first size of the QL solver
+    (140, 600, 100, [140], 1),       # T' = 100 (the reference's own test width), LT = 7
+    (200, 400, 137, [200], 1),       # T' = 137: the largest matrix the QL solver keeps entirely in LDS
+    (200, 400, 138, [200], 1),       # T' = 138: leading 137 x 137 block in LDS, the rest in the global workspace
+    (260, 500, 192, [260], 1),       # T' = 192 / 193: one / two rows of the eigenvector matrix per rotating thread
+    (260, 500, 193, [260], 1),
+    (200, 500, 30, [25, 25], 4),     # T' = 8 cells x 30 = 240: two chunks of L tiles, rotation operand staged in pieces
     (400, 900, 352, [400], 1),       # T' = 352 = the block limit (22 data tiles + moments)
     (420, 700, 353, [420], 1),       # T' = 353: first sliced layout (one cell cut into two row slices)
     (100, 1000, 100, [25], 4),       # T' = 400, the reference's own test shape (pyls/tests/types/test_svd.py:87)
@@ -33,6 +39,8 @@ def _bind(eng, X, Y, groups, n_cond, **kw):
                                         # (B >= T': with L < T' the Procrustes result depends on WHICH
                                         # null vectors the SVD returns, in the reference too)
     (160, 520, 30, [10] * 8, 2),     # T' = 480 from 16 cells: slices share a cell, 12 + 5 moment rows
+    (450, 600, 385, [450], 1),       # T' = 385 / 577: three / seven rows per rotating thread
+    (640, 800, 577, [640], 1),
     (33, 17, 2, [33], 1),            # tiny, S not a multiple of 8, B < 128
     (603, 140, 3, [603], 1),         # S > 512
 ])

@@ -265,7 +265,7 @@ int plsx_set_timing(plsx_ctx* ctx, int enable);
 
 /* Summed duration (ms) and launch count of one kernel class since timing was
  * enabled: 0 k_xprod (cross-product), 1 k_gram / k_gram4 (+ partial reduce),
- * 2 k_small (Jacobi + Procrustes), 3 k_urot (+ split add), 4 k_nt_gemm
+ * 2 k_small / k_small_ql (eigen-solve + Procrustes), 3 k_urot (+ split add), 4 k_nt_gemm
  * (+ reduce), 5 k_ucorr_partial, 6 k_simpls_dual, 7 reserved.
  * plsx_kernel_class_name returns the label, NULL past the last class.
  * Measurement only; no reference counterpart. */

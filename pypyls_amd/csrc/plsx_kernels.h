@@ -18,6 +18,7 @@
 //   k_urot       U = R^T . M, fused sum / sum-of-squares accumulation  "K_U"
 //   k_ucorr_partial   split-half feature-axis correlation sums
 //   k_small      T'xT' Jacobi eigen-solve + Procrustes polar factor    "K4-K6"
+//   k_small_ql   the same for T' > 64: Householder + implicit QL (plsx_symeig.h)
 //
 // Reference semantics implemented (pyls/...): compute.xcorr :55-94,
 // behavioral.gen_covcorr :27-52, compute.get_mean_center :267-357,

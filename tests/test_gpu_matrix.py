@@ -210,7 +210,7 @@ def test_behavioral_reference_shapes(groups, n_cond, n_split):
 # ---- wide behaviour matrices (the reference's tests use 100 Y columns) ----------
 @pytest.mark.parametrize('n_groups,n_cond,n_split', [(1, 1, 4), (1, 2, None), (2, 1, 3)])
 def test_behavioral_wide_y(n_groups, n_cond, n_split):
-    """T = 100 behaviours, T' = 100 / 200 stacked rows: global-workspace small
+    """T = 100 behaviours, T' = 100 / 200 stacked rows: Householder + QL small
     solver, chunked L tiles; parity against the oracle incl. split-half and
     cross-validation."""
     import pypyls_amd as pls

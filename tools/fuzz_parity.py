@@ -35,7 +35,7 @@ def one_case(rs, idx):
     S = sum(per) * n_cond
     B = int(rs.choice([3, 17, 64, 129, 500, 1500]))
     # (occasionally wide: T' = J T beyond one cross-product block -> sliced layout, global-memory solvers)
-    T = int(rs.choice([1, 2, 5, 11, 24, 24, 60, 110])) if method == 'behavioral' else 0
+    T = int(rs.choice([70, 85, 110, 140, 33] if os.environ.get('FUZZ_WIDE') else [1, 2, 5, 11, 24, 24, 60, 110])) if method == 'behavioral' else 0
     cov = bool(method == 'behavioral' and rs.rand() < 0.25)
     mc = int(rs.randint(0, 3))
     if method == 'meancentered':

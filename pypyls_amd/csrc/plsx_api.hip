@@ -714,7 +714,8 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
 #define SMALL_LDS_LAUNCH(ITL, THREADS) { HIPCHK(set_lds(k_small<ITL>, lds)); \
         hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), lds, st, a); }
-    if (n <= 32) SMALL_LDS_LAUNCH(4, 128)
+    if (n <= 16) SMALL_LDS_LAUNCH(2, 64)          // one wave per resample: the step barriers cost nothing
+    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128)
     else if (n <= 56) SMALL_LDS_LAUNCH(7, 256)
     else SMALL_LDS_LAUNCH(8, 256)
 #undef SMALL_LDS_LAUNCH

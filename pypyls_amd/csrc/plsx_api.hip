@@ -182,10 +182,21 @@ int plan_groups(plsx_ctx* c)
     const int Jw = c->momrows ? c->J : 0;
     c->gps = 0;
     c->h_slice_row0.clear(); c->h_slice_rows.clear(); c->h_slice_cell0.clear(); c->h_slice_ncell.clear();
-    int best = 0;
-    for (int n = 1; n <= 512; ++n) {
-        int td = ceil_div(n * c->Tp, 16), tw = Jw ? ceil_div(n * Jw, 16) : 0;
-        if (td + 2 * tw <= c->MT && tw * 16 <= 48) best = n; else break;
+    auto fit = [&](int mt) {
+        int b = 0;
+        for (int n = 1; n <= 512; ++n) {
+            int td = ceil_div(n * c->Tp, 16), tw = Jw ? ceil_div(n * Jw, 16) : 0;
+            if (td + 2 * tw <= mt && tw * 16 <= 48) b = n; else break;
+        }
+        return b;
+    };
+    c->MT = 24;
+    int best = fit(24);
+    // a block of 16 tiles when it wastes clearly fewer rows (one resample of 177 <= T' <= 224 rows
+    // fills 15 of 24 tiles but 15 of 16); behavioural correlation PLS only (instantiations of k_xprod)
+    if (c->method == PLSX_BEHAVIORAL && !getenv("PLSX_XPROD_MT24")) {
+        const int b16 = fit(16);
+        if (b16 >= 1 && (double)b16 / 16.0 > 1.15 * (double)best / 24.0) { c->MT = 16; best = b16; }
     }
     int tw = Jw ? ceil_div(std::max(best, 1) * Jw, 16) : 0;
     if (best == 0) {
@@ -347,6 +358,13 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 // `groups` = physical groups (phys_groups of the resample groups)
 int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 {
+    if (ctx->MT == 16)
+        switch (ctx->MT - ctx->sq0) {
+            case 0: return launch_xprod_t<16, 4, 1, 0>(ctx, groups, st);
+            case 1: return launch_xprod_t<16, 4, 1, 1>(ctx, groups, st);
+            case 2: return launch_xprod_t<16, 4, 1, 2>(ctx, groups, st);
+            default: return launch_xprod_t<16, 4, 1, 3>(ctx, groups, st);
+        }
     switch (ctx->MT - ctx->sq0) {          // number of second-moment tiles (0..3)
         case 0: return launch_xprod_t<24, 4, 1, 0>(ctx, groups, st);
         case 1: return launch_xprod_t<24, 4, 1, 1>(ctx, groups, st);
@@ -1418,7 +1436,8 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
     if (int e = ensure(ctx, ctx->Mvd, (size_t)pcmax * mstride * 8 + 1024)) return e;
     const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
     // behavioral correlation mode: only the first half of a split takes the MFMA pass
-    const bool fused = ctx->scaled && !permute_x && ctx->gps == 0 && ctx->Gcap >= 2 && !getenv("PLSX_NO_SPLIT_FUSE");
+    const bool fused = ctx->scaled && !permute_x && ctx->gps == 0 && ctx->Gcap >= 2 && ctx->MT == 24 &&
+                       !getenv("PLSX_NO_SPLIT_FUSE");       // (the fused epilogue is instantiated for 24-tile blocks)
     // splits per pass (the fused path writes two R slots per split from groups of npg splits)
     const int spp = fused ? std::max(1, std::min(nb / 2, (ctx->Gcap / 2) * ctx->npg)) : nb / 2;
     for (int p0 = 0; p0 < np; p0 += pcmax) {

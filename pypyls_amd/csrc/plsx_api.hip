@@ -601,29 +601,58 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
         double* part = ptr<double>(ctx->part);
         KTimer tm(ctx, KC_GRAM, st);
         const dim3 gG(ceil_div(ctx->Tp * ctx->Tp, 256), nres), gP(ceil_div(ctx->Tp * std::max(Erows, 1), 256), nres);
-        if (mode == 1 && nt_l == nt_t) {
-            // square: G and P of the blocks tm <= tn share their A fragments in one pass,
-            // P of the blocks below the diagonal follows
-            hipLaunchKernelGGL(k_gram<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                               ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
-            LAUNCHCHK();
-            if (nt_t > 1) {
-                hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
-                                   ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
-                                   pitch, tiles, nt_t, 2);
+        const bool reg_streamed = getenv("PLSX_GRAM_REG") != nullptr;     // the A side from global memory in every wave
+        if (!reg_streamed) {
+            if (mode == 1 && nt_l == nt_t) {
+                // square: G and P of the blocks tm <= tn share their A fragments in one pass,
+                // P of the blocks below the diagonal follows
+                hipLaunchKernelGGL(k_gram_lds<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
                 LAUNCHCHK();
+                if (nt_t > 1) {
+                    hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
+                                       ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
+                                       pitch, tiles, nt_t, 2);
+                    LAUNCHCHK();
+                }
+            } else {
+                if (nz_g) {
+                    hipLaunchKernelGGL(k_gram_lds<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                       ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
+                                       tiles, nt_t, 1);
+                    LAUNCHCHK();
+                }
+                if (nz_p) {
+                    hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                       ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
+                    LAUNCHCHK();
+                }
             }
         } else {
-            if (nz_g) {
-                hipLaunchKernelGGL(k_gram<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                   ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
-                                   tiles, nt_t, 1);
+            if (mode == 1 && nt_l == nt_t) {
+                // square: G and P of the blocks tm <= tn share their A fragments in one pass,
+                // P of the blocks below the diagonal follows
+                hipLaunchKernelGGL(k_gram<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
                 LAUNCHCHK();
-            }
-            if (nz_p) {
-                hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
-                LAUNCHCHK();
+                if (nt_t > 1) {
+                    hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
+                                       ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
+                                       pitch, tiles, nt_t, 2);
+                    LAUNCHCHK();
+                }
+            } else {
+                if (nz_g) {
+                    hipLaunchKernelGGL(k_gram<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                       ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
+                                       tiles, nt_t, 1);
+                    LAUNCHCHK();
+                }
+                if (nz_p) {
+                    hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                       ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
+                    LAUNCHCHK();
+                }
             }
         }
         if (nz_g) {

@@ -918,6 +918,121 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
         }
 }
 
+// Tiled products (T' > 64 or L > 64) with the A side staged through LDS.  In k_gram the four
+// waves of a block fetch the same four A row tiles from global memory: 40 KB per 16-column step
+// and block against ~64 B/clk of L1, which held the tiled launches at 42 % of their MFMA time.
+// Here the 64 x 16 block of A rows is copied global -> LDS once per step by LDS-DMA (8 pieces of
+// 1 KB in operand order: piece (a, j), lane l = row 16 a + (l & 15), columns 8 j + 2 (l >> 4) + {0, 1},
+// so every ds_read_b128 of a fragment is lane-linear), double buffered, one barrier per step; the
+// B operands (rows of R / of U0^T of the wave's own column tile) stay register-streamed.  Same
+// block enumeration, output layout and MODE as k_gram.
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_gram_lds(const double* __restrict__ R, long long strideR, int ldr, int Tp,
+                const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
+                double* __restrict__ part, int nres, int tiles_n, int tiles_total, int enum_n, int upper)
+{
+    constexpr bool WITH_P = (MODE != 0), WITH_G = (MODE != 2);
+    __shared__ __attribute__((aligned(16))) double sA[2][8 * 128];      // two stages of 8 pieces x 64 lanes x d2
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.x, r = blockIdx.y;
+    int tm = 0, tn = 0;
+    {
+        int z = blockIdx.z;
+        if (upper == 1) { while (z >= enum_n - tm) { z -= enum_n - tm; ++tm; } tn = tm + z; }
+        else if (upper == 2) { tm = 1; while (z >= tm) { z -= tm; ++tm; } tn = z; }      // strictly lower blocks
+        else { tm = z / enum_n; tn = z - tm * enum_n; }
+    }
+    const int ra0 = 64 * tm, rb0 = 64 * tn;
+    const bool live_g = WITH_G && rb0 + 16 * w < Tp, live_p = WITH_P && rb0 + 16 * w < L;
+    const int cbeg = chunk * cols_per_chunk;
+    const int cend = min(B, cbeg + cols_per_chunk);
+    const int nsteps = (cend - cbeg + 15) / 16;
+    if (nsteps <= 0) return;
+    const double* Rr = R + (size_t)r * strideR;
+    // A pieces of this wave: p = w and w + 4 (a = p >> 1, j = p & 1); rows beyond T' are clamped (they
+    // only feed output rows >= T', which the reduction never reads)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(Rr + (size_t)ra0 * ldr), (short)0,
+                                                                   0x7fffffff, PLSX_RSRC_FLAGS);
+    int voff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int p = w + 4 * k, a = p >> 1, j = p & 1;
+        const int row = min(ra0 + 16 * a + m, Tp - 1) - ra0;
+        voff[k] = (int)(((long long)row * ldr + 8 * j + 2 * q) * 8);
+    }
+    const int swave = __builtin_amdgcn_readfirstlane(w);
+    auto issue = [&](int step, int buf) {
+        const int c0 = min(cbeg + 16 * step, ldr - 16);          // (the last step of a ragged chunk stays inside the row)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsA, (__attribute__((address_space(3))) void*)(&sA[buf][(swave + 4 * k) * 128]), 16, voff[k], c0 * 8, 0, 0);
+    };
+    const double* pb = Rr + (size_t)min(rb0 + 16 * w + m, Tp - 1) * ldr + 2 * q;
+    const double* pu = WITH_P ? U0T + (size_t)min(rb0 + 16 * w + m, L - 1) * ldu + 2 * q : nullptr;
+    d4 accG[4], accP[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
+    d2 xb[2], ub[2];
+    xb[0] = xb[1] = ub[0] = ub[1] = (d2){0, 0};
+    auto load_b = [&](int step, d2 (&b)[2], d2 (&u)[2]) {
+        const int c0 = min(cbeg + 16 * step, ldr - 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (WITH_G) b[j] = *reinterpret_cast<const d2*>(pb + c0 + 8 * j);
+            if (WITH_P) u[j] = *reinterpret_cast<const d2*>(pu + c0 + 8 * j);
+        }
+    };
+    issue(0, 0);
+    load_b(0, xb, ub);
+    for (int s = 0; s < nsteps; ++s) {
+        __syncthreads();                      // stage s landed (issued one step ago), stage s - 1 fully read
+        if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
+        d2 nb[2], nu[2];
+        nb[0] = nb[1] = nu[0] = nu[1] = (d2){0, 0};
+        load_b(min(s + 1, nsteps - 1), nb, nu);
+        if (cbeg + 16 * s + 16 > cend) {      // ragged last step: columns >= cend contribute nothing
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    if (cbeg + 16 * s + 8 * j + 2 * q + e >= cend) { xb[j][e] = 0.0; ub[j][e] = 0.0; }
+        }
+        if (live_g || live_p) {               // (a wave whose column tile lies beyond T' and L only copies)
+            const double* st = &sA[s & 1][0];
+            d2 xa[4][2];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xa[a][j] = *reinterpret_cast<const d2*>(st + ((a * 2 + j) * 64 + lane) * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        if (WITH_G) accG[a] = mfma_f64(xa[a][j][e], xb[j][e], accG[a]);
+                        if (WITH_P) accP[a] = mfma_f64(xa[a][j][e], ub[j][e], accP[a]);
+                    }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { xb[j] = nb[j]; ub[j] = nu[j]; }
+    }
+    if (!live_g && !live_p) return;
+    const size_t tt = (size_t)tiles_total;
+    double* out = part + (((size_t)chunk * nres + r) * 2) * tt * 4096 + (size_t)(tm * tiles_n + tn) * 4096;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * a + q + 4 * i, col = 16 * w + m;
+            if (WITH_G) out[row * 64 + col] = accG[a][i];
+            if (WITH_P) out[tt * 4096 + row * 64 + col] = accP[a][i];
+        }
+}
+
 // ---------------------------------------------------------------------------
 // K_G4: the same Gram products on v_mfma_f64_4x4x4_4b_f64 (four independent
 // 4x4x4 products per instruction, 16 cycles: the same 32 flop/cycle/SIMD as the

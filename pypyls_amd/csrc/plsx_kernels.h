@@ -1859,8 +1859,53 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                     rsM, (__attribute__((address_space(3))) void*)(buf + p * 128), 16, lane * 16, p * 1024, 0, 0);
         };
         if (NKS < 0) issue_c(0, sm_u);                     // (NKS == 0: issue() above did it)
-        __syncthreads();
         d4 acc[LT];
+        if constexpr (NKS < 0) {
+            // the R fragments of stage q + 1 are fetched while stage q is multiplied (with only
+            // four k-steps in flight the MFMA pipe sat idle 57 % of the time: SQ_VALU_MFMA_BUSY)
+            constexpr int KCC = PLSX_UROT_KC;
+            auto load_stage = [&](int q, double (&a)[KCC]) {
+                const int r = r_beg + q / nch, ks0 = (q % nch) * KCC;
+                __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+#pragma unroll
+                for (int ks = 0; ks < KCC; ++ks)
+                    a[ks] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                           rsR, rvoff, min(ks0 + ks, nks_t - 1) * rstep, 0));
+            };
+            double a_cur[KCC];
+            load_stage(0, a_cur);
+            __syncthreads();
+            for (int q = 0; q < nq; ++q) {
+                const int c = q % nch;
+                const int len = min(KCC, nks_t - c * KCC);
+                const double* sM = sm_u + (q & 1) * stage_c + lane;
+                if (q + 1 < nq) issue_c(q + 1, sm_u + ((q + 1) & 1) * stage_c);
+                double a_next[KCC];
+                load_stage(min(q + 1, nq - 1), a_next);
+                if (c == 0) {
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int ks = 0; ks < KCC; ++ks)
+                    if (ks < len) {
+#pragma unroll
+                        for (int l = 0; l < LT; ++l) acc[l] = mfma_f64(a_cur[ks], sM[(ks * LT + l) * 64], acc[l]);
+                    }
+                if (c == nch - 1) {
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        sum[l] += acc[l];
+                        sq[l] += acc[l] * acc[l];
+                    }
+                }
+#pragma unroll
+                for (int ks = 0; ks < KCC; ++ks) a_cur[ks] = a_next[ks];
+                __syncthreads();     // drains the copy of the next stage, frees this buffer
+            }
+        } else {
+        __syncthreads();
         for (int q = 0; q < nq; ++q) {
             const int r = r_beg + q / nch, c = q % nch;
             const int ks0 = c * KC, len = min(KC, nks_t - ks0);
@@ -1897,6 +1942,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                 }
             }
             __syncthreads();         // drains the copy of the next stage, frees this buffer
+        }
         }
     }
     if (!live) return;

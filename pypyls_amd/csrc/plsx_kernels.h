@@ -926,26 +926,27 @@ void k_gram(const double* __restrict__ R, long long strideR, int ldr, int Tp,
 // so every ds_read_b128 of a fragment is lane-linear), double buffered, one barrier per step; the
 // B operands (rows of R / of U0^T of the wave's own column tile) stay register-streamed.  Same
 // block enumeration, output layout and MODE as k_gram.
-template <int MODE>
-__global__ __launch_bounds__(256)
-void k_gram_lds(const double* __restrict__ R, long long strideR, int ldr, int Tp,
-                const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
-                double* __restrict__ part, int nres, int tiles_n, int tiles_total, int enum_n, int upper)
+// One 64 x 64 output block.  LW == 4: wave w owns column tile w and multiplies it with the LA live row
+// tiles of the A side (LA < 4 only in the last block row).  LW < 4 (last block column: only LW column
+// tiles are live): the roles turn -- wave w owns ROW tile w and multiplies it with the LW column tiles, so
+// that all four waves work instead of LW of them (at T' = 200 four of the ten upper blocks have one
+// live column tile: 70 % of the SIMD slots of the launch were the ceiling).
+template <int MODE, int LA, int LW>
+__device__ __forceinline__ void gram_lds_block(const double* __restrict__ R, long long strideR, int ldr, int Tp,
+                                               const double* __restrict__ U0T, int ldu, int L, int B,
+                                               int cols_per_chunk, double* __restrict__ part, int nres, int tiles_n,
+                                               int tiles_total, int tm, int tn, double (*sA)[8 * 128])
 {
     constexpr bool WITH_P = (MODE != 0), WITH_G = (MODE != 2);
-    __shared__ __attribute__((aligned(16))) double sA[2][8 * 128];      // two stages of 8 pieces x 64 lanes x d2
+    constexpr bool TURNED = LW < 4;
+    constexpr int NB = TURNED ? LW : 1;       // column tiles whose B operands this wave streams
+    constexpr int NA = TURNED ? 1 : LA;       // row tiles it reads from LDS
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int chunk = blockIdx.x, r = blockIdx.y;
-    int tm = 0, tn = 0;
-    {
-        int z = blockIdx.z;
-        if (upper == 1) { while (z >= enum_n - tm) { z -= enum_n - tm; ++tm; } tn = tm + z; }
-        else if (upper == 2) { tm = 1; while (z >= tm) { z -= tm; ++tm; } tn = z; }      // strictly lower blocks
-        else { tm = z / enum_n; tn = z - tm * enum_n; }
-    }
     const int ra0 = 64 * tm, rb0 = 64 * tn;
-    const bool live_g = WITH_G && rb0 + 16 * w < Tp, live_p = WITH_P && rb0 + 16 * w < L;
+    const bool live = TURNED ? (ra0 + 16 * w < Tp)
+                             : ((WITH_G && rb0 + 16 * w < Tp) || (WITH_P && rb0 + 16 * w < L));
     const int cbeg = chunk * cols_per_chunk;
     const int cend = min(B, cbeg + cols_per_chunk);
     const int nsteps = (cend - cbeg + 15) / 16;
@@ -970,67 +971,119 @@ void k_gram_lds(const double* __restrict__ R, long long strideR, int ldr, int Tp
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsA, (__attribute__((address_space(3))) void*)(&sA[buf][(swave + 4 * k) * 128]), 16, voff[k], c0 * 8, 0, 0);
     };
-    const double* pb = Rr + (size_t)min(rb0 + 16 * w + m, Tp - 1) * ldr + 2 * q;
-    const double* pu = WITH_P ? U0T + (size_t)min(rb0 + 16 * w + m, L - 1) * ldu + 2 * q : nullptr;
-    d4 accG[4], accP[4];
+    const double* pb[NB];
+    const double* pu[NB];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
-    d2 xb[2], ub[2];
-    xb[0] = xb[1] = ub[0] = ub[1] = (d2){0, 0};
-    auto load_b = [&](int step, d2 (&b)[2], d2 (&u)[2]) {
+    for (int t = 0; t < NB; ++t) {
+        const int ct = TURNED ? t : w;        // column tile
+        pb[t] = Rr + (size_t)min(rb0 + 16 * ct + m, Tp - 1) * ldr + 2 * q;
+        pu[t] = WITH_P ? U0T + (size_t)min(rb0 + 16 * ct + m, L - 1) * ldu + 2 * q : nullptr;
+    }
+    constexpr int NACC = TURNED ? LW : 4;
+    d4 accG[NACC], accP[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) { accG[a] = (d4){0, 0, 0, 0}; accP[a] = (d4){0, 0, 0, 0}; }
+    d2 xb[NB][2], ub[NB][2];
+    auto load_b = [&](int step, d2 (&b)[NB][2], d2 (&u)[NB][2]) {
         const int c0 = min(cbeg + 16 * step, ldr - 16);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (WITH_G) b[j] = *reinterpret_cast<const d2*>(pb + c0 + 8 * j);
-            if (WITH_P) u[j] = *reinterpret_cast<const d2*>(pu + c0 + 8 * j);
-        }
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b[t][j] = WITH_G ? *reinterpret_cast<const d2*>(pb[t] + c0 + 8 * j) : (d2){0, 0};
+                u[t][j] = WITH_P ? *reinterpret_cast<const d2*>(pu[t] + c0 + 8 * j) : (d2){0, 0};
+            }
     };
     issue(0, 0);
     load_b(0, xb, ub);
     for (int s = 0; s < nsteps; ++s) {
         __syncthreads();                      // stage s landed (issued one step ago), stage s - 1 fully read
         if (s + 1 < nsteps) issue(s + 1, (s + 1) & 1);
-        d2 nb[2], nu[2];
-        nb[0] = nb[1] = nu[0] = nu[1] = (d2){0, 0};
+        d2 nb[NB][2], nu[NB][2];
         load_b(min(s + 1, nsteps - 1), nb, nu);
         if (cbeg + 16 * s + 16 > cend) {      // ragged last step: columns >= cend contribute nothing
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < NB; ++t)
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    if (cbeg + 16 * s + 8 * j + 2 * q + e >= cend) { xb[j][e] = 0.0; ub[j][e] = 0.0; }
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        if (cbeg + 16 * s + 8 * j + 2 * q + e >= cend) { xb[t][j][e] = 0.0; ub[t][j][e] = 0.0; }
         }
-        if (live_g || live_p) {               // (a wave whose column tile lies beyond T' and L only copies)
+        if (live) {                           // (a wave with nothing to contribute only copies)
             const double* st = &sA[s & 1][0];
-            d2 xa[4][2];
+            d2 xa[NA][2];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xa[a][j] = *reinterpret_cast<const d2*>(st + ((a * 2 + j) * 64 + lane) * 2);
+                for (int j = 0; j < 2; ++j) {
+                    const int at = TURNED ? w : a;
+                    xa[a][j] = *reinterpret_cast<const d2*>(st + ((at * 2 + j) * 64 + lane) * 2);
+                }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e) {
+                    if constexpr (TURNED) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        if (WITH_G) accG[a] = mfma_f64(xa[a][j][e], xb[j][e], accG[a]);
-                        if (WITH_P) accP[a] = mfma_f64(xa[a][j][e], ub[j][e], accP[a]);
+                        for (int t = 0; t < LW; ++t) {
+                            if (WITH_G) accG[t] = mfma_f64(xa[0][j][e], xb[t][j][e], accG[t]);
+                            if (WITH_P) accP[t] = mfma_f64(xa[0][j][e], ub[t][j][e], accP[t]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < LA; ++a) {
+                            if (WITH_G) accG[a] = mfma_f64(xa[a][j][e], xb[0][j][e], accG[a]);
+                            if (WITH_P) accP[a] = mfma_f64(xa[a][j][e], ub[0][j][e], accP[a]);
+                        }
                     }
+                }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { xb[j] = nb[j]; ub[j] = nu[j]; }
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { xb[t][j] = nb[t][j]; ub[t][j] = nu[t][j]; }
     }
-    if (!live_g && !live_p) return;
+    if (!live) return;
     const size_t tt = (size_t)tiles_total;
     double* out = part + (((size_t)chunk * nres + r) * 2) * tt * 4096 + (size_t)(tm * tiles_n + tn) * 4096;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < (TURNED ? LW : LA); ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = 16 * a + q + 4 * i, col = 16 * w + m;
+            const int row = 16 * (TURNED ? w : a) + q + 4 * i, col = 16 * (TURNED ? a : w) + m;
             if (WITH_G) out[row * 64 + col] = accG[a][i];
             if (WITH_P) out[tt * 4096 + row * 64 + col] = accP[a][i];
         }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_gram_lds(const double* __restrict__ R, long long strideR, int ldr, int Tp,
+                const double* __restrict__ U0T, int ldu, int L, int B, int cols_per_chunk,
+                double* __restrict__ part, int nres, int tiles_n, int tiles_total, int enum_n, int upper)
+{
+    __shared__ __attribute__((aligned(16))) double sA[2][8 * 128];      // two stages of 8 pieces x 64 lanes x d2
+    int tm = 0, tn = 0;
+    {
+        int z = blockIdx.z;
+        if (upper == 1) { while (z >= enum_n - tm) { z -= enum_n - tm; ++tm; } tn = tm + z; }
+        else if (upper == 2) { tm = 1; while (z >= tm) { z -= tm; ++tm; } tn = z; }      // strictly lower blocks
+        else { tm = z / enum_n; tn = z - tm * enum_n; }
+    }
+    // live 16-row tiles of the A side and live column tiles (G: rows of R, P: rows of U0^T) of this block
+    const int la = min(4, (Tp - 64 * tm + 15) / 16);
+    const int ncol = (MODE == 0) ? Tp : ((MODE == 2) ? L : max(Tp, L));
+    const int lw = min(4, (ncol - 64 * tn + 15) / 16);
+#define GRAM_LDS(LA, LW) gram_lds_block<MODE, LA, LW>(R, strideR, ldr, Tp, U0T, ldu, L, B, cols_per_chunk, part, nres, \
+                                                      tiles_n, tiles_total, tm, tn, sA)
+    if (lw == 1) GRAM_LDS(4, 1);
+    else if (lw == 2) GRAM_LDS(4, 2);       // (three live column tiles: turning the roles was measured slower)
+    else if (la == 1) GRAM_LDS(1, 4);
+    else if (la == 2) GRAM_LDS(2, 4);
+    else if (la == 3) GRAM_LDS(3, 4);
+    else GRAM_LDS(4, 4);
+#undef GRAM_LDS
 }
 
 // ---------------------------------------------------------------------------

@@ -2180,22 +2180,46 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
             for (int ks = 0; ks < NKS; ++ks) { a1[ks] = n1[ks]; a2[ks] = n2[ks]; }
         }
     } else {
-        for (int tile = t0 + wave; tile < t1; tile += 4) {
-            d4 e1[LT], e2[LT];
-#pragma unroll
-            for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
+        // generic k-step count: the R fragments travel in pieces of KP k-steps, the next piece (of this
+        // tile or the first of the wave's next tile) in flight while the current one is multiplied
+        constexpr int KP = 8;
+        const int npc = (nks_t + KP - 1) / KP;                       // pieces per tile
+        const int ntl = (t1 - (t0 + wave) + 3) / 4;                  // tiles of this wave
+        const int nseq = ntl > 0 ? ntl * npc : 0;
+        auto load_piece = [&](int sq, double (&x1)[KP], double (&x2)[KP]) {
+            const int tile = t0 + wave + 4 * (sq / npc), k0p = (sq % npc) * KP;
             const int vo = tile_off(tile);
-            for (int ks = 0; ks < nks_t; ++ks) {
-                const double a1 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, ks * rstep, 0));
-                const double a2 = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, vo, ks * rstep, 0));
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
-                    const double mv = sM[(ks * LT + l) * 64];
-                    e1[l] = mfma_f64(a1, mv, e1[l]);
-                    e2[l] = mfma_f64(a2, mv, e2[l]);
-                }
+            for (int u = 0; u < KP; ++u) {
+                const int ks = min(k0p + u, nks_t - 1);
+                x1[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs1, vo, ks * rstep, 0));
+                x2[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs2, vo, ks * rstep, 0));
             }
-            accumulate(tile * 16, e1, e2);
+        };
+        double a1[KP], a2[KP];
+        if (nseq > 0) load_piece(0, a1, a2);
+        d4 e1[LT], e2[LT];
+        for (int sq = 0; sq < nseq; ++sq) {
+            const int pc = sq % npc, k0p = pc * KP;
+            double n1[KP], n2[KP];
+            load_piece(min(sq + 1, nseq - 1), n1, n2);
+            if (pc == 0) {
+#pragma unroll
+                for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
+            }
+#pragma unroll
+            for (int u = 0; u < KP; ++u)
+                if (k0p + u < nks_t) {
+#pragma unroll
+                    for (int l = 0; l < LT; ++l) {
+                        const double mv = sM[((k0p + u) * LT + l) * 64];
+                        e1[l] = mfma_f64(a1[u], mv, e1[l]);
+                        e2[l] = mfma_f64(a2[u], mv, e2[l]);
+                    }
+                }
+            if (pc == npc - 1) accumulate((t0 + wave + 4 * (sq / npc)) * 16, e1, e2);
+#pragma unroll
+            for (int u = 0; u < KP; ++u) { a1[u] = n1[u]; a2[u] = n2[u]; }
         }
     }
     // reduce over the four row groups of the wave (lanes l, l+16, l+32, l+48)

@@ -101,7 +101,9 @@ def regression_case(rs, idx):
     S = int(rs.randint(12, 90))
     B = int(rs.choice([5, 40, 300, 1200]))
     T = int(rs.choice([1, 3, 8, 20]))
-    k = int(rs.randint(1, min(S - 3, B, T, 12) + 1))      # beyond rank(Y) = T the components are noise-defined
+    # beyond rank(Y) = T the components are noise-defined; a bootstrap of S rows keeps ~0.63 S distinct ones,
+    # components beyond the centred rank of a resample are arbitrary (in the reference too)
+    k = int(rs.randint(1, max(1, min(S // 2 - 2, B, T, 12)) + 1))
     X = rs.randn(S, B) + rs.rand(1, B)
     Y = rs.randn(S, T)
     m = min(T, B)

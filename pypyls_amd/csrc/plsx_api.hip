@@ -593,7 +593,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
         const int pitch = std::max(nt_t, nt_l), tiles = nt_t * pitch;
         const int nz_g = mode != 2 ? nt_t * (nt_t + 1) / 2 : 0, nz_p = mode != 0 ? nt_t * nt_l : 0;
         const int maxchunk = std::max(1, ctx->B / 512);
-        int nchunk = std::max(1, ceil_div(4096, nres * std::max(nz_g, nz_p)));
+        int nchunk = std::max(1, ceil_div(8192, nres * std::max(nz_g, nz_p)));     // (4 chunks at T' = 200, 256 resamples: 0.145 -> 0.139 ms)
         nchunk = std::min(nchunk, maxchunk);
         const int cols = round_up(ceil_div(ctx->B, nchunk), 16);
         nchunk = ceil_div(ctx->B, cols);

@@ -167,6 +167,7 @@ class PLSC(object):
         self.usum.zero_()
         self.usq.zero_()
         if self.args.mode == 'weak':
+            eng.set_perm_path(None)                     # one step = one analysis: it forms its own S x S kernel
             eng.perm_into(self.perm_idx[i], self.out_sv, rotate=True)
             if ev:
                 ev[1].record()
@@ -184,30 +185,62 @@ class PLSC(object):
             ev[3].record()
             self.legs.append(ev)
 
-    def _strong_step(self, i):
-        """One whole analysis: seed-compatible index generation on the host (every
-        rank draws the same arrays from the same seed), this rank's shard to the
-        device, permutations, bootstraps.  The bootstrap arrays are generated in a
-        worker thread while the device runs the permutations."""
+    def _strong_step(self, i, rank=None, world=None):
+        """One whole analysis, the way the front-end runs it (pypyls_amd/plsc.py): ONE
+        RandomState drawn on a host thread in the reference's order -- permutation arrays,
+        then bootstrap arrays (every rank draws the same full arrays from the same seed) --
+        while this rank ships its contiguous shard to the device chunk by chunk as the rows
+        become final (resampling.IndexStream), permutations first, then bootstraps; the
+        S x S kernel of the dual permutation route is formed once per analysis."""
         from pypyls_amd import parallel, resampling
         eng = self.eng
-        rank, world = parallel.rank_world()
-        seed = 4321 + i
-        box = {}
+        if rank is None:
+            rank, world = parallel.rank_world()
+        ps = resampling.IndexStream('perm', self.groups, self.n_cond, self.perms)
+        bs = resampling.IndexStream('boot', self.groups, self.n_cond, self.boots)
+        draws = resampling.DrawThread(np.random.RandomState(4321 + i), [ps.draw, bs.draw]).start()
+        try:
+            eng.set_perm_path(None)
+            lo, hi = parallel.shard_bounds(self.perms, rank, world)
+            for a, b in ps.chunks(lo, hi):
+                eng.perm_into(eng.rows_tensor(ps.rows[a:b]), self.out_sv[a - lo:b - lo], rotate=True)
+            lo, hi = parallel.shard_bounds(self.boots, rank, world)
+            for a, b in bs.chunks(lo, hi):
+                eng.boot_into(eng.rows_tensor(bs.rows[a:b]), self.usum, self.usq, self.dist_out[a - lo:b - lo])
+        finally:
+            draws.thread.join()
+        if draws.error is not None:
+            raise draws.error
 
-        def gen_boots():
-            box['b'] = resampling.gen_bootsamp(self.groups, self.n_cond, self.boots, seed=seed + 500,
-                                               verbose=False)
-        th = threading.Thread(target=gen_boots)
-        perms = resampling.gen_permsamp(self.groups, self.n_cond, self.perms, seed=seed, verbose=False)
-        th.start()
-        lo, hi = parallel.shard_bounds(self.perms, rank, world)
-        if hi > lo:
-            eng.perm_into(eng.index_tensor(perms[:, lo:hi]), self.out_sv[:hi - lo], rotate=True)
-        th.join()
-        lo, hi = parallel.shard_bounds(self.boots, rank, world)
-        if hi > lo:
-            eng.boot_into(eng.index_tensor(box['b'][:, lo:hi]), self.usum, self.usq, self.dist_out[:hi - lo])
+    def emulate(self, worlds, reps=2):
+        """Critical path of ONE analysis on rank r of an emulated world N, measured on this
+        one GPU: the rank draws the full index arrays (as every rank of a real run does),
+        runs only its shard, and the all-gather is skipped (no peers).  Both end ranks are
+        timed -- rank N-1 owns the rows that are drawn last -- and the slower one counts.
+        Returns {N: {'rank0_ms', 'last_rank_ms', 'critical_path_ms'}}."""
+        import torch
+        out = {}
+        for n in worlds:
+            row = {}
+            for label, r in (('rank0_ms', 0), ('last_rank_ms', n - 1)):
+                best = None
+                for rep in range(reps + 1):                 # first pass warms the allocator
+                    self.usum.zero_()
+                    self.usq.zero_()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    self._strong_step(1000 + rep, rank=r, world=n)
+                    torch.cuda.synchronize()
+                    dt = 1e3 * (time.perf_counter() - t0)
+                    if rep > 0:
+                        best = dt if best is None else min(best, dt)
+                row[label] = best
+                if n == 1:
+                    row['last_rank_ms'] = best
+                    break
+            row['critical_path_ms'] = max(row['rank0_ms'], row['last_rank_ms'])
+            out[n] = row
+        return out
 
     def roofline(self, kt, steps, world):
         """Dominant kernel k_xprod.  Algorithmic work per resample of THIS kernel:
@@ -477,6 +510,10 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=8,
                     help='permutations and bootstraps (each) timed for the CPU baseline; 0 = skip')
     ap.add_argument('--no-primal', action='store_true', help='skip the second (feature-pass) timed region')
+    ap.add_argument('--emulate-world', default='',
+                    help='strong mode, one GPU: comma-separated world sizes N; times the critical path of one '
+                         'analysis on rank 0 and on rank N-1 of an emulated world N (full index generation, own '
+                         'shard only, no gather) on both permutation routes and reports the implied efficiency')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
@@ -564,6 +601,23 @@ def main():
         eng.set_timing(False)
         eng.set_perm_path(True)
 
+    emu = None
+    if args.emulate_world and isinstance(wl, PLSC) and args.mode == 'strong' and world == 1:
+        worlds = sorted({1} | {int(v) for v in args.emulate_world.split(',') if v.strip()})
+        emu = {}
+        for route, is_dual in (('dual', True), ('feature_pass', False)):
+            if is_dual and not dual:
+                continue
+            eng.set_perm_path(is_dual)
+            tab = wl.emulate(worlds)
+            base = tab[1]['critical_path_ms']
+            for n, row in tab.items():
+                row['ideal_ms'] = base / n
+                row['efficiency'] = base / (n * row['critical_path_ms'])
+                row['over_ideal'] = row['critical_path_ms'] * n / base
+            emu[route] = {str(n): row for n, row in tab.items()}
+        eng.set_perm_path(True)
+
     if rank == 0:
         units = wl.units_per_step(world)
         value = units * args.steps / elapsed
@@ -590,6 +644,13 @@ def main():
             'scaling': args.mode, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': cfgd, 'roofline': roof,
         }
+        if emu is not None:
+            out['strong_scaling_emulation'] = {
+                'what': 'one analysis of {} + {} resamples; rank r of an emulated world N on ONE GPU: full index '
+                        'generation on the host (as every rank of a real run), own contiguous shard on the device, '
+                        'all-gather skipped; critical path = slower of rank 0 and rank N-1; efficiency = '
+                        't(1) / (N t(N)).  NOT a hardware scaling curve.'.format(wl.perms, wl.boots),
+                'routes': emu}
         if isinstance(wl, PLSC):
             cfgd['perm_path'] = 'dual (S x S kernel; included in value, excluded from value_primal)' if dual \
                 else 'feature pass'

@@ -277,7 +277,11 @@ const char* plsx_kernel_class_name(int kernel_class);
  * features again; dual = 0 takes the feature pass R_p = A_p X per permutation,
  * the same pipeline the bootstrap uses (the north-star pipeline; what
  * bench.py reports as value_primal).  Both give the same statistics to
- * rounding.  Returns the route now in effect (0 / 1) or a negative status.
+ * rounding.  The S x S kernel is a function of the bound data only: the first
+ * dual call after plsx_set_data or after this call forms it, later calls
+ * (chunks of one analysis) reuse it; dual < 0 keeps the route and only drops
+ * that kernel (bench.py: every timed analysis forms its own).  Returns the
+ * route now in effect (0 / 1) or a negative status.
  * Equivalent environment switch at bind time: PLSX_NO_DUAL_PERM=1. */
 int plsx_set_perm_path(plsx_ctx* ctx, int dual);
 
@@ -299,6 +303,15 @@ int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, u
                       int32_t* out);
 int plsx_gen_bootsamp(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
                       int32_t* out);
+/* Streaming variants: identical draws and output; *rows_done (may be NULL) is
+ * stored with release order after every finished row, so that another host
+ * thread can ship rows [0, *rows_done) to the device while later rows are
+ * still being drawn -- the duplicate test only ever looks backwards
+ * (base.py:67-69, 145-149), finished rows never change. */
+int plsx_gen_permsamp_stream(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
+                             int32_t* out, int* rows_done);
+int plsx_gen_bootsamp_stream(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
+                             int32_t* out, int* rows_done);
 int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
                     uint32_t* mt_key, int* mt_pos, uint8_t* out);
 int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_split, double test_size,

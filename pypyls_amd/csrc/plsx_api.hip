@@ -57,7 +57,7 @@ struct plsx_ctx {
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
-    int dual = 0, dual_ok = 0;
+    int dual = 0, dual_ok = 0, has_Kd = 0;              // has_Kd: the S x S kernel of the bound data is current
     int tune = 0;                                       // PLSX_TUNE (measurement switches)
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
@@ -1022,6 +1022,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
     ctx->has_data = ctx->has_orig = false;
+    ctx->has_Kd = 0;
     // a re-bound context keeps its scratch: the padding rows (t >= T') of every R slot must
     // read as zero under the new layout too
     if (ctx->R.p) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
@@ -1248,11 +1249,17 @@ int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, 
               double* d_out_sv, hipStream_t st)
 {
     const int S = ctx->S, Tp = ctx->Tp, Sd = round_up(S, 8);
-    if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
-    const double* Xf = ctx->has_Xn ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
-    if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
-                       ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
-        return e;
+    // K depends on the bound data only: formed by the first permutation call after
+    // plsx_set_data / plsx_set_perm_path and kept for the later ones (a front-end that
+    // ships its permutations in chunks as the index rows arrive pays one pass over X)
+    if (!ctx->has_Kd) {
+        if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
+        const double* Xf = ctx->has_Xn ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
+        if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
+                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
+            return e;
+        ctx->has_Kd = 1;
+    }
     // resamples per pass: 2 GB operands, grid.y / grid.z limits of the tiled GEMM
     long long nb = std::min<long long>(32768, (2LL << 30) / ((long long)Tp * Sd * 8));
     nb = std::min<long long>(nb, 60000LL * 64 / ((long long)Tp * ceil_div(S, 64)));
@@ -1907,7 +1914,8 @@ const char* plsx_kernel_class_name(int kernel_class)
 int plsx_set_perm_path(plsx_ctx* ctx, int dual)
 {
     NEED_DATA();
-    ctx->dual = (dual && ctx->dual_ok) ? 1 : 0;
+    if (dual >= 0) ctx->dual = (dual && ctx->dual_ok) ? 1 : 0;      // dual < 0: keep the route
+    ctx->has_Kd = 0;            // the next dual call forms K again (bench.py: once per timed analysis)
     return ctx->dual;
 }
 
@@ -1928,13 +1936,31 @@ bool bad_design(const int* groups, int n_groups, int n_cond)
 }
 }  // namespace
 
-int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
-                      int32_t* out)
+int plsx_gen_permsamp_stream(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
+                             int32_t* out, int* rows_done)
 {
     plsx_rs::MT rs;
     if (bad_design(groups, n_groups, n_cond) || n_perm < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
         return PLSX_ERR_ARG;
-    const int w = plsx_rs::gen_permsamp(plsx_rs::Design(groups, n_groups, n_cond), n_perm, rs, out);
+    const int w = plsx_rs::gen_permsamp(plsx_rs::Design(groups, n_groups, n_cond), n_perm, rs, out, rows_done);
+    memcpy(mt_key, rs.key, sizeof(rs.key));
+    *mt_pos = rs.pos;
+    return w;
+}
+
+int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
+                      int32_t* out)
+{
+    return plsx_gen_permsamp_stream(groups, n_groups, n_cond, n_perm, mt_key, mt_pos, out, nullptr);
+}
+
+int plsx_gen_bootsamp_stream(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
+                             int32_t* out, int* rows_done)
+{
+    plsx_rs::MT rs;
+    if (bad_design(groups, n_groups, n_cond) || n_boot < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
+        return PLSX_ERR_ARG;
+    const int w = plsx_rs::gen_bootsamp(plsx_rs::Design(groups, n_groups, n_cond), n_boot, rs, out, rows_done);
     memcpy(mt_key, rs.key, sizeof(rs.key));
     *mt_pos = rs.pos;
     return w;
@@ -1943,13 +1969,7 @@ int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, u
 int plsx_gen_bootsamp(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
                       int32_t* out)
 {
-    plsx_rs::MT rs;
-    if (bad_design(groups, n_groups, n_cond) || n_boot < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
-        return PLSX_ERR_ARG;
-    const int w = plsx_rs::gen_bootsamp(plsx_rs::Design(groups, n_groups, n_cond), n_boot, rs, out);
-    memcpy(mt_key, rs.key, sizeof(rs.key));
-    *mt_pos = rs.pos;
-    return w;
+    return plsx_gen_bootsamp_stream(groups, n_groups, n_cond, n_boot, mt_key, mt_pos, out, nullptr);
 }
 
 int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, double test_size, uint32_t* mt_key,
@@ -1980,9 +2000,19 @@ int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_sp
             warn[t] |= plsx_rs::gen_splits(d, n_split, test_size, rs, out + (size_t)i * n_split * d.n_rows);
         }
     };
+    // thread creation may throw (ulimit, container limits) and nothing may unwind through the
+    // C ABI: the streams of a worker that could not be started are drawn on this thread
     std::vector<std::thread> pool;
-    for (int t = 1; t < nth; ++t) pool.emplace_back(work, t);
+    std::vector<int> inline_work;
+    for (int t = 1; t < nth; ++t) {
+        try {
+            pool.emplace_back(work, t);
+        } catch (...) {
+            inline_work.push_back(t);
+        }
+    }
     work(0);
+    for (int t : inline_work) work(t);
     for (auto& th : pool) th.join();
     int w = 0;
     for (int v : warn) w |= v;

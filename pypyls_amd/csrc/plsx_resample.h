@@ -23,7 +23,6 @@
 #include <algorithm>
 #include <cmath>
 #include <string.h>
-#include <unordered_map>
 #include <vector>
 
 namespace plsx_rs {
@@ -39,26 +38,24 @@ struct MT {
         }
         pos = 624;
     }
+    static inline uint32_t twist(uint32_t a, uint32_t b, uint32_t far_)
+    {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+        return far_ ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    }
     void refill()
     {
-        const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, MA = 0x9908b0dfu;
-        int kk = 0;
-        uint32_t y;
-        for (; kk < 624 - 397; ++kk) {
-            y = (key[kk] & UP) | (key[kk + 1] & LO);
-            key[kk] = key[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
-        }
-        for (; kk < 623; ++kk) {
-            y = (key[kk] & UP) | (key[kk + 1] & LO);
-            key[kk] = key[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
-        }
-        y = (key[623] & UP) | (key[0] & LO);
-        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? MA : 0u);
+        // three dependence-free segments (distance to the words they read >= 227), so the
+        // compiler vectorises each
+        for (int kk = 0; kk < 227; ++kk) key[kk] = twist(key[kk], key[kk + 1], key[kk + 397]);
+        for (int kk = 227; kk < 454; ++kk) key[kk] = twist(key[kk], key[kk + 1], key[kk - 227]);
+        for (int kk = 454; kk < 623; ++kk) key[kk] = twist(key[kk], key[kk + 1], key[kk - 227]);
+        key[623] = twist(key[623], key[0], key[396]);
         pos = 0;
     }
-    uint32_t next()
+    inline uint32_t next()
     {
-        if (pos >= 624) refill();
+        if (__builtin_expect(pos >= 624, 0)) refill();
         uint32_t y = key[pos++];
         y ^= (y >> 11);
         y ^= (y << 7) & 0x9d2c5680u;
@@ -66,27 +63,67 @@ struct MT {
         y ^= (y >> 18);
         return y;
     }
+    void skip(long n)
+    {
+        while (n > 0) {
+            if (pos >= 624) refill();
+            const long take = std::min<long>(n, 624 - pos);
+            pos += (int)take;
+            n -= take;
+        }
+    }
     double sample()
     {
         const uint32_t a = next() >> 5, b = next() >> 6;
         return (a * 67108864.0 + b) / 9007199254740992.0;
     }
+    static inline uint32_t mask_of(uint32_t max)
+    {
+        uint32_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        return mask;
+    }
     uint32_t interval(uint32_t max)
     {
         if (max == 0) return 0;
-        uint32_t mask = max;
-        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t mask = mask_of(max);
         uint32_t v;
         while ((v = (next() & mask)) > max) {}
         return v;
     }
-    // x = permutation of 0..n-1 (numpy permutation(n) / shuffle(arange(n)))
-    void permutation(std::vector<int>& x, int n)
+    void permutation(int* x, int n)
     {
-        x.resize(n);
         for (int i = 0; i < n; ++i) x[i] = i;
-        for (int i = n - 1; i >= 1; --i) std::swap(x[i], x[interval((uint32_t)i)]);
+        if (n < 2) return;
+        // branch-free Fisher-Yates with numpy's masked rejection: a rejected draw swaps
+        // x[i] with itself and does not advance (the accept test is a coin flip the branch
+        // predictor loses ~28 % of the time)
+        uint32_t mask = mask_of((uint32_t)(n - 1));
+        uint32_t i = (uint32_t)(n - 1);
+        while (i >= 1) {
+            if (__builtin_expect(pos + 8 > 624, 0)) {            // slow path near a refill
+                const uint32_t v = next() & mask;
+                if (v <= i) { const int t = x[i]; x[i] = x[v]; x[v] = t; --i; mask >>= (i <= (mask >> 1)); }
+                continue;
+            }
+            int p = pos;
+            for (int u = 0; u < 8 && i >= 1; ++u) {
+                uint32_t y = key[p++];
+                y ^= (y >> 11);
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= (y >> 18);
+                const uint32_t v = y & mask;
+                const uint32_t acc = v <= i;
+                const uint32_t j = acc ? v : i;
+                const int t = x[i]; x[i] = x[j]; x[j] = t;
+                i -= acc;
+                mask >>= (i <= (mask >> 1));
+            }
+            pos = p;
+        }
     }
+    void permutation(std::vector<int>& x, int n) { x.resize(n); permutation(x.data(), n); }
 };
 
 // Row bookkeeping (group-major, then condition, then subject; pyls/structures.py:37-44)
@@ -118,57 +155,93 @@ struct Design {
     }
 };
 
-// Exact duplicate detection among the rows already written: 64-bit hash -> earlier row
-// numbers, byte comparison on a hash hit (the reference compares every earlier
-// column element-wise, base.py:67-69).
+// Exact duplicate detection among the rows already written (the reference compares every
+// earlier column element-wise, base.py:67-69): 64-bit hash of the key bytes in an
+// open-addressing table sized once for the whole run, byte comparison on a hash hit.
 inline uint64_t hash_bytes(const void* p, size_t bytes)
 {
     const unsigned char* c = (const unsigned char*)p;
-    uint64_t h = 0x9e3779b97f4a7c15ull ^ bytes;
+    uint64_t h0 = 0x9e3779b97f4a7c15ull ^ bytes, h1 = 0xc2b2ae3d27d4eb4full;
     size_t i = 0;
-    for (; i + 8 <= bytes; i += 8) {
-        uint64_t w;
-        memcpy(&w, c + i, 8);
-        h = (h ^ w) * 0xff51afd7ed558ccdull;
-        h ^= h >> 32;
+    for (; i + 16 <= bytes; i += 16) {                 // two independent lanes: the multiplies overlap
+        uint64_t w0, w1;
+        memcpy(&w0, c + i, 8);
+        memcpy(&w1, c + i + 8, 8);
+        h0 = (h0 ^ w0) * 0xff51afd7ed558ccdull;
+        h1 = (h1 ^ w1) * 0x9fb21c651e98df25ull;
+        h0 ^= h0 >> 32;
+        h1 ^= h1 >> 29;
     }
-    for (; i < bytes; ++i) h = (h ^ c[i]) * 0x100000001b3ull;
+    for (; i < bytes; ++i) h0 = (h0 ^ c[i]) * 0x100000001b3ull;
+    uint64_t h = (h0 ^ (h1 * 0x9e3779b97f4a7c15ull));
+    h ^= h >> 31;
     return h;
 }
 
 struct SeenRows {
-    std::unordered_multimap<uint64_t, int> idx;      // hash -> row number
+    std::vector<int32_t> slot;                        // row number + 1, 0 = empty
+    std::vector<uint64_t> hashes;                     // hash of every added row
+    uint64_t mask;
     const unsigned char* base;                        // first byte of row 0's key
     size_t pitch, bytes;                              // bytes between rows, key length
-    SeenRows(const void* b, size_t p, size_t n) : base((const unsigned char*)b), pitch(p), bytes(n) {}
-    bool contains(const void* key) const
+    SeenRows(const void* b, size_t p, size_t n, int max_rows)
+        : base((const unsigned char*)b), pitch(p), bytes(n)
     {
-        auto range = idx.equal_range(hash_bytes(key, bytes));
-        for (auto it = range.first; it != range.second; ++it)
-            if (memcmp(base + (size_t)it->second * pitch, key, bytes) == 0) return true;
+        size_t cap = 16;
+        while (cap < 2 * (size_t)std::max(max_rows, 1)) cap <<= 1;
+        slot.assign(cap, 0);
+        hashes.assign((size_t)std::max(max_rows, 1), 0);
+        mask = cap - 1;
+    }
+    bool contains(const void* key, uint64_t h) const
+    {
+        for (uint64_t s = h & mask; slot[s]; s = (s + 1) & mask) {
+            const int row = slot[s] - 1;
+            if (hashes[row] == h && memcmp(base + (size_t)row * pitch, key, bytes) == 0) return true;
+        }
         return false;
     }
-    void add(int row) { idx.emplace(hash_bytes(base + (size_t)row * pitch, bytes), row); }
+    void add(int row, uint64_t h)
+    {
+        hashes[row] = h;
+        uint64_t s = h & mask;
+        while (slot[s]) s = (s + 1) & mask;
+        slot[s] = row + 1;
+    }
 };
 
+// Rows [0, *progress) of `out` are final: a consumer on another thread may ship them to
+// the device while later rows are still being drawn (the duplicate test only ever looks
+// backwards, and the RNG stream is consumed in the reference's order either way).
+typedef int Progress;                                 // plain int in the caller's memory (C ABI)
+inline void publish(Progress* p, int rows_done)
+{
+    if (p) __atomic_store_n(p, rows_done, __ATOMIC_RELEASE);
+}
+
 // pyls/base.py:10-79.  out: (n_perm, S) int32, one permutation per row.
-inline int gen_permsamp(const Design& d, int n_perm, MT& rs, int32_t* out)
+inline int gen_permsamp(const Design& d, int n_perm, MT& rs, int32_t* out, Progress* progress = nullptr)
 {
     const int S = d.n_rows, ns = d.n_subj, nc = d.n_cond;
-    SeenRows seen(out, (size_t)S * 4, (size_t)S * 4);
-    std::vector<int> shuffled((size_t)nc * ns), picked((size_t)nc * ns), perm, ord(nc);
+    const int ng = (int)d.groups.size();
+    SeenRows seen(out, (size_t)S * 4, (size_t)S * 4, n_perm);
+    std::vector<int> shuffled(d.rows), perm(ns), ord(nc);
     std::vector<double> u((size_t)nc * ns);
     int warned = 0;
     for (int i = 0; i < n_perm; ++i) {
         int count = 0;
         bool dup = true;
         int32_t* row = out + (size_t)i * S;
+        uint64_t h = 0;
         while (dup && count < 500) {
             ++count;
             dup = false;
-            // conditions shuffled within subject: random_sample((n_cond, n_g)) per group, argsort over conditions
-            for (size_t gi = 0; gi < d.groups.size(); ++gi) {
+            // conditions shuffled within subject: random_sample((n_cond, n_g)) per group, argsort over
+            // conditions.  With ONE condition the argsort is the identity whatever was drawn: the
+            // 2 n_g words of the stream are stepped over, not tempered and converted.
+            for (int gi = 0; gi < ng; ++gi) {
                 const int g = d.groups[gi], s0 = d.g0[gi];
+                if (nc == 1) { rs.skip(2L * g); continue; }
                 for (int c = 0; c < nc; ++c)
                     for (int s = 0; s < g; ++s) u[(size_t)c * g + s] = rs.sample();
                 for (int s = 0; s < g; ++s) {
@@ -181,35 +254,44 @@ inline int gen_permsamp(const Design& d, int n_perm, MT& rs, int32_t* out)
                         shuffled[(size_t)c * ns + s0 + s] = d.rows[(size_t)ord[c] * ns + s0 + s];
                 }
             }
-            rs.permutation(perm, ns);
-            if (d.groups.size() > 1)
-                for (size_t gi = 0; gi < d.groups.size(); ++gi) {
+            rs.permutation(perm.data(), ns);
+            if (ng > 1)
+                for (int gi = 0; gi < ng; ++gi) {
                     const int a = d.g0[gi], b = a + d.groups[gi];
                     bool inside = true;
                     for (int s = a; s < b && inside; ++s) inside = perm[s] >= a && perm[s] < b;
                     if (inside) dup = true;
                 }
-            for (int c = 0; c < nc; ++c)
-                for (int s = 0; s < ns; ++s) picked[(size_t)c * ns + s] = shuffled[(size_t)c * ns + perm[s]];
-            d.expand(picked, row);
-            if (seen.contains(row)) dup = true;
+            // shuffled[:, perm] in canonical row order (group, condition, subject)
+            size_t k = 0;
+            for (int gi = 0; gi < ng; ++gi)
+                for (int c = 0; c < nc; ++c) {
+                    const int* sh = shuffled.data() + (size_t)c * ns;
+                    const int* pp = perm.data() + d.g0[gi];
+                    for (int s = 0; s < d.groups[gi]; ++s) row[k++] = sh[pp[s]];
+                }
+            h = hash_bytes(row, (size_t)S * 4);
+            if (seen.contains(row, h)) dup = true;
         }
         if (count == 500) warned = 1;
-        seen.add(i);
+        seen.add(i, h);
+        publish(progress, i + 1);
     }
     return warned;
 }
 
 // pyls/base.py:82-159.  out: (n_boot, S) int32.
-inline int gen_bootsamp(const Design& d, int n_boot, MT& rs, int32_t* out)
+inline int gen_bootsamp(const Design& d, int n_boot, MT& rs, int32_t* out, Progress* progress = nullptr)
 {
     const int S = d.n_rows, ns = d.n_subj, nc = d.n_cond;
+    const int ng = (int)d.groups.size();
     const int gmin = *std::min_element(d.groups.begin(), d.groups.end());
     const int min_subj = (int)std::ceil(gmin * 0.5);
     std::vector<SeenRows> seen;
-    for (size_t gi = 0; gi < d.groups.size(); ++gi)
-        seen.emplace_back(out + d.g0[gi], (size_t)S * 4, (size_t)d.groups[gi] * 4);
-    std::vector<int> boot(ns), table((size_t)nc * ns), cnt;
+    for (int gi = 0; gi < ng; ++gi)
+        seen.emplace_back(out + d.g0[gi], (size_t)S * 4, (size_t)d.groups[gi] * 4, n_boot);
+    std::vector<int> boot(ns + 4), cnt;
+    std::vector<uint64_t> h(ng);
     int warned = 0;
     for (int i = 0; i < n_boot; ++i) {
         int count = 0;
@@ -218,30 +300,53 @@ inline int gen_bootsamp(const Design& d, int n_boot, MT& rs, int32_t* out)
         while (dup && count < 500) {
             ++count;
             dup = false;
-            for (size_t gi = 0; gi < d.groups.size(); ++gi) {
+            for (int gi = 0; gi < ng; ++gi) {
                 const int a = d.g0[gi], g = d.groups[gi];
+                const uint32_t gmax = (uint32_t)(g - 1), mask = MT::mask_of(gmax);
                 for (;;) {
                     // draws are subject numbers of the group: counting sort (= np.sort), distinct count
                     cnt.assign(g, 0);
-                    for (int s = 0; s < g; ++s) ++cnt[rs.interval((uint32_t)(g - 1))];
+                    if (gmax == 0) rs.skip(0);                     // interval(0) consumes nothing
+                    else
+                        for (int s = 0; s < g; ++s) {
+                            uint32_t v;
+                            while ((v = (rs.next() & mask)) > gmax) {}
+                            ++cnt[v];
+                        }
+                    if (gmax == 0) cnt[0] = g;
+                    // expansion without a data-dependent inner loop (its trip count 0 / 1 / 2 / ... is a
+                    // misprediction per subject): four unconditional stores, the next subject
+                    // overwrites what ran past this one's count
                     int uniq = 0, k = a;
                     for (int v = 0; v < g; ++v) {
-                        uniq += cnt[v] != 0;
-                        for (int c = 0; c < cnt[v]; ++c) boot[k++] = a + v;
+                        const int c = cnt[v], val = a + v;
+                        uniq += c != 0;
+                        boot[k] = val; boot[k + 1] = val; boot[k + 2] = val; boot[k + 3] = val;
+                        if (__builtin_expect(c > 4, 0))
+                            for (int q = 4; q < c; ++q) boot[k + q] = val;
+                        k += c;
                     }
                     if (uniq >= min_subj) break;
                 }
             }
-            for (int c = 0; c < nc; ++c)
-                for (int s = 0; s < ns; ++s) table[(size_t)c * ns + s] = d.rows[(size_t)c * ns + boot[s]];
-            d.expand(table, row);
+            // rows[:, boot] in canonical row order
+            size_t k = 0;
+            for (int gi = 0; gi < ng; ++gi)
+                for (int c = 0; c < nc; ++c) {
+                    const int* rr = d.rows.data() + (size_t)c * ns;
+                    const int* bb = boot.data() + d.g0[gi];
+                    for (int s = 0; s < d.groups[gi]; ++s) row[k++] = rr[bb[s]];
+                }
             // the reference compares positions [a, b) of the FLAT row vector, subject
             // numbers used as row positions (base.py:145-149)
-            for (size_t gi = 0; gi < d.groups.size(); ++gi)
-                if (seen[gi].contains(row + d.g0[gi])) dup = true;
+            for (int gi = 0; gi < ng; ++gi) {
+                h[gi] = hash_bytes(row + d.g0[gi], (size_t)d.groups[gi] * 4);
+                if (seen[gi].contains(row + d.g0[gi], h[gi])) dup = true;
+            }
         }
         if (count == 500) warned = 1;
-        for (size_t gi = 0; gi < d.groups.size(); ++gi) seen[gi].add(i);
+        for (int gi = 0; gi < ng; ++gi) seen[gi].add(i, h[gi]);
+        publish(progress, i + 1);
     }
     return warned;
 }
@@ -250,7 +355,7 @@ inline int gen_bootsamp(const Design& d, int n_boot, MT& rs, int32_t* out)
 inline int gen_splits(const Design& d, int n_split, double test_size, MT& rs, uint8_t* out)
 {
     const int S = d.n_rows, ns = d.n_subj, nc = d.n_cond;
-    SeenRows seen(out, (size_t)S, (size_t)S);
+    SeenRows seen(out, (size_t)S, (size_t)S, n_split);
     std::vector<uint8_t> split(ns), table((size_t)nc * ns);
     std::vector<int> perm;
     int warned = 0;
@@ -258,6 +363,7 @@ inline int gen_splits(const Design& d, int n_split, double test_size, MT& rs, ui
         int count = 0;
         bool dup = true;
         uint8_t* row = out + (size_t)i * S;
+        uint64_t h = 0;
         while (dup && count < 500) {
             ++count;
             dup = false;
@@ -273,10 +379,11 @@ inline int gen_splits(const Design& d, int n_split, double test_size, MT& rs, ui
             for (int c = 0; c < nc; ++c)
                 for (int s = 0; s < ns; ++s) table[(size_t)c * ns + s] = split[s];
             d.expand(table, row);
-            if (seen.contains(row)) dup = true;
+            h = hash_bytes(row, (size_t)S);
+            if (seen.contains(row, h)) dup = true;
         }
         if (count == 500) warned = 1;
-        seen.add(i);
+        seen.add(i, h);
     }
     return warned;
 }

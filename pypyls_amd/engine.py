@@ -77,6 +77,8 @@ def _load():
         'plsx_simpls_set_row_masks': ([vp, vp, vp, vp], i32),
         'plsx_gen_permsamp': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp], i32),
         'plsx_gen_bootsamp': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp], i32),
+        'plsx_gen_permsamp_stream': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp, ctypes.POINTER(i32)], i32),
+        'plsx_gen_bootsamp_stream': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp, ctypes.POINTER(i32)], i32),
         'plsx_gen_splits': ([vp, i32, i32, i32, c_d, vp, ctypes.POINTER(i32), vp], i32),
         'plsx_gen_splits_seeded': ([vp, i32, i32, i32, c_d, vp, i32, vp], i32),
     }
@@ -99,7 +101,8 @@ def exported_symbols():
              'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
-             'plsx_gen_splits', 'plsx_gen_splits_seeded']
+             'plsx_gen_splits', 'plsx_gen_splits_seeded', 'plsx_gen_permsamp_stream',
+             'plsx_gen_bootsamp_stream']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -417,6 +420,11 @@ class Engine(object):
         """(S, n) host index array -> (n, S) int32 device tensor."""
         return self._index_rows(samples)
 
+    def rows_tensor(self, rows):
+        """(n, S) int32 host rows (one resample per row, already validated) -> device tensor."""
+        torch = _torch()
+        return torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(self.device)
+
     def perm_into(self, idx_dev, out_dev, rotate=True):
         """idx_dev (n, S) int32 device tensor, out_dev (n, L) fp64 device tensor."""
         self._check(self.lib.plsx_perm_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
@@ -434,11 +442,15 @@ class Engine(object):
         self._check(self.lib.plsx_simpls_perm_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
                                                     out_dev.data_ptr(), self._stream()))
 
-    def simpls_boot_into(self, idx_dev, usum, usq, yl_dev):
-        """idx_dev (n, S) int32; usum / usq (B, k) accumulated in place; yl_dev (n, T, k)."""
-        self._check(self.lib.plsx_simpls_boot_batch(self.ctx, idx_dev.data_ptr(), None, idx_dev.shape[0],
-                                                    usum.data_ptr(), usq.data_ptr(), yl_dev.data_ptr(),
-                                                    self._stream()))
+    def simpls_boot_into(self, idx_dev, usum, usq, yl_dev, ystack=None):
+        """idx_dev (n, S) int32; usum / usq (B, k) accumulated in place; yl_dev (n, T, k);
+        ystack (n, S, T) device tensor: one Y per bootstrap (3-D Y), or None."""
+        if ystack is not None and tuple(ystack.shape) != (idx_dev.shape[0], self.S, self.T):
+            raise ValueError('ystack must have shape ({}, {}, {})'.format(idx_dev.shape[0], self.S, self.T))
+        self._check(self.lib.plsx_simpls_boot_batch(self.ctx, idx_dev.data_ptr(),
+                                                    None if ystack is None else ystack.data_ptr(),
+                                                    idx_dev.shape[0], usum.data_ptr(), usq.data_ptr(),
+                                                    yl_dev.data_ptr(), self._stream()))
 
     def split_half_into(self, perm_dev, masks_dev, uc_dev, vc_dev):
         """perm_dev (np, S) int32 or None, masks_dev (np, ns, S) uint8, outputs (np, ns, L)."""
@@ -510,8 +522,9 @@ class Engine(object):
         return out
 
     def set_perm_path(self, dual):
-        """Permutations through the S x S dual path (True) or the feature pass."""
-        rc = self.lib.plsx_set_perm_path(self.ctx, 1 if dual else 0)
+        """Permutations through the S x S dual path (True) or the feature pass; None keeps
+        the route and only drops the cached S x S kernel (a new analysis forms its own)."""
+        rc = self.lib.plsx_set_perm_path(self.ctx, -1 if dual is None else (1 if dual else 0))
         if rc < 0:
             self._check(rc)
         return bool(rc)

@@ -129,41 +129,63 @@ def _pad_rows(t, n):
     return torch.cat([t, pad])
 
 
-def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
-    """The one collective of a front-end call.  local_perm (L, p_loc) ndarray or
-    None; local_dist (T', L, r_loc) ndarray or None; usum / usq torch tensors
-    (B, L) or None.  Returns (perm (L, n_perm) | None, dist (T', L, n_boot) |
-    None, usum, usq) identical on every rank."""
+def collect_slices(slices, totals, sums):
+    """THE collective of a front-end call, on tensors that are already where the
+    backend wants them (device tensors under RCCL: the shard results never visit the
+    host before the gather).
+
+    slices: torch tensors whose leading axis is this rank's contiguous shard
+            (shard_bounds) of ``totals[i]`` resamples; sums: tensors to add over
+            ranks.  Returns (list of numpy arrays with the FULL leading axis in
+            global order, list of rank-ordered sums as tensors), identical on every
+            rank.  Without a process group nothing moves."""
+    import torch
     rank, world = rank_world()
     d = _dist()
     if d is None:
-        return local_perm, local_dist, usum, usq
-    import torch
-    with_boot = usum is not None
+        return [t.detach().cpu().numpy() for t in slices], list(sums)
     if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU
-        device = usum.device if with_boot else torch.device('cuda', torch.cuda.current_device())
+        device = torch.device('cuda', torch.cuda.current_device())
+        for t in list(slices) + list(sums):
+            if t.is_cuda:
+                device = t.device
+                break
     else:                                   # gloo (CPU tests / single-GPU dry runs)
         device = torch.device('cpu')
-    slices = []
+    padded = [(t, shard_bounds(n, 0, world)[1]) for t, n in zip(slices, totals)]
+    got, summed = gather_device(padded, sums, device)
+    full = []
+    for blk, n in zip(got, totals):
+        host = blk.cpu().numpy()                                        # (world, nmax, ...)
+        full.append(np.concatenate([host[r][:np.diff(shard_bounds(n, r, world))[0]] for r in range(world)],
+                                   axis=0))
+    return full, summed
+
+
+def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):
+    """Host-array form of :func:`collect_slices` (regression front-end, tests).
+    local_perm (L, p_loc) ndarray or None; local_dist (T', L, r_loc) ndarray or
+    None; usum / usq torch tensors (B, L) or None.  Returns (perm (L, n_perm) |
+    None, dist (T', L, n_boot) | None, usum, usq) identical on every rank."""
+    if _dist() is None:
+        return local_perm, local_dist, usum, usq
+    import torch
+    slices, totals = [], []
     if local_perm is not None:
-        pmax = shard_bounds(n_perm, 0, world)[1]
-        slices.append((torch.from_numpy(np.ascontiguousarray(local_perm.T)).to(device), pmax))
+        slices.append(torch.from_numpy(np.ascontiguousarray(local_perm.T)))
+        totals.append(n_perm)
     if local_dist is not None:
-        rmax = shard_bounds(n_boot, 0, world)[1]
-        slices.append((torch.from_numpy(np.ascontiguousarray(np.moveaxis(local_dist, -1, 0))).to(device), rmax))
-    sums = [usum, usq] if with_boot else []
-    got, summed = gather_device(slices, sums, device)
+        slices.append(torch.from_numpy(np.ascontiguousarray(np.moveaxis(local_dist, -1, 0))))
+        totals.append(n_boot)
+    sums = [usum, usq] if usum is not None else []
+    full, summed = collect_slices(slices, totals, sums)
     perm = dist_out = None
     k = 0
     if local_perm is not None:
-        host = got[k].cpu().numpy()                                     # (world, pmax, L)
+        perm = np.ascontiguousarray(full[k].T)
         k += 1
-        perm = np.concatenate([host[r][:np.diff(shard_bounds(n_perm, r, world))[0]].T
-                               for r in range(world)], axis=1)
     if local_dist is not None:
-        host = got[k].cpu().numpy()                                     # (world, rmax, T', L)
-        dist_out = np.concatenate([np.moveaxis(host[r][:np.diff(shard_bounds(n_boot, r, world))[0]], 0, -1)
-                                   for r in range(world)], axis=2)
-    if with_boot:
+        dist_out = np.ascontiguousarray(np.moveaxis(full[k], 0, -1))
+    if usum is not None:
         usum, usq = summed
     return perm, dist_out, usum, usq

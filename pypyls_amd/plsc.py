@@ -70,11 +70,94 @@ class _PLSCRun(object):
         self.engine = kwargs.get('_engine')
 
     # ------------------------------------------------------------------
+    def _plan_draws(self, L):
+        """Everything the analysis draws from ``self.rs``, in the reference's order
+        (BasePLS.run_pls, base.py:362-397; crossval after the bootstrap,
+        behavioral.py:219-221), as jobs of ONE host thread that starts before the
+        data goes to the device: the SVD's seed matrix, the permutation arrays, the
+        split masks of the original data, the bootstrap arrays, the cross-validation
+        splits.  Only the ORDER of consumption is pinned by a seed; the device takes
+        finished rows while later ones are still drawn (resampling.IndexStream)."""
+        inp = self.inputs
+        S = self.cells.size
+        # the reference's randomized_svd consumes normal((L, L + 10)) from self.rs for the
+        # original decomposition; draw it so that later index arrays match for a seed
+        jobs = [lambda rs: rs.normal(size=(L, L + 10))]
+        self.perm_stream = self.boot_stream = self.ystack = None
+        self.orig_splits = self.cv_splits = None
+        n_perm = inp.get('n_perm') or 0
+        n_boot = inp.get('n_boot') or 0
+        from .engine import check_index_array
+        if n_perm > 0:
+            # BasePLS.permutation, base.py:601-652
+            permsamp = inp.get('permsamples')
+            if permsamp is None:
+                self.perm_stream = resampling.IndexStream('perm', inp.groups, inp.n_cond, n_perm)
+                jobs.append(self.perm_stream.draw)
+            elif not inp.get('permindices'):
+                # pre-permuted Y matrices, (n_perm, S, T) (base.py:636-639)
+                permsamp = np.asarray(permsamp)
+                if self.method != 'behavioral' or permsamp.ndim != 3:
+                    raise ValueError('permindices=False expects `permsamples` of shape '
+                                     '(n_perm, S, T) and behavioral PLS')
+                self.ystack = permsamp.astype(np.float64, copy=False)
+            else:
+                permsamp = np.asarray(permsamp)
+                if permsamp.ndim != 2 or permsamp.shape[0] != S:
+                    raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'
+                                     .format(S, permsamp.shape))
+                self.perm_stream = resampling.IndexStream.of_array(check_index_array(permsamp, S))
+                self.perm_given = permsamp
+        n_split = inp.get('n_split')
+        if (self.perm_stream is not None or self.ystack is not None) and n_split is not None:
+            # the reference draws the split masks of the ORIGINAL data from self.rs after the
+            # permutation arrays and before the bootstrap arrays (base.py:373-380); permutation
+            # i uses a fresh RandomState(i) (base.py:705-708, 738-742)
+            self.orig_splits = inp.get('_splitsamples')
+            if self.orig_splits is None:
+                jobs.append(lambda rs: setattr(self, 'orig_splits', resampling.gen_splits(
+                    inp.groups, inp.n_cond, n_split, seed=rs, test_size=0.5)))
+        if n_boot > 0:
+            # BasePLS.bootstrap, base.py:439-528 (index arrays drawn AFTER the permutation
+            # arrays, as in the reference's run_pls order)
+            bootsamp = inp.get('bootsamples')
+            if bootsamp is None:
+                self.boot_stream = resampling.IndexStream('boot', inp.groups, inp.n_cond, n_boot)
+                jobs.append(self.boot_stream.draw)
+            else:
+                bootsamp = np.asarray(bootsamp)
+                if bootsamp.ndim != 2 or bootsamp.shape[0] != S:
+                    raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'
+                                     .format(S, bootsamp.shape))
+                self.boot_stream = resampling.IndexStream.of_array(check_index_array(bootsamp, S))
+                self.boot_given = bootsamp
+        if (self.method == 'behavioral' and inp.get('test_split') is not None
+                and (inp.get('test_size') or 0) > 0):
+            # behavioral.py:219-221, 82-170
+            self.cv_splits = inp.get('_cvsplits')
+            if self.cv_splits is None:
+                jobs.append(lambda rs: setattr(self, 'cv_splits', resampling.gen_splits(
+                    inp.groups, inp.n_cond, inp.test_split, seed=rs, test_size=inp.test_size)))
+        return resampling.DrawThread(self.rs, jobs)
+
     def run(self):
+        import torch
         from .engine import Engine
         inp = self.inputs
         X = _as_float_array(inp.X, 'X')
         Y = None if self.method == 'meancentered' else _as_float_array(inp.Y, 'Y')
+        Tp = self.n_cells * Y.shape[1] if Y is not None else self.n_cells
+        self.perm_given = self.boot_given = None
+        draws = self._plan_draws(min(Tp, X.shape[1])).start()
+        try:
+            return self._run_device(X, Y, draws)
+        finally:
+            draws.thread.join()                        # never leave the generator running on an error
+
+    def _run_device(self, X, Y, draws):
+        import torch
+        from .engine import Engine
+        inp = self.inputs
         eng = self.engine or Engine()
         eng.set_data(X, Y, self.cells, len(inp.groups), inp.n_cond, _METHOD_CODE[self.method],
                      mean_centering=inp.get('mean_centering') or 0,
@@ -91,95 +174,105 @@ class _PLSCRun(object):
             _check_finite(Y, 'Y')
 
         # ---- original decomposition (BasePLS.svd, base.py:362-364) -------
-        # the reference's randomized_svd consumes normal((L, L + 10)) from
-        # self.rs here; draw it so that later index arrays match for a seed
-        self.rs.normal(size=(L, L + 10))
         xw, sv, yw = eng.decompose()
         xw, yw = hostmath.sign_convention(xw, yw)
         eng.set_original(xw, sv, yw)
         res['x_weights'], res['y_weights'] = xw, yw
         res['x_scores'] = eng.project(xw) + (xmean @ xw)[None, :]
         rank, world = parallel.rank_world()
+        rotate = bool(inp.get('rotate', True))
 
-        # ---- resampling: local shard of permutations and bootstraps, then
-        # ---- ONE collective (parallel.collect) ----------------------------
-        n_perm = inp.get('n_perm') or 0
-        n_boot = inp.get('n_boot') or 0
-        permsamp = bootsamp = local_perm = local_dist = usum = usq = ystack = None
-        if n_perm > 0:
-            # BasePLS.permutation, base.py:601-652
-            permsamp = inp.get('permsamples')
-            if permsamp is None:
-                permsamp = resampling.gen_permsamp(inp.groups, inp.n_cond, n_perm, seed=self.rs,
-                                                   verbose=inp.get('verbose'))
-            permsamp = np.asarray(permsamp)
-            if not inp.get('permindices'):
-                # pre-permuted Y matrices, (n_perm, S, T) (base.py:636-639)
-                if self.method != 'behavioral' or permsamp.ndim != 3:
-                    raise ValueError('permindices=False expects `permsamples` of shape '
-                                     '(n_perm, S, T) and behavioral PLS')
-                ystack, permsamp = permsamp.astype(np.float64, copy=False), None
+        # ---- resampling: this rank's contiguous shard of the permutations and of the
+        # ---- bootstraps, launched chunk by chunk as the index rows arrive; results stay
+        # ---- on the device until THE one collective (parallel.collect_slices) ---------
+        pstream, bstream, ystack = self.perm_stream, self.boot_stream, self.ystack
+        n_perm_tot = pstream.n if pstream is not None else (ystack.shape[0] if ystack is not None else 0)
+        n_boot_tot = bstream.n if bstream is not None else 0
+        d_perm = d_dist = usum = usq = None
+        plo, phi = parallel.shard_bounds(n_perm_tot, rank, world)
+        if pstream is not None:
+            d_perm = eng._zeros((phi - plo, L))
+            for a, b in pstream.chunks(plo, phi):
+                eng.perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - plo:b - plo], rotate=rotate)
+        elif ystack is not None:
+            host = eng.perm_ystack(ystack[plo:phi], rotate=rotate) if phi > plo else np.zeros((L, 0))
+            d_perm = torch.from_numpy(np.ascontiguousarray(host.T)).to(eng.device)
+        if bstream is not None:
+            blo, bhi = parallel.shard_bounds(n_boot_tot, rank, world)
+            usum, usq = eng._zeros((eng.B, L)), eng._zeros((eng.B, L))
+            d_dist = eng._zeros((bhi - blo, eng.Tp, L))
+            for a, b in bstream.chunks(blo, bhi):
+                eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq, d_dist[a - blo:b - blo])
+        # host work that needs no device result runs while the device is busy: the index arrays
+        # in the reference's layout and dtype ((S, n) C-contiguous int64)
+        permsamp = bootsamp = None
+        if pstream is not None:
+            permsamp = self.perm_given if self.perm_given is not None else pstream.samples
+        if bstream is not None:
+            bootsamp = self.boot_given if self.boot_given is not None else bstream.samples
+        draws.join()
+        for st in (pstream, bstream):
+            if st is not None:
+                st.warn()
+        orig_splits = self.orig_splits
         n_split = inp.get('n_split')
-        orig_splits = None
-        if (permsamp is not None or ystack is not None) and n_split is not None:
-            # the reference draws the split masks of the ORIGINAL data from
-            # self.rs after the permutation arrays and before the bootstrap
-            # arrays (base.py:373-380); permutation i uses a fresh
-            # RandomState(i) (base.py:705-708, 738-742)
-            orig_splits = inp.get('_splitsamples')
-            if orig_splits is None:
-                orig_splits = resampling.gen_splits(inp.groups, inp.n_cond, n_split, seed=self.rs,
-                                                    test_size=0.5)
-        if n_boot > 0:
-            # BasePLS.bootstrap, base.py:439-528 (index arrays drawn AFTER the
-            # permutation arrays, as in the reference's run_pls order)
-            bootsamp = inp.get('bootsamples')
-            if bootsamp is None:
-                bootsamp = resampling.gen_bootsamp(inp.groups, inp.n_cond, n_boot, seed=self.rs,
-                                                   verbose=inp.get('verbose'))
-            bootsamp = np.asarray(bootsamp)
-        n_perm_tot = 0 if permsamp is None else permsamp.shape[1]
-        if ystack is not None:
-            n_perm_tot = ystack.shape[0]
-            lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
-            local_perm = eng.perm_ystack(ystack[lo:hi], rotate=bool(inp.get('rotate', True))) \
-                if hi > lo else np.zeros((L, 0))
-        if permsamp is not None:
-            lo, hi = parallel.shard_bounds(permsamp.shape[1], rank, world)
-            local_perm = eng.perm(permsamp[:, lo:hi], rotate=bool(inp.get('rotate', True))) \
-                if hi > lo else np.zeros((L, 0))
-        if bootsamp is not None:
-            lo, hi = parallel.shard_bounds(bootsamp.shape[1], rank, world)
-            if hi > lo:
-                usum, usq, local_dist = eng.boot(bootsamp[:, lo:hi])
-            else:
-                usum, usq = eng._zeros((eng.B, L)), eng._zeros((eng.B, L))
-                local_dist = np.zeros((eng.Tp, L, 0))
-        local_uc = local_vc = None
-        if orig_splits is not None:
-            lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
-            pmasks = inp.get('_perm_splitsamples')
-            if pmasks is None:
-                pmasks = resampling.gen_splits_seeded(inp.groups, inp.n_cond, n_split, np.arange(lo, hi),
-                                                      test_size=0.5, rows=True)
-                rows = True
-            else:
-                pmasks, rows = np.asarray(pmasks)[lo:hi], False
-            if hi > lo:
-                if ystack is not None:
-                    uc, vc = eng.split_half(pmasks, ystack=ystack[lo:hi], mask_rows=rows)
+        slices, totals = [], []
+        if d_perm is not None:
+            if orig_splits is not None:
+                pmasks = inp.get('_perm_splitsamples')
+                if pmasks is None:
+                    pmasks = resampling.gen_splits_seeded(inp.groups, inp.n_cond, n_split, np.arange(plo, phi),
+                                                          test_size=0.5, rows=True)
+                    rows = True
                 else:
-                    uc, vc = eng.split_half(pmasks, perms=permsamp[:, lo:hi], mask_rows=rows)
-                local_uc, local_vc = uc.mean(axis=-1).T, vc.mean(axis=-1).T      # (L, p_loc)
+                    pmasks, rows = np.asarray(pmasks)[plo:phi], False
+                if phi > plo:
+                    if ystack is not None:
+                        uc, vc = eng.split_half(pmasks, ystack=ystack[plo:phi], mask_rows=rows)
+                    else:
+                        uc, vc = eng.split_half(pmasks, perms=pstream.rows[plo:phi].T, mask_rows=rows)
+                    halves = np.hstack([uc.mean(axis=-1), vc.mean(axis=-1)])          # (p_loc, 2 L)
+                else:
+                    halves = np.zeros((0, 2 * L))
+                # ride along with the permutation block of the single collective
+                d_perm = torch.cat([d_perm, torch.from_numpy(halves).to(d_perm.device)], dim=1)
+            slices.append(d_perm)
+            totals.append(n_perm_tot)
+        if d_dist is not None:
+            slices.append(d_dist)
+            totals.append(n_boot_tot)
+        cv_splits = self.cv_splits
+        if cv_splits is not None:
+            # cross-validation (behavioral.py:219-221, 82-170): its shard rides in the same buffer
+            clo, chi = parallel.shard_bounds(cv_splits.shape[1], rank, world)
+            if chi > clo:
+                r, r2 = eng.crossval(cv_splits[:, clo:chi])
+                local_cv = np.vstack([r, r2]).T                                       # (m_loc, 2 T)
             else:
-                local_uc = local_vc = np.zeros((L, 0))
-            # ride along with the permutation block of the single collective
-            local_perm = np.vstack([local_perm, local_uc, local_vc])
-        d_perm, distrib, usum, usq = parallel.collect(
-            local_perm, n_perm_tot,
-            local_dist, bootsamp.shape[1] if bootsamp is not None else 0, usum, usq)
-        if orig_splits is not None:
-            d_perm, ucorrs, vcorrs = d_perm[:L], d_perm[L:2 * L], d_perm[2 * L:]
+                local_cv = np.zeros((0, 2 * Y.shape[1]))
+            slices.append(torch.from_numpy(np.ascontiguousarray(local_cv)).to(eng.device))
+            totals.append(cv_splits.shape[1])
+        sums = [usum, usq] if usum is not None else []
+        full, summed = parallel.collect_slices(slices, totals, sums)
+        if usum is not None:
+            usum, usq = summed
+        k = 0
+        d_perm = distrib = None
+        if n_perm_tot > 0:
+            blk = full[k].T                                                           # (L or 3 L, n_perm)
+            k += 1
+            d_perm = np.ascontiguousarray(blk[:L])
+            if orig_splits is not None:
+                ucorrs, vcorrs = np.ascontiguousarray(blk[L:2 * L]), np.ascontiguousarray(blk[2 * L:])
+        if bstream is not None:
+            distrib = np.ascontiguousarray(np.moveaxis(full[k], 0, -1))               # (T', L, n_boot)
+            k += 1
+        if cv_splits is not None:
+            Tn = Y.shape[1]
+            cv = full[k].T
+            res['cvres'].update(dict(pearson_r=np.ascontiguousarray(cv[:Tn]),
+                                     r_squared=np.ascontiguousarray(cv[Tn:])))
+        if orig_splits is not None and d_perm is not None:
             uc, vc = eng.split_half(orig_splits)
             orig_uc, orig_vc = uc[0].mean(axis=-1), vc[0].mean(axis=-1)
             ci = inp.get('ci', 95)
@@ -233,23 +326,6 @@ class _PLSCRun(object):
                     x_weights_normed=bsr, x_weights_stderr=se, bootsamples=bootsamp,
                     contrast=contrast, contrast_boot=distrib,
                     contrast_ci=np.stack(eng.percentile_ci(distrib, ci=inp.get('ci', 95)), -1)))
-
-        # ---- cross-validation (behavioral.py:219-221, 82-170) ----------------
-        if (self.method == 'behavioral' and inp.get('test_split') is not None
-                and (inp.get('test_size') or 0) > 0):
-            splits = inp.get('_cvsplits')
-            if splits is None:
-                splits = resampling.gen_splits(inp.groups, inp.n_cond, inp.test_split, seed=self.rs,
-                                               test_size=inp.test_size)
-            lo, hi = parallel.shard_bounds(splits.shape[1], rank, world)
-            if hi > lo:
-                r, r2 = eng.crossval(splits[:, lo:hi])
-                local_cv = np.vstack([r, r2])
-            else:
-                local_cv = np.zeros((2 * Y.shape[1], 0))
-            cv, _, _, _ = parallel.collect(local_cv, splits.shape[1], None, 0, None, None)
-            Tn = Y.shape[1]
-            res['cvres'].update(dict(pearson_r=cv[:Tn], r_squared=cv[Tn:]))
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv

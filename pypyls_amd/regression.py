@@ -130,11 +130,54 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
                        seed=seed, verbose=verbose, n_proc=n_proc, **kwargs)
     rs = resampling.check_random_state(seed)
     k = n_components
+    B, T = X.shape[1], Y_agg.shape[1]
 
+    # ---- everything drawn from `rs`, in the reference's order, on one host thread that
+    # ---- starts before the data goes to the device (resampling.DrawThread): the rank-1
+    # ---- randomized SVD's normal((min(B, T), 11)) per component (regression.py:103 ->
+    # ---- compute.py:43-50), the permutation arrays, the bootstrap arrays
+    from .engine import check_index_array
+
+    def svd_seed_draws(r):
+        for _ in range(k):
+            r.normal(size=(min(B, T), 11))
+    jobs = [svd_seed_draws]
+    pstream = bstream = None
+    if n_perm > 0:
+        if permsamples is None:
+            pstream = resampling.IndexStream('perm', [S], 1, n_perm)
+            jobs.append(pstream.draw)
+        else:
+            ps = np.asarray(permsamples)
+            if ps.ndim != 2 or ps.shape[0] != S:
+                raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'.format(S, ps.shape))
+            pstream = resampling.IndexStream.of_array(check_index_array(ps, S))
+    if n_boot > 0:
+        if bootsamples is None:
+            bstream = resampling.IndexStream('boot', [S], 1, n_boot)
+            jobs.append(bstream.draw)
+        else:
+            bs = np.asarray(bootsamples)
+            if bs.ndim != 2 or bs.shape[0] != S:
+                raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'.format(S, bs.shape))
+            bstream = resampling.IndexStream.of_array(check_index_array(bs, S))
+    draws = resampling.DrawThread(rs, jobs).start()
+    try:
+        return _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
+                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'))
+    finally:
+        draws.thread.join()
+
+
+def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,
+                bootsamples_out, k, ci, engine):
+    import torch
+    from .engine import Engine
+    S = len(X)
     # regression.py:395-397 (on copies: the reference centres the caller's X in place)
     Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
     B, T = X.shape[1], Yc.shape[1]
-    eng = kwargs.get('_engine') or Engine()
+    eng = engine or Engine()
     if np.isfinite(X.mean(axis=0)).all() and np.isfinite(Yc).all():
         # no missing data (one cheap pass): the device centres X itself (plsx_set_data),
         # so the S x B matrix is not copied / centred / scanned on the host
@@ -151,10 +194,6 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
             eng.simpls_set_row_masks(okx, oky)
     res = PLSResults(inputs=inputs)
 
-    # the reference's rank-1 randomized SVD draws normal((min(B, T), 11)) per
-    # component from self.rs (regression.py:103 -> compute.py:43-50)
-    for _ in range(k):
-        rs.normal(size=(min(B, T), 11))
     W, pctvar, cvec, _ = eng.simpls_decompose()
     # sign rule of compute.svd: on r (prop. to the x_weights column) when B > T,
     # otherwise on c
@@ -170,40 +209,52 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     res['x_scores'] = x_scores
     rank, world = parallel.rank_world()
 
-    permsamp = bootsamp = local_perm = local_dist = usum = usq = None
-    if n_perm > 0:
-        permsamp = permsamples
-        if permsamp is None:
-            permsamp = resampling.gen_permsamp([S], 1, n_perm, seed=rs, verbose=verbose)
-        permsamp = np.asarray(permsamp)
-    if n_boot > 0:
-        bootsamp = bootsamples
-        if bootsamp is None:
-            bootsamp = resampling.gen_bootsamp([S], 1, n_boot, seed=rs, verbose=verbose)
-        bootsamp = np.asarray(bootsamp)
-    if permsamp is not None:
-        lo, hi = parallel.shard_bounds(permsamp.shape[1], rank, world)
-        local_perm = eng.simpls_perm(permsamp[:, lo:hi]) if hi > lo else np.zeros((k, 0))
-    if bootsamp is not None:
-        lo, hi = parallel.shard_bounds(bootsamp.shape[1], rank, world)
+    # this rank's contiguous shards, launched chunk by chunk as the index rows arrive; the
+    # results stay on the device until the one collective
+    d_perm = d_yl = usum = usq = None
+    n_perm_tot = pstream.n if pstream is not None else 0
+    n_boot_tot = bstream.n if bstream is not None else 0
+    if pstream is not None:
+        lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
+        d_perm = eng._zeros((hi - lo, k))
+        for a, b in pstream.chunks(lo, hi):
+            eng.simpls_perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - lo:b - lo])
+    if bstream is not None:
+        lo, hi = parallel.shard_bounds(n_boot_tot, rank, world)
         usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
-        parts = []
-        step = 256 if third is not None else max(hi - lo, 1)
-        for a0 in range(lo, hi, step):
-            a1 = min(hi, a0 + step)
+        d_yl = eng._zeros((hi - lo, T, k))
+        for a, b in bstream.chunks(lo, hi, first=256, grow=4 if third is None else 1,
+                                   limit=None if third is None else 256):
             ystack = None
             if third is not None:
                 # Y aggregated over the resampled third axis, NOT centred
                 # (the reference bootstraps the original Y, regression.py:308-310, 408)
-                ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a0, a1)])
+                ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a, b)])
                 if masked:
                     ystack = np.nan_to_num(ystack)         # all-NaN rows are dropped by the row masks
-            usum, usq, d = eng.simpls_boot(bootsamp[:, a0:a1], usum, usq, ystack=ystack)
-            parts.append(d)
-        local_dist = np.concatenate(parts, axis=-1) if parts else np.zeros((T, k, 0))
-    d_perm, distrib, usum, usq = parallel.collect(
-        local_perm, permsamp.shape[1] if permsamp is not None else 0,
-        local_dist, bootsamp.shape[1] if bootsamp is not None else 0, usum, usq)
+                ystack = eng._dev(ystack, np.float64)
+            eng.simpls_boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq, d_yl[a - lo:b - lo], ystack=ystack)
+    permsamp = bootsamp = None
+    if pstream is not None:
+        permsamp = np.asarray(permsamples) if permsamples is not None else pstream.samples
+    if bstream is not None:
+        bootsamp = np.asarray(bootsamples) if bootsamples is not None else bstream.samples
+    draws.join()
+    for st in (pstream, bstream):
+        if st is not None:
+            st.warn()
+    slices = [t for t in (d_perm, d_yl) if t is not None]
+    totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
+    full, summed = parallel.collect_slices(slices, totals, [usum, usq] if usum is not None else [])
+    if usum is not None:
+        usum, usq = summed
+    i = 0
+    d_perm = distrib = None
+    if pstream is not None:
+        d_perm = np.ascontiguousarray(full[i].T)                    # (k, n_perm)
+        i += 1
+    if bstream is not None:
+        distrib = np.ascontiguousarray(np.moveaxis(full[i], 0, -1))  # (T, k, n_boot)
     if permsamp is not None:
         res['permres']['pvals'] = hostmath.perm_sig(pctvar, d_perm)
         res['permres']['permsamples'] = permsamp

@@ -45,7 +45,7 @@ def _native():
         return None
 
 
-def _native_call(fn_name, rs, groups, n_cond, n, out, *extra):
+def _native_call(fn_name, rs, groups, n_cond, n, out, *extra, tail=()):
     """Run one native generator on the stream of ``rs`` (a RandomState)."""
     lib = _native()
     state = rs.get_state()
@@ -55,11 +55,21 @@ def _native_call(fn_name, rs, groups, n_cond, n, out, *extra):
     pos = ctypes.c_int(int(state[2]))
     g = np.ascontiguousarray(groups, dtype=np.int32)
     rc = getattr(lib, fn_name)(g.ctypes.data, len(g), int(n_cond), int(n), *extra, key.ctypes.data,
-                               ctypes.byref(pos), out.ctypes.data)
+                               ctypes.byref(pos), out.ctypes.data, *tail)
     if rc < 0:
         raise ValueError('{} failed with status {}'.format(fn_name, rc))
     rs.set_state((state[0], key, pos.value) + tuple(state[3:]))
     return rc + 1                                       # 1 = ok, 2 = duplicate limit hit
+
+
+def _prefaulted(shape, dtype=np.int32):
+    """Zeroed output array whose pages are already mapped: ``np.zeros`` hands out
+    lazily-zeroed pages and the generator then takes one page fault per 4 KB it
+    writes (measured: 65 of 97 ms for a 10 000 x 500 array); a sequential fill
+    maps them at memset speed (5 ms)."""
+    out = np.empty(shape, dtype=dtype)
+    out.fill(0)
+    return out
 
 
 def check_random_state(seed):
@@ -135,7 +145,7 @@ def gen_permsamp(groups, n_cond, n_perm, seed=None, verbose=True):
     """(S, n_perm) permutation index arrays."""
     groups = [int(g) for g in (groups if isinstance(groups, (list, tuple, np.ndarray)) else [groups])]
     rs = check_random_state(seed)
-    out = np.zeros((int(n_perm), int(sum(groups)) * int(n_cond)), dtype=np.int32)
+    out = _prefaulted((int(n_perm), int(sum(groups)) * int(n_cond)))
     done = _native_call('plsx_gen_permsamp', rs, groups, n_cond, n_perm, out)
     if done:
         if done == 2:
@@ -180,7 +190,7 @@ def gen_bootsamp(groups, n_cond, n_boot, seed=None, verbose=True):
     """(S, n_boot) bootstrap index arrays."""
     groups = [int(g) for g in (groups if isinstance(groups, (list, tuple, np.ndarray)) else [groups])]
     rs = check_random_state(seed)
-    out = np.zeros((int(n_boot), int(sum(groups)) * int(n_cond)), dtype=np.int32)
+    out = _prefaulted((int(n_boot), int(sum(groups)) * int(n_cond)))
     done = _native_call('plsx_gen_bootsamp', rs, groups, n_cond, n_boot, out)
     if done:
         if done == 2:
@@ -289,3 +299,135 @@ def _py_gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5):
         seen.add(key)
         out[:, i] = half
     return out
+
+
+# ---------------------------------------------------------------------------
+# streaming generation: rows become final while later rows are still drawn
+# ---------------------------------------------------------------------------
+
+class IndexStream(object):
+    """One seeded index array (``kind`` 'perm' or 'boot') drawn on a host thread
+    while the caller already ships finished rows to the device.
+
+    The reference draws a whole array before its first resample runs
+    (pyls/base.py:362-397, 627-633, 468-476); the ORDER in which the RandomState
+    is consumed is what a seed pins, not when the rows are used.  The duplicate
+    test of both generators only looks backwards (base.py:67-69, 145-149), so rows
+    ``[0, available())`` never change.  ``rows`` is (n, S) int32, one resample per
+    row -- the layout the device consumes; ``samples`` the reference's (S, n)."""
+
+    def __init__(self, kind, groups, n_cond, n):
+        import threading
+        if kind not in ('perm', 'boot'):
+            raise ValueError(kind)
+        self.kind = kind
+        self.groups = [int(g) for g in (groups if isinstance(groups, (list, tuple, np.ndarray)) else [groups])]
+        self.n_cond, self.n = int(n_cond), int(n)
+        self.S = int(sum(self.groups)) * self.n_cond
+        self.rows = _prefaulted((self.n, self.S))
+        self._done = ctypes.c_int(0)
+        self.finished = threading.Event()
+        self.error = None
+        self.duplicates = False
+
+    @classmethod
+    def of_array(cls, samples):
+        """A stream that is complete from the start (caller-supplied (S, n) array)."""
+        samples = np.asarray(samples)
+        st = cls.__new__(cls)
+        st.kind, st.groups, st.n_cond = 'given', None, None
+        st.S, st.n = samples.shape
+        st.rows = np.ascontiguousarray(samples.T, dtype=np.int32)
+        st._done = ctypes.c_int(st.n)
+        import threading
+        st.finished = threading.Event()
+        st.finished.set()
+        st.error, st.duplicates = None, False
+        return st
+
+    def draw(self, rs):
+        """Fill ``rows`` from the stream of ``rs`` (runs on the generator thread)."""
+        try:
+            fn = 'plsx_gen_permsamp_stream' if self.kind == 'perm' else 'plsx_gen_bootsamp_stream'
+            done = _native_call(fn, rs, self.groups, self.n_cond, self.n, self.rows,
+                                tail=(ctypes.byref(self._done),))
+            if not done:
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter('always')
+                    py = _py_gen_permsamp if self.kind == 'perm' else _py_gen_bootsamp
+                    self.rows[:] = py(self.groups, self.n_cond, self.n, rs).T
+                self.duplicates = any('Duplicate' in str(w.message) for w in caught)
+            else:
+                self.duplicates = done == 2
+            self._done.value = self.n
+        except BaseException as exc:                     # surfaced by wait() on the consumer side
+            self.error = exc
+        finally:
+            self.finished.set()
+
+    def available(self):
+        return self.n if (self.finished.is_set() and self.error is None) else int(self._done.value)
+
+    def wait(self, upto):
+        """Block until rows [0, upto) are final; returns available()."""
+        import time
+        upto = min(int(upto), self.n)
+        while self._done.value < upto and not self.finished.is_set():
+            time.sleep(2e-5)
+        if self.error is not None:
+            raise self.error
+        return self.available()
+
+    def warn(self):
+        if self.duplicates:
+            warnings.warn('WARNING: Duplicate {} used.'.format(
+                'permutations' if self.kind == 'perm' else 'bootstraps'))
+
+    @property
+    def samples(self):
+        """(S, n) index array in the reference's layout and dtype (C-contiguous int64)."""
+        self.wait(self.n)
+        return np.ascontiguousarray(self.rows.T, dtype=np.int64)
+
+    def chunks(self, lo, hi, first=256, grow=4, limit=None):
+        """Row ranges [a, b) covering [lo, hi) as they become final: a first small
+        one so that the device starts early, then everything that has arrived
+        (at most ``limit`` rows per range)."""
+        pos, size = int(lo), int(first)
+        while pos < hi:
+            want = min(hi, pos + size)
+            have = self.wait(want)
+            if limit is not None:
+                have = min(have, pos + int(limit))
+            end = min(hi, max(want, have))
+            yield pos, end
+            pos, size = end, size * grow
+
+
+class DrawThread(object):
+    """Runs an ordered list of draws on ONE RandomState in a host thread, in the
+    reference's order (run_pls: SVD seed matrix, permutation arrays, split masks
+    of the original data, bootstrap arrays, cross-validation splits --
+    pyls/base.py:362-397, pyls/types/behavioral.py:219-221).  ``jobs`` are
+    callables taking the RandomState; their results are read after ``join``."""
+
+    def __init__(self, rs, jobs):
+        import threading
+        self.rs, self.jobs, self.error = rs, list(jobs), None
+        self.thread = threading.Thread(target=self._run, name='plsx-draws', daemon=True)
+
+    def start(self):
+        self.thread.start()
+        return self
+
+    def _run(self):
+        try:
+            for job in self.jobs:
+                job(self.rs)
+        except BaseException as exc:
+            self.error = exc
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error

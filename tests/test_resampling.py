@@ -157,3 +157,55 @@ def test_native_generators_are_fast():
     b = rsmp.gen_bootsamp([500], 1, 10000, seed=2)
     dt = time.perf_counter() - t0
     assert p.shape == b.shape == (500, 10000) and dt < 1.0, dt
+
+
+@pytest.mark.parametrize('groups,n_cond', [([40], 1), ([9, 11], 2), ([5, 7, 6], 3)])
+def test_streamed_draws_equal_the_blocking_generators(groups, n_cond):
+    """resampling.IndexStream / DrawThread: the same RandomState consumed in the same
+    order on a host thread gives the arrays (and the stream position) of the blocking
+    calls; rows handed out by chunks() are final when they are handed out."""
+    n = 300
+    rs = np.random.RandomState(77)
+    ps = rsmp.IndexStream('perm', groups, n_cond, n)
+    bs = rsmp.IndexStream('boot', groups, n_cond, n)
+    seen = []
+    th = rsmp.DrawThread(rs, [lambda r: r.normal(size=(3, 13)), ps.draw, bs.draw]).start()
+    for st in (ps, bs):
+        got = []
+        for a, b in st.chunks(37, 290, first=16, grow=2):
+            assert 37 <= a < b <= 290 and b <= st.available()
+            got.append(st.rows[a:b].copy())                 # copy NOW: must not change later
+        seen.append(np.vstack(got))
+    th.join()
+    ref_rs = np.random.RandomState(77)
+    ref_rs.normal(size=(3, 13))
+    perm = rsmp.gen_permsamp(groups, n_cond, n, seed=ref_rs, verbose=False)
+    boot = rsmp.gen_bootsamp(groups, n_cond, n, seed=ref_rs, verbose=False)
+    np.testing.assert_array_equal(ps.samples, perm)
+    np.testing.assert_array_equal(bs.samples, boot)
+    np.testing.assert_array_equal(seen[0], perm.T[37:290])
+    np.testing.assert_array_equal(seen[1], boot.T[37:290])
+    assert ps.samples.dtype == np.int64 and ps.samples.flags['C_CONTIGUOUS']   # the reference's layout
+    assert rs.randint(1 << 30) == ref_rs.randint(1 << 30)                      # stream position preserved
+
+
+def test_stream_of_given_array_and_errors():
+    arr = rsmp.gen_permsamp([12], 1, 9, seed=3, verbose=False)
+    st = rsmp.IndexStream.of_array(arr)
+    assert st.available() == 9 and list(st.chunks(2, 9, first=4)) == [(2, 9)]
+    np.testing.assert_array_equal(st.samples, arr)
+    # an exception on the generator thread surfaces in the consumer
+    bad = rsmp.IndexStream('perm', [12], 1, 5)
+    th = rsmp.DrawThread(None, [bad.draw]).start()          # rs = None: get_state fails
+    with pytest.raises(Exception):
+        bad.wait(5)
+    th.thread.join()
+
+
+def test_python_fallback_stream(monkeypatch):
+    """PLSX_PY_RESAMPLE=1: the stream falls back to the Python loops, same arrays."""
+    monkeypatch.setenv('PLSX_PY_RESAMPLE', '1')
+    st = rsmp.IndexStream('boot', [7, 8], 2, 20)
+    rsmp.DrawThread(np.random.RandomState(5), [st.draw]).start().join()
+    monkeypatch.delenv('PLSX_PY_RESAMPLE')
+    np.testing.assert_array_equal(st.samples, rsmp.gen_bootsamp([7, 8], 2, 20, seed=5, verbose=False))

@@ -35,7 +35,7 @@ struct plsx_ctx {
     // resampled rows come out of the same pass); scaled: the epilogue also applies 1/std
     // to R (correlation mode).  Covariance mode keeps the rows for cross-validation's zmap.
     int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, momrows = 0, Gcap = 0, Galloc = 0;
-    int nks_t = 0, LT = 0;
+    int nks_t = 0, LT = 0, cv_mom = 0;
     size_t group_stride = 0;
     // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
     int gps = 0;
@@ -58,7 +58,6 @@ struct plsx_ctx {
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
     int dual = 0, dual_ok = 0, has_Kd = 0;              // has_Kd: the S x S kernel of the bound data is current
-    int tune = 0;                                       // PLSX_TUNE (measurement switches)
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
     Buf psum, psq;                                      // k_urot resample-split partials
     bool has_okx = false, has_oky = false;
@@ -178,7 +177,9 @@ int phys_groups(const plsx_ctx* c, int rgroups) { return c->gps > 0 ? rgroups * 
 int plan_groups(plsx_ctx* c)
 {
     c->scaled = (c->method == PLSX_BEHAVIORAL && !c->cov) ? 1 : 0;   // mean-centred / regression: no feature scaling
-    c->momrows = (c->method == PLSX_BEHAVIORAL) ? 1 : 0;
+    // covariance mode scales nothing: its moment rows only serve cross-validation's zmap and are
+    // planned in for the duration of plsx_crossval_batch (cv_mom), not for permutations / bootstraps
+    c->momrows = (c->method == PLSX_BEHAVIORAL && (!c->cov || c->cv_mom)) ? 1 : 0;
     const int Jw = c->momrows ? c->J : 0;
     c->gps = 0;
     c->h_slice_row0.clear(); c->h_slice_rows.clear(); c->h_slice_cell0.clear(); c->h_slice_ncell.clear();
@@ -350,7 +351,7 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
                        std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg,
-                       SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, ctx->tune}, std::max(ctx->gps, 1));
+                       SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}, std::max(ctx->gps, 1));
     LAUNCHCHK();
     return 0;
 }
@@ -404,7 +405,7 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
                        ptr<double>(ctx->Afrag), ctx->group_stride_f, ptr<double>(ctx->Xn), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npgf * ctx->Tpp,
                        ptr<int>(ctx->out_row_f), ptr<int>(ctx->mom_idx_f), ptr<double>(ctx->mom_n), 0,
-                       groups, ncolblk, (double*)nullptr, SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, ctx->tune}, 1);
+                       groups, ncolblk, (double*)nullptr, SplitEpi{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}, 1);
     LAUNCHCHK();
     return 0;
 }
@@ -947,7 +948,6 @@ int plsx_ctx_create(int device, plsx_ctx** out)
     plsx_ctx* c = new (std::nothrow) plsx_ctx();
     if (!c) return PLSX_ERR_HIP;
     c->device = device;
-    if (const char* env = getenv("PLSX_TUNE")) c->tune = atoi(env);
     if (const char* env = getenv("PLSX_SCRATCH_GB")) {
         if (atof(env) > 0.0) { c->scratch_gb = atof(env); c->scratch_fixed = 1; }
     }
@@ -1375,7 +1375,7 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
     const size_t epi0 = (size_t)NW * 5 * se.nmu * 16 + (size_t)MT * 16;
     const size_t pre0 = round_up((int)std::max(stage, epi0), 128);
     const size_t pre_total = pre0 + (size_t)ctx->Tpp * NW * 16 + (size_t)MT * 16 * 5;
-    se.off_pre = (pre_total * 8 <= 80 * 1024 && !(ctx->tune & 16)) ? (int)pre0 : 0;
+    se.off_pre = (pre_total * 8 <= 80 * 1024) ? (int)pre0 : 0;
     const size_t lds = se.off_pre ? pre_total * 8 : std::max(stage, epi0 + (size_t)MT * 16 * 5) * 8;
     HIPCHK(set_lds(k_xprod<MT, NW, KT, NSQ, true>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
@@ -1426,7 +1426,7 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
     se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
     se.cell_len = ptr<int>(ctx->cell_len);
     se.rowc = ptr<double>(ctx->rowc);
-    se.J = J; se.Tpp = ctx->Tpp; se.tune = ctx->tune;
+    se.J = J; se.Tpp = ctx->Tpp;
     switch (ctx->MT - ctx->sq0) {
         case 1: return launch_xprod_split<1>(ctx, groups, se, st);
         case 2: return launch_xprod_split<2>(ctx, groups, se, st);
@@ -1537,6 +1537,24 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
     return PLSX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+int crossval_impl(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2, hipStream_t st);
+
+// Lay the groups out again with / without the per-cell moment rows (covariance mode carries
+// them only while cross-validation needs the training mean / std of every feature).
+int replan_moments(plsx_ctx* ctx, int want)
+{
+    ctx->cv_mom = want;
+    if (plan_groups(ctx) != 0) return fail(ctx, PLSX_ERR_UNSUPPORTED, "cannot lay out the moment rows of a resample");
+    ctx->Galloc = 0;                                   // scratch sizes follow the new group layout
+    return upload_rowmaps(ctx);
+}
+}  // namespace
+
+extern "C" {
+
 int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2, void* stream)
 {
     NEED_DATA();
@@ -1545,6 +1563,20 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
     if (!d_masks || !d_r || !d_r2 || m < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->momrows) return crossval_impl(ctx, d_masks, m, d_r, d_r2, st);
+    HIPCHK(hipStreamSynchronize(st));                  // the row maps of queued launches are about to change
+    if (int e = replan_moments(ctx, 1)) return e;
+    const int rc = crossval_impl(ctx, d_masks, m, d_r, d_r2, st);
+    HIPCHK(hipStreamSynchronize(st));
+    if (int e = replan_moments(ctx, 0)) return e;
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+int crossval_impl(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2, hipStream_t st)
+{
     const int S = ctx->S, T = ctx->T, J = ctx->J, Tp = ctx->Tp, L = ctx->L;
     // splits per pass: bounded by the super-batch and by the J rescaled copies kept in R2
     int nb = std::max(1, std::min(launch_groups(ctx, m, ctx->npg) * ctx->npg, 256 / std::max(J, 1)));
@@ -1591,6 +1623,9 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
     }
     return PLSX_OK;
 }
+}  // namespace
+
+extern "C" {
 
 // ---- SIMPLS regression (pyls/types/regression.py) ---------------------------
 namespace {

@@ -306,7 +306,6 @@ struct SplitEpi {
     const int* cell_len;     // [J]
     const double* rowc;      // [groups][MT*16][5]: Sy1, 1/((n1-1) sy1), Sy2, 1/((n2-1) sy2), (nF-1) syF
     int J, Tpp;
-    int tune;                // PLSX_TUNE measurement switches (0 in production)
     int nmu;                 // moment rows in use (splits per group x cells)
     int off_pre;             // > 0: doubles offset of the LDS region that receives this block's tile of
                              // Rfull ([Tpp][64]) and its row constants by DMA at kernel start
@@ -500,10 +499,6 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nkt = nks / KT;
-    if ((se.tune & 4) && blockIdx.x < 512) {          // measurement: de-phase the first round of blocks
-        const int n = (blockIdx.x * 37 % 64) * (se.tune >> 8);
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     if constexpr (SPLIT) {
         // Fused split-half: the epilogue needs this block's (Tpp x 64) tile of the
         // arrangement's full-sample R and the group's row constants.  Fetched here by
@@ -630,15 +625,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const double* rc = s_rc + row * 5;
                 const double c1 = acc[m][i];
                 const double rf = pre ? sRf[t * (NW * 16) + wave * 16 + (lane & 15)]
-                                      : ((se.tune & 2) ? 1.0 : se.Rfull[(size_t)t * ldr + col]);
+                                      : se.Rfull[(size_t)t * ldr + col];
                 const double cf = rf * rc[4] * w5[4 * nmu * 16 + o];
                 const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * nmu * 16 + o];
                 const double r2 = ((cf - c1) - rc[2] * w5[2 * nmu * 16 + o]) * rc[3] * w5[3 * nmu * 16 + o];
                 // non-temporal: the 2 x 83 MB per split are read back from HBM by later kernels
-                if (!(se.tune & 1) || r1 == 123.456) {
-                    __builtin_nontemporal_store(r1, &Rg[(size_t)orow * ldr]);
-                    __builtin_nontemporal_store(r2, &Rg[(size_t)(orow + se.Tpp) * ldr]);
-                }
+                __builtin_nontemporal_store(r1, &Rg[(size_t)orow * ldr]);
+                __builtin_nontemporal_store(r2, &Rg[(size_t)(orow + se.Tpp) * ldr]);
             }
         return;
     }
@@ -688,7 +681,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (orow[i] >= 0 && (!(se.tune & 1) || acc[m][i] == 123.456)) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
+            if (orow[i] >= 0) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
     }
 }
 

@@ -36,7 +36,8 @@ enum plsx_status {
     PLSX_ERR_ARG = -1,       /* bad shape / flag / null pointer            */
     PLSX_ERR_UNSUPPORTED = -2, /* shape outside what the device path covers */
     PLSX_ERR_HIP = -3,       /* HIP runtime failure (incl. out of memory)   */
-    PLSX_ERR_STATE = -4      /* call order violated (e.g. no data set)      */
+    PLSX_ERR_STATE = -4,     /* call order violated (e.g. no data set)      */
+    PLSX_ERR_NUMERIC = -5    /* an eigen-solve of a finished batch did not converge (reported by plsx_sync) */
 };
 
 enum plsx_method {

@@ -55,6 +55,7 @@ struct plsx_ctx {
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
+    Buf status;                                         // device word: numerical status bits of the small solvers
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
     int dual = 0, dual_ok = 0, has_Kd = 0;              // has_Kd: the S x S kernel of the bound data is current
@@ -921,6 +922,7 @@ SmallArgs small_args(plsx_ctx* ctx, int mode)
     a.G = ptr<double>(ctx->Gm); a.P = ptr<double>(ctx->Pm);
     a.V0 = ptr<double>(ctx->V0); a.d0 = ptr<double>(ctx->d0);
     a.Mfrag = ptr<double>(ctx->Mfrag); a.nks_t = ctx->nks_t; a.LT = ctx->LT;
+    a.status = ptr<int>(ctx->status);
     return a;
 }
 
@@ -948,6 +950,11 @@ int plsx_ctx_create(int device, plsx_ctx** out)
     plsx_ctx* c = new (std::nothrow) plsx_ctx();
     if (!c) return PLSX_ERR_HIP;
     c->device = device;
+    if (hipMalloc(&c->status.p, sizeof(int)) != hipSuccess || hipMemset(c->status.p, 0, sizeof(int)) != hipSuccess) {
+        delete c;
+        return PLSX_ERR_HIP;
+    }
+    c->status.bytes = sizeof(int);
     if (const char* env = getenv("PLSX_SCRATCH_GB")) {
         if (atof(env) > 0.0) { c->scratch_gb = atof(env); c->scratch_fixed = 1; }
     }
@@ -966,7 +973,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -980,6 +987,15 @@ int plsx_sync(plsx_ctx* ctx)
     if (!ctx) return PLSX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
+    // numerical status of everything that ran since the last call: an eigen-solve that gave up is an
+    // error of the results already written, reported here instead of flowing on silently
+    int st = 0;
+    HIPCHK(hipMemcpy(&st, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        HIPCHK(hipMemset(ctx->status.p, 0, sizeof(int)));
+        return fail(ctx, PLSX_ERR_NUMERIC, "small solver: implicit QL did not converge within 60 iterations for at least "
+                                           "one resample (non-finite or pathological Gram matrix); results of the batch are invalid");
+    }
     return PLSX_OK;
 }
 

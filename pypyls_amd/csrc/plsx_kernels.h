@@ -1481,6 +1481,7 @@ struct SmallArgs {
     int ld;            // column pitch of the work matrices (n | 1)
     int lds_cap;       // QL: doubles of LDS behind the bookkeeping vectors
     double jtol;       // Jacobi stopping threshold on |a_p.a_q| / (|a_p| |a_q|)
+    int* status;       // device word: bit 0 set when an eigen-solve did not converge
 };
 
 // LDS Jacobi variant (T' <= PLSX_JACOBI_TP): both n x (n|1) work matrices in LDS, one block per
@@ -1671,13 +1672,26 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     __shared__ double s_dmax;
     const double* G = a.G + (size_t)r * n * n;
 
+    // G is solved scaled to a unit largest diagonal entry: the shift / rotation recurrences of the
+    // QL phase use absolute guards (1e-280), which data of a very small or very large scale
+    // (covariance mode: G ~ scale^4) would otherwise run into
+    double gm = 0.0;
+    for (int i = tid; i < n; i += nt) gm = fmax(gm, fabs(G[(size_t)i * n + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+    if ((tid & 63) == 0) red[tid >> 6] = gm;
+    __syncthreads();
+    gm = 0.0;
+    for (int w = 0; w < (nt + 63) / 64; ++w) gm = fmax(gm, red[w]);
+    const double gscale = (gm > 0.0 && isfinite(gm)) ? gm : 1.0, ginv = 1.0 / gscale;
+    __syncthreads();
     for (int idx = tid; idx < n * n; idx += nt) {
         const int i = idx % n, c = idx / n;
-        Wa[(size_t)c * ld + i] = 0.5 * (G[(size_t)i * n + c] + G[(size_t)c * n + i]);
+        Wa[(size_t)c * ld + i] = 0.5 * ginv * (G[(size_t)i * n + c] + G[(size_t)c * n + i]);
     }
     __syncthreads();
-    sym_eig<RPT, CH>(Wa, n, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap);
-    for (int c = tid; c < n; c += nt) lam[c] = fmax(dd[c], 0.0);
+    sym_eig<RPT, CH>(Wa, n, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap, a.status);
+    for (int c = tid; c < n; c += nt) lam[c] = fmax(dd[c], 0.0) * gscale;
     __syncthreads();
     for (int c = tid; c < n; c += nt) {
         int rk = 0;
@@ -1736,7 +1750,7 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     }
     __syncthreads();
     se_block_gemm<true>(Wc, ld, Wb, ld, Wb, ld, L, L, n, nullptr);     // H = temp temp^T
-    sym_eig<RPT, CH>(Wc, L, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap);
+    sym_eig<RPT, CH>(Wc, L, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap, a.status);
     if (tid == 0) {
         double mx = 0.0;
         for (int c = 0; c < L; ++c) mx = fmax(mx, dd[c]);

@@ -153,7 +153,8 @@ __device__ __forceinline__ void se_block_gemm(double* C, int ldc, const double* 
 // blockDim.x >= 256.
 template <int RPT, int CH>
 __device__ __forceinline__ void sym_eig(double* W, const int n, const int ld, double* dd, double* ee, double* hh,
-                                        double* uu, double* pp, double* ps, double* red, double* lds_mat, const int lds_cap)
+                                        double* uu, double* pp, double* ps, double* red, double* lds_mat, const int lds_cap,
+                                        int* status = nullptr)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     if (n == 1) { if (tid == 0) { dd[0] = W[0]; W[0] = 1.0; } __syncthreads(); return; }
@@ -291,7 +292,13 @@ __device__ __forceinline__ void sym_eig(double* W, const int n, const int ld, do
                 if (fabs(ee[k]) <= eps * tst1) atomicMin(&s_m, k);
             __syncthreads();
             const int m = s_m;
-            if (m == l || ++iter > 60) break;
+            if (m == l) break;
+            if (++iter > 60) {
+                // no convergence within LAPACK's iteration budget: reported, not hidden
+                // (plsx_sync / the next status check fails with PLSX_ERR_NUMERIC)
+                if (tid == 0 && status) atomicOr(status, 1);
+                break;
+            }
             // shift
             const double el = ee[l];
             const double g = dd[l];

@@ -360,6 +360,28 @@ def main_reg_3d_nan():
     print('wrote simpls_3d_nan')
 
 
+def main_reg_seed_envelope():
+    """SIMPLS with T = 20 > 11 behaviours (the regime of BASELINE config c5): the
+    reference's rank-1 randomized SVD (regression.py:103 -> compute.py:43-50: 1 + 10
+    oversampled directions, 4 power iterations) is APPROXIMATE there and depends on its
+    seed.  Records what the reference returns for three seeds on one design, so that the
+    distance of the exact restatement (the oracle) can be stated against the reference's
+    own spread -- the survey's ruling for "parity unpinned" (SURVEY.md section 0.3)."""
+    from pyls.types.regression import simpls
+    rs = np.random.RandomState(20200)
+    S, B, T, k = 80, 400, 20, 8
+    Xs = rs.randn(S, B)
+    Ys = rs.randn(S, T) + 0.5 * Xs[:, :T]
+    out = dict(X=Xs, Y=Ys, n_components=np.asarray(k), seeds=np.array([0, 1, 2]))
+    for sd in (0, 1, 2):
+        r = simpls(Xs.copy(), Ys.copy(), n_components=k, seed=sd)
+        out['ref_x_weights_seed{}'.format(sd)] = r['x_weights']
+        out['ref_pctvar_y_seed{}'.format(sd)] = np.asarray(r['pctvar'][1])
+        out['ref_y_loadings_seed{}'.format(sd)] = r['y_loadings']
+    np.savez_compressed(os.path.join(HERE, 'simpls_t20_seeds.npz'), **out)
+    print('wrote simpls_t20_seeds')
+
+
 def main_matimport():
     """pyls.matlab.import_matlab_result on the reference's own .mat fixtures
     (pyls/tests/data/*.mat, mirrored as data files under tests/golden/mat/):
@@ -403,6 +425,8 @@ if __name__ == '__main__':
         main_reg_extra()
     elif len(sys.argv) > 1 and sys.argv[1] == 'cvcov':
         main_cv_cov()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'regseeds':
+        main_reg_seed_envelope()
     else:
         main()
         main_cv()
@@ -410,3 +434,4 @@ if __name__ == '__main__':
         main_cv_cov()
         main_matimport()
         main_reg_3d_nan()
+        main_reg_seed_envelope()

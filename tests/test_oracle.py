@@ -238,3 +238,30 @@ def test_simpls_3d_with_nan_rows_vs_reference():
         assert_close(np.nan_to_num(out[k]), np.nan_to_num(g['ref_' + k]), 1e-9, what=k)
     for k in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
         assert_close(out['bootres'][k], g['ref_bootres__' + k], 1e-9, what=k)
+
+
+def test_simpls_t20_oracle_within_the_reference_seed_envelope():
+    """T = 20 > 11 (the regime of BASELINE config c5): the reference's rank-1 randomized SVD
+    (regression.py:103) is approximate and seed dependent, so there is no single reference
+    answer to pin.  tests/golden/simpls_t20_seeds.npz holds the reference's own x_weights /
+    pctvar for seeds 0, 1, 2 on one design; the exact restatement must lie INSIDE the spread
+    the reference shows against itself: for every component, the distance oracle <-> run is
+    at most the largest run <-> run distance.  Measured: weights
+    3.7e-3 vs 4.1e-3 relative (max over components), pctvar of Y 4.2e-4 vs 5.1e-4."""
+    g = load_golden('simpls_t20_seeds')
+    X, Y, k = g['X'], g['Y'], int(g['n_components'])
+    out = ref.simpls(X, Y, k)
+    W = [g['ref_x_weights_seed{}'.format(s)] for s in (0, 1, 2)]
+    P = [g['ref_pctvar_y_seed{}'.format(s)] for s in (0, 1, 2)]
+
+    def coldist(A, B):
+        sg = np.sign(np.sum(A * B, axis=0))
+        return np.max(np.abs(A * sg - B), axis=0) / np.max(np.abs(B), axis=0)
+    ow = np.max([coldist(out['x_weights'], w) for w in W], axis=0)
+    ww = np.max([coldist(W[a], W[b]) for a in range(3) for b in range(a + 1, 3)], axis=0)
+    op = np.max([np.abs(np.asarray(out['pctvar'])[1] - p) / p for p in P], axis=0)
+    pp = np.max([np.abs(P[a] - P[b]) / P[b] for a in range(3) for b in range(a + 1, 3)], axis=0)
+    assert np.all(ow <= ww), (ow, ww)
+    assert np.all(op <= pp), (op, pp)
+    assert ww.max() < 1e-2 and pp.max() < 2e-3              # the envelope itself is what was recorded
+    assert ow.max() > 1e-6                                  # and it is NOT a 1e-9 pin: "parity unpinned" stays

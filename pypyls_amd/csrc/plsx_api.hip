@@ -36,6 +36,7 @@ struct plsx_ctx {
     // to R (correlation mode).  Covariance mode keeps the rows for cross-validation's zmap.
     int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, momrows = 0, Gcap = 0, Galloc = 0;
     int nks_t = 0, LT = 0, cv_mom = 0;
+    int afrag_group0 = 0;                               // first group of Afrag a prebuilt cross-product launch reads
     size_t group_stride = 0;
     // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
     int gps = 0;
@@ -348,7 +349,8 @@ int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
     dim3 grid(ncolblk * round_up(groups, 8)), block(NW * 64);
     KTimer tm(ctx, KC_XPROD, st);
     hipLaunchKernelGGL((k_xprod<MT, NW, KT, NSQ>), grid, block, lds, st,
-                       ptr<double>(ctx->Afrag), ctx->group_stride, ptr<double>(ctx->Xc), ctx->Bpad,
+                       ptr<double>(ctx->Afrag) + (size_t)ctx->afrag_group0 * ctx->group_stride, ctx->group_stride,
+                       ptr<double>(ctx->Xc), ctx->Bpad,
                        ctx->nks, ptr<double>(ctx->R), ctx->Bpad, ctx->npg * ctx->Tpp,
                        ptr<int>(ctx->out_row), ptr<int>(ctx->mom_idx), ptr<double>(ctx->mom_n),
                        std::max(ctx->nmom_pad, 0), groups, ncolblk, ctx->mom_out_arg,
@@ -1026,9 +1028,9 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_ARG, "plsx_set_data: mean_centering must be 0, 1 or 2");
     const int J = n_groups * n_cond;
     const int Tp = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
-    if (method == PLSX_REGRESSION && ((size_t)T * (T | 1) + 2 * T + ncomp + 32 + (size_t)S) * 8 > 160 * 1024)
+    if (method == PLSX_REGRESSION && sd_step_lds(S, T, ncomp) * 8 > 158 * 1024)
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
-                    "SIMPLS: S / T too large for the on-chip eigen-solver (8 (T^2 + S) bytes must fit 160 KB)");
+                    "SIMPLS: S / T too large for the on-chip component step (8 (T^2 + S) bytes must fit 158 KB)");
     if ((long long)B + Tp > 2000000LL)
         return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
     if (Tp > PLSX_MAX_TP || J > PLSX_MAX_CELLS || (method != PLSX_BEHAVIORAL && Tp > PLSX_BLOCK_TP)) {
@@ -1651,10 +1653,10 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
 {
     const int S = ctx->S, T = ctx->T, k = ctx->ncomp;
     const int groups = ceil_div(nres, ctx->npg);
-    if (int e = ensure_scratch(ctx, groups)) return e;
+    if (int e = ensure_scratch(ctx, std::min(groups, ctx->Gcap))) return e;
     SdArgs a;
     memset(&a, 0, sizeof(a));
-    a.S = S; a.T = T; a.k = k;
+    a.S = S; a.T = T; a.k = k; a.nres = nres;
     a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
     a.y_stride = ystack ? (long long)S * T : 0;
     a.okx = ctx->has_okx ? ptr<uint8_t>(ctx->okx) : nullptr;
@@ -1663,7 +1665,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     // per-resample state, carved out of one scratch buffer (doubles)
     const size_t n = (size_t)nres;
     const size_t per = (size_t)S /* xs, ys as ints share one S-double slot */ + 2 * (size_t)S * T + 4 * (size_t)k * S +
-                       3 * (size_t)S + 2 * (size_t)T * T + 2 * (size_t)k * T + 4;
+                       2 * (size_t)S + 2 * (size_t)T * T + 2 * (size_t)k * T + 4;
     const size_t gemm_rows = n * (T + 1);
     if (int e = ensure(ctx, ctx->swork, (n * per + 2 * gemm_rows * S + 64) * 8)) return e;
     double* w = ptr<double>(ctx->swork);
@@ -1676,7 +1678,6 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.XW = w; w += n * k * S;
     a.WD = w; w += n * k * S;
     a.va = w; w += n * S;
-    a.vt = w; w += n * S;
     a.kcpos = w; w += n * S;
     a.H = w; w += n * T * T;
     a.H0 = w; w += n * T * T;
@@ -1687,18 +1688,23 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.Zt = w;
     a.pctvar = pctvar; a.yload = yload; a.cvec = cvec;
     if (scatter) {
+        // the solver batch may span several cross-product batches: its own span of A operands
+        if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * ctx->group_stride * 8 + 4096)) return e;
         HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * ctx->group_stride * 8, st));
         a.Afrag = ptr<double>(ctx->Afrag); a.group_stride = ctx->group_stride;
         a.lay.n = ctx->npg; a.lay.Tp = ctx->Tp; a.lay.J = 1; a.lay.T = T; a.lay.MT = ctx->MT;
         a.lay.w0 = ctx->w0; a.lay.sq0 = ctx->sq0; a.lay.Tpp = ctx->Tpp;
     }
     const double* K = ptr<double>(ctx->Kmat);
+    // one wavefront per resample; as many waves per block as keep >= 2 blocks of k_sd_step on a CU
+    const size_t step_wave = sd_step_lds(S, T, k) * 8;
+    const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (72 * 1024) / step_wave));
+    const dim3 grid(ceil_div(nres, wpb)), block(wpb * 64);
     {
-        const int CH = std::max(1, std::min(T + 1, 6144 / S));
-        const size_t lds = ((size_t)CH * S + 32) * 8;
+        const size_t lds = (size_t)wpb * S * 8;
         HIPCHK(set_lds(k_sd_init, lds));
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_init, dim3(nres), dim3(256), lds, st, a, CH);
+        hipLaunchKernelGGL(k_sd_init, grid, block, lds, st, a);
         LAUNCHCHK();
     }
     // GEMM 0: (T + 1) subject-space vectors per resample against K (symmetric)
@@ -1707,34 +1713,42 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         return e;
     {
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_post0, dim3(nres), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_sd_post0, grid, block, 0, st, a);
         LAUNCHCHK();
     }
-    const size_t lds_a = ((size_t)T * (T | 1) + 2 * T + k + 32 + S) * 8;
-    const size_t lds_b = ((size_t)4 * T + k + 32) * 8;
-    HIPCHK(set_lds(k_sd_comp_a, lds_a));
+    const size_t lds_step = (size_t)wpb * step_wave;
+    HIPCHK(set_lds(k_sd_step, lds_step));
     for (int c = 0; c < k; ++c) {
         a.c = c;
         {
             KTimer tm(ctx, KC_SIMPLS, st);
-            hipLaunchKernelGGL(k_sd_comp_a, dim3(nres), dim3(256), lds_a, st, a);
+            hipLaunchKernelGGL(k_sd_step, grid, block, lds_step, st, a);
             LAUNCHCHK();
         }
-        // GEMM c: K beta for every resample of the batch
-        if (int e = run_nt(ctx, a.Wt, 0, S, nres, K, 0, S, S, nullptr, 0, 0, 0, S, 1, a.Zt, 0, S,
-                           nullptr, 0, 0, st))
-            return e;
-        {
-            KTimer tm(ctx, KC_SIMPLS, st);
-            hipLaunchKernelGGL(k_sd_comp_b, dim3(nres), dim3(256), lds_b, st, a);
-            LAUNCHCHK();
-        }
+        // GEMM c: K beta for every resample of the batch (the last component needs none)
+        if (c + 1 < k)
+            if (int e = run_nt(ctx, a.Wt, 0, S, nres, K, 0, S, S, nullptr, 0, 0, 0, S, 1, a.Zt, 0, S,
+                               nullptr, 0, 0, st))
+                return e;
     }
     {
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_final, dim3(nres), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_sd_final, grid, block, 0, st, a);
         LAUNCHCHK();
     }
+#ifdef PLSX_SD_PROBE
+    {
+        unsigned long long h[16][32];
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sd_probe), sizeof(h)));
+        for (int c : {0, 7, 14})
+            if (c < k) {
+                fprintf(stderr, "[sd probe] c=%d nres=%d cycles:", c, nres);
+                for (int m = 1; m <= 12; ++m) fprintf(stderr, " %d:%lld", m, h[c][m] > h[c][m - 1] ? (long long)(h[c][m] - h[c][m - 1]) : -1LL);
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     return 0;
 }
 }  // namespace
@@ -1776,7 +1790,9 @@ int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, doub
     if (!d_perm_idx || !d_out || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_perm_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int nb = 2048;
+    // solver batches are as large as the call: a launch of the component step lasts as long as one
+    // wave's latency chain whatever the batch (one wave per resample, up to 8 per SIMD)
+    const int nb = 8192;
     if (int e = ensure(ctx, ctx->spct, (size_t)nb * ctx->T * ctx->ncomp * 8)) return e;
     if (int e = ensure(ctx, ctx->sc, (size_t)nb * ctx->T * ctx->ncomp * 8)) return e;
     for (int off = 0; off < n; off += nb) {
@@ -1821,23 +1837,32 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const doubl
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     const int k = ctx->ncomp, T = ctx->T;
-    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
-    if (int e = ensure(ctx, ctx->spct, (size_t)nb * k * 8)) return e;
-    if (int e = ensure(ctx, ctx->sc, (size_t)nb * T * k * 8)) return e;
-    for (int off = 0; off < n; off += nb) {
-        const int m = std::min(nb, n - off);
+    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;          // cross-product batch (R scratch)
+    // the dual solver runs on batches of up to 4096 bootstraps (whole groups), each followed by the
+    // cross-product batches that turn its dual weights into feature-space weights
+    const int nbs = std::max(nb, (4096 / ctx->npg) * ctx->npg);
+    if (int e = ensure(ctx, ctx->spct, (size_t)std::min(n, nbs) * k * 8)) return e;
+    if (int e = ensure(ctx, ctx->sc, (size_t)std::min(n, nbs) * T * k * 8)) return e;
+    for (int off = 0; off < n; off += nbs) {
+        const int ms = std::min(nbs, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
         double* yl = d_yload + (size_t)off * T * k;
         const double* yst = d_ystack ? d_ystack + (size_t)off * ctx->S * T : nullptr;
-        if (int e = run_simpls_dual(ctx, idx, idx, m, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st, yst))
+        if (int e = run_simpls_dual(ctx, idx, idx, ms, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st, yst))
             return e;
-        if (int e = run_xprod(ctx, idx, idx, m, st, true)) return e;          // R_r = W_r^T (k x B)
-        // sign alignment against the (centred) original weights
-        if (int e = run_gram_ex(ctx, m, 2, ptr<double>(ctx->U0T), k, ptr<double>(ctx->Pm), st)) return e;
-        hipLaunchKernelGGL(k_simpls_signs, dim3(m), dim3(256), 0, st, ptr<double>(ctx->Pm), k, T, ctx->nks_t,
-                           ctx->LT, ptr<double>(ctx->Mfrag), yl);
-        LAUNCHCHK();
-        if (int e = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e;
+        for (int o2 = 0; o2 < ms; o2 += nb) {
+            const int m = std::min(nb, ms - o2);
+            ctx->afrag_group0 = o2 / ctx->npg;
+            int e = run_xprod(ctx, idx, idx, m, st, true);                    // R_r = W_r^T (k x B)
+            ctx->afrag_group0 = 0;
+            if (e) return e;
+            // sign alignment against the (centred) original weights
+            if (int e2 = run_gram_ex(ctx, m, 2, ptr<double>(ctx->U0T), k, ptr<double>(ctx->Pm), st)) return e2;
+            hipLaunchKernelGGL(k_simpls_signs, dim3(m), dim3(256), 0, st, ptr<double>(ctx->Pm), k, T, ctx->nks_t,
+                               ctx->LT, ptr<double>(ctx->Mfrag), yl + (size_t)o2 * T * k);
+            LAUNCHCHK();
+            if (int e2 = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e2;
+        }
     }
     return PLSX_OK;
 }

@@ -31,27 +31,60 @@
 // -- so Y0 / Z0 are written once.  (The reference re-applies the deflation
 // against the earlier basis vectors, regression.py:148-150; in exact
 // arithmetic those coefficients vanish and they are not re-applied here.)
-// Kernels, one block per resample:
-//   k_sd_init -> [GEMM 0] -> k_sd_post0 -> { k_sd_comp_a -> [GEMM c] -> k_sd_comp_b } x k -> k_sd_final
+// Kernels, ONE WAVEFRONT per resample (round 3; round 2 ran one 256-thread block per
+// resample, whose ~100 block barriers per component -- Jacobi steps, block-wide sums, the
+// 2 c sequential dot products of the Gram-Schmidt pass -- left the kernels 10 x off their
+// memory traffic):
+//   k_sd_init -> [GEMM 0] -> k_sd_post0 -> { k_sd_step(c) -> [GEMM c] } x k -> k_sd_final
+// k_sd_step(c) finishes component c - 1 (what follows its K beta product: basis pair,
+// deflation coefficients, H -= g g^T) and opens component c (leading eigenpair of H, scores,
+// dual weights, new basis vector scattered for GEMM c); the last component needs no
+// product.  Everything a resample owns is touched by its wave only: reductions are
+// wavefront shuffles, the S-long vectors stay with the lane that owns position p
+// (p = lane + 64 i), the small matrices (H, G, ...) live in the wave's slice of LDS.
+// S x T matrices are stored T-major ([t][p]) so that lanes over p read 512 contiguous bytes.
 #pragma once
 #include "plsx_kernels.h"
 
-__device__ __forceinline__ double block_sum(double v, double* red)
+// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS round trip):
+// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies; row_half_mirror and
+// row_mirror pair the quads / halves of a 16-lane row, which is all a SUM needs once every
+// lane of a quad (half) already holds that quad's (half's) total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-    // red: >= 16 doubles of LDS.  Returns the block-wide sum to every thread.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    __syncthreads();
-    double s = 0.0;
-    for (int w = 0; w < nw; ++w) s += red[w];
-    return s;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define SD_DPP_XOR1 0xB1
+#define SD_DPP_XOR2 0x4E
+#define SD_DPP_HALF_MIRROR 0x141
+#define SD_DPP_ROW_MIRROR 0x140
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_f64<SD_DPP_XOR1>(v);
+    v += dpp_f64<SD_DPP_XOR2>(v);
+    v += dpp_f64<SD_DPP_HALF_MIRROR>(v);
+    v += dpp_f64<SD_DPP_ROW_MIRROR>(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// LDS written by some lanes of the wave, read by others: the wave's DS operations execute in
+// order, the compiler must not move them across
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 struct SdArgs {
     int S, T, k, c;             // c: current component
+    int nres;
     const double* Yc;           // S x T globally centred Y (or a stack, y_stride != 0)
     long long y_stride;
     const uint8_t* okx;         // [S] usable X rows or nullptr
@@ -61,14 +94,13 @@ struct SdArgs {
     // per-resample state (library scratch)
     int* xs;                    // [nres][S] X source of position p, -1 = position excluded
     int* ys;                    // [nres][S]
-    double* Y0;                 // [nres][S][T]  resample-centred Y
-    double* Z0;                 // [nres][S][T]  K_r Y0
+    double* Y0;                 // [nres][T][S]  resample-centred Y, T-major
+    double* Z0;                 // [nres][T][S]  K_r Y0, T-major
     double* BT;                 // [nres][k][S]  beta_j (centred, normalised)
     double* KB;                 // [nres][k][S]  K_r beta_j
     double* XW;                 // [nres][k][S]  X[xs] w_j (un-centred)
     double* WD;                 // [nres][k][S]  dual weights (centred)
-    double* va;                 // [nres][S]  work vector
-    double* vt;                 // [nres][S]  work vector
+    double* va;                 // [nres][S]  centred beta of the open component
     double* kcpos;              // [nres][S]  (K cnt)[xs_p]
     double* H;                  // [nres][T][T]
     double* H0;                 // [nres][T][T]
@@ -85,23 +117,47 @@ struct SdArgs {
     GroupLayout lay;
 };
 
+// doubles of LDS one wave of k_sd_step needs
+__host__ __device__ inline size_t sd_step_lds(int S, int T, int k)
+{
+    return (size_t)T * (T | 1) + 3 * (size_t)T + 2 * (size_t)k + (size_t)S + 8;
+}
+
+// Scatter a position-space vector to subject space through the wave's LDS buffer
+// (w[i] = sum over included positions p with xs_p = i) and write it to dst[0..S).
+// A subject drawn more than once receives bit-identical addends, so the order in which
+// the LDS atomics land does not matter.
+template <class F>
+__device__ __forceinline__ void sd_scatter(double* buf, const int* xs, int S, int lane, double* dst, F value)
+{
+    for (int i = lane; i < S; i += 64) buf[i] = 0.0;
+    wave_sync();
+    for (int p = lane; p < S; p += 64) {
+        const int x = xs[p];
+        if (x >= 0) atomicAdd(&buf[x], value(p));
+    }
+    wave_sync();
+    for (int i = lane; i < S; i += 64) dst[i] = buf[i];
+    wave_sync();
+}
+
 // Resample setup: sources, masks, Y0 = Jc Y[ys], sum of squares, and the T + 1
 // subject-space vectors scatter(Y0[:, t]), cnt for GEMM 0.
-// dynamic LDS: CH * S doubles (CH vectors scattered per pass) + 32 doubles.
+// dynamic LDS: S doubles per wave.
 __global__ __launch_bounds__(256)
-void k_sd_init(SdArgs a, int CH)
+void k_sd_init(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
-    double* buf = sm_sd;                               // [CH][S]
-    double* red = sm_sd + (size_t)CH * a.S;            // [32]
-    const int S = a.S, T = a.T, tid = threadIdx.x, NT = blockDim.x;
-    const int r = blockIdx.x;
+    const int S = a.S, T = a.T, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= a.nres) return;
+    double* buf = sm_sd + (size_t)wave * S;
     int* xs = a.xs + (size_t)r * S;
     int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
     double* Y0 = a.Y0 + (size_t)r * S * T;
     double cnt = 0.0;
-    for (int p = tid; p < S; p += NT) {
+    for (int p = lane; p < S; p += 64) {
         const int x = a.xsrc ? a.xsrc[(size_t)r * S + p] : p;
         const int y = a.ysrc ? a.ysrc[(size_t)r * S + p] : p;
         const int ok = (!a.okx || a.okx[x]) && (!a.oky || a.oky[y]);
@@ -109,270 +165,574 @@ void k_sd_init(SdArgs a, int CH)
         ys[p] = y;
         cnt += ok;
     }
-    const double ninc = block_sum(cnt, red);
+    const double ninc = wave_sum(cnt);
     double ssy = 0.0;
     for (int t = 0; t < T; ++t) {
         double part = 0.0;
-        for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Ysrc[(size_t)ys[p] * T + t];
-        const double mean = block_sum(part, red) / ninc;
-        for (int p = tid; p < S; p += NT) {
+        for (int p = lane; p < S; p += 64) if (xs[p] >= 0) part += Ysrc[(size_t)ys[p] * T + t];
+        const double mean = wave_sum(part) / ninc;
+        for (int p = lane; p < S; p += 64) {
             const double y = xs[p] >= 0 ? Ysrc[(size_t)ys[p] * T + t] - mean : 0.0;
-            Y0[(size_t)p * T + t] = y;
+            Y0[(size_t)t * S + p] = y;
             ssy += y * y;
         }
     }
-    const double ssY = block_sum(ssy, red);
-    if (tid == 0) { a.scal[(size_t)r * 4] = ninc; a.scal[(size_t)r * 4 + 1] = ssY; }
-    __syncthreads();
+    const double ssY = wave_sum(ssy);
+    if (lane == 0) { a.scal[(size_t)r * 4] = ninc; a.scal[(size_t)r * 4 + 1] = ssY; }
     // subject-space operands of GEMM 0: vectors 0..T-1 = columns of Y0, vector T = counts
     double* Wt = a.Wt + (size_t)r * (T + 1) * S;
-    for (int t0 = 0; t0 <= T; t0 += CH) {
-        const int nv = min(CH, T + 1 - t0);
-        for (int i = tid; i < nv * S; i += NT) buf[i] = 0.0;
-        __syncthreads();
-        for (int idx = tid; idx < nv * S; idx += NT) {
-            const int v = idx / S, p = idx - v * S;
-            const int x = xs[p];
-            if (x < 0) continue;
-            const int t = t0 + v;
-            atomicAdd(&buf[(size_t)v * S + x], t < T ? Y0[(size_t)p * T + t] : 1.0);
-        }
-        __syncthreads();
-        for (int i = tid; i < nv * S; i += NT) Wt[(size_t)t0 * S + i] = buf[i];
-        __syncthreads();
+    for (int t = 0; t <= T; ++t)
+        sd_scatter(buf, xs, S, lane, Wt + (size_t)t * S,
+                   [&](int p) { return t < T ? Y0[(size_t)t * S + p] : 1.0; });
+}
+
+// The kernels below are latency chains of ONE wave (a launch lasts as long as its slowest
+// wave, and a batch rarely fills every SIMD more than once), so what matters is how many
+// independent loads a wave has in flight.  Positions are walked in tiles of 64 x SD_RC: a
+// lane owns SD_RC positions of a tile, the loops over them are fully unrolled with clamped
+// addresses (no control flow around the loads), and reductions are taken four at a time.
+// tools-only phase timing of k_sd_step (compile with -DPLSX_SD_PROBE; never in the product build)
+#ifdef PLSX_SD_PROBE
+__device__ unsigned long long g_sd_probe[16][32];
+#define SD_MARK(n) do { if (r == 0 && lane == 0) g_sd_probe[a.c & 15][n] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SD_MARK(n) do {} while (0)
+#endif
+
+#define SD_RC 16
+#define SD_TILE (64 * SD_RC)
+#define SD_OWN(i) _Pragma("unroll") for (int i = 0; i < SD_RC; ++i)
+// positions of the tile at p0 owned by this lane, clamped into [0, S): 32-bit offsets against
+// wave-uniform row pointers (scalar base + vector offset addressing, no 64-bit pointer per load)
+#define SD_TILE_PC(pc, p0) int pc[SD_RC]; SD_OWN(i_) pc[i_] = min((p0) + lane + 64 * i_, S - 1)
+#define SD_IN(p0, i) ((p0) + lane + 64 * (i) < S)
+
+// 8-byte load through a buffer resource: vector byte offset (one 32-bit register per owned
+// position, shared by every row) + scalar byte offset (the row).  Keeps the address arithmetic
+// of the hot loops on the scalar unit; with plain pointers the compiler strength-reduces every
+// (position, array) pair into its own 64-bit induction pointer, runs out of registers and
+// ends up waiting for each load before it issues the next.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sd_rsrc(const double* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+}
+__device__ __forceinline__ double sd_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+
+__device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, double& d)
+{
+#define SD_STEP4(CTRL) a += dpp_f64<CTRL>(a); b += dpp_f64<CTRL>(b); c += dpp_f64<CTRL>(c); d += dpp_f64<CTRL>(d);
+    SD_STEP4(SD_DPP_XOR1) SD_STEP4(SD_DPP_XOR2) SD_STEP4(SD_DPP_HALF_MIRROR) SD_STEP4(SD_DPP_ROW_MIRROR)
+#undef SD_STEP4
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); d += __shfl_xor(d, o);
     }
 }
 
 // After GEMM 0: Z0 = Jc gather(K scatter(Y0)), kcpos, H = H0 = Y0^T Z0.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_post0(SdArgs a)
 {
-    __shared__ double red[32];
-    const int S = a.S, T = a.T, tid = threadIdx.x, NT = blockDim.x;
-    const int r = blockIdx.x;
+    const int S = a.S, T = a.T, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= a.nres) return;
     const int* xs = a.xs + (size_t)r * S;
     const double* Zt = a.Zt + (size_t)r * (T + 1) * S;
     const double* Y0 = a.Y0 + (size_t)r * S * T;
     double* Z0 = a.Z0 + (size_t)r * S * T;
     const double ninc = a.scal[(size_t)r * 4];
-    for (int t = 0; t < T; ++t) {
-        double part = 0.0;
-        for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Zt[(size_t)t * S + xs[p]];
-        const double mean = block_sum(part, red) / ninc;
-        for (int p = tid; p < S; p += NT)
-            Z0[(size_t)p * T + t] = xs[p] >= 0 ? Zt[(size_t)t * S + xs[p]] - mean : 0.0;
+    // column means of the gathered products, four columns at a time
+    for (int t0 = 0; t0 <= T; t0 += 4) {
+        const double* z0 = Zt + (size_t)min(t0, T) * S;
+        const double* z1 = Zt + (size_t)min(t0 + 1, T) * S;
+        const double* z2 = Zt + (size_t)min(t0 + 2, T) * S;
+        const double* z3 = Zt + (size_t)min(t0 + 3, T) * S;
+        double m[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+            SD_TILE_PC(pc, p0);
+            SD_OWN(i) {
+                const int x = xs[pc[i]];
+                const bool ok = SD_IN(p0, i) && x >= 0;
+                const int xc = x >= 0 ? x : 0;
+                const double a0 = z0[xc], a1 = z1[xc], a2 = z2[xc], a3 = z3[xc];
+                m[0] += ok ? a0 : 0.0; m[1] += ok ? a1 : 0.0; m[2] += ok ? a2 : 0.0; m[3] += ok ? a3 : 0.0;
+            }
+        }
+        wave_sum4(m[0], m[1], m[2], m[3]);
+        for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+            SD_TILE_PC(pc, p0);
+            SD_OWN(i) {
+                const int x = xs[pc[i]];
+                const int xc = x >= 0 ? x : 0;
+                const double zz[4] = {z0[xc], z1[xc], z2[xc], z3[xc]};
+                if (SD_IN(p0, i)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u;
+                        if (t < T) Z0[(size_t)t * S + pc[i]] = x >= 0 ? zz[u] - m[u] / ninc : 0.0;
+                        if (t == T) a.kcpos[(size_t)r * S + pc[i]] = x >= 0 ? zz[u] : 0.0;     // un-centred K cnt
+                    }
+                }
+            }
+        }
     }
-    for (int p = tid; p < S; p += NT)
-        a.kcpos[(size_t)r * S + p] = xs[p] >= 0 ? Zt[(size_t)T * S + xs[p]] : 0.0;
-    __syncthreads();
+    // H[t1][t2] = sum_p Y0[p][t1] Z0[p][t2]: four columns of Z0 per pass over a column of Y0
     double* H = a.H + (size_t)r * T * T;
     double* H0 = a.H0 + (size_t)r * T * T;
-    for (int idx = tid; idx < T * T; idx += NT) {
-        const int t1 = idx / T, t2 = idx - t1 * T;
+    for (int t1 = 0; t1 < T; ++t1)
+        for (int t2 = 0; t2 < T; t2 += 4) {
+            const double* y1 = Y0 + (size_t)t1 * S;
+            const double* z0 = Z0 + (size_t)min(t2, T - 1) * S;
+            const double* z1 = Z0 + (size_t)min(t2 + 1, T - 1) * S;
+            const double* z2 = Z0 + (size_t)min(t2 + 2, T - 1) * S;
+            const double* z3 = Z0 + (size_t)min(t2 + 3, T - 1) * S;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                SD_OWN(i) {
+                    const double yv = y1[pc[i]], y = SD_IN(p0, i) ? yv : 0.0;
+                    s4[0] += y * z0[pc[i]]; s4[1] += y * z1[pc[i]]; s4[2] += y * z2[pc[i]]; s4[3] += y * z3[pc[i]];
+                }
+            }
+            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+            if (lane == 0)
+                for (int u = 0; u < 4 && t2 + u < T; ++u) { H[t1 * T + t2 + u] = s4[u]; H0[t1 * T + t2 + u] = s4[u]; }
+        }
+}
+
+// One-sided Jacobi on the columns of A (m x n, column pitch ld, in the wave's LDS) by ONE
+// wavefront: 4 lanes per column pair, 16 disjoint pairs of a round-robin step at a time.  At
+// convergence column j holds lambda_j v_j for a symmetric PSD input.  Same pairing, threshold
+// and null-pair rule as jacobi_cols (the block-level solver of the PLS-C path).  A step is a
+// pure latency chain (152 of them for T = 20: the longest phase of k_sd_step), so: both
+// columns of a pair are fetched into registers up front (IT rows per lane), the group sums are
+// two DPP butterflies, and the rotation comes from two reciprocal square roots instead of
+// three divisions and three square roots:
+//     d = beta - alpha, g = 2 gamma, h = hypot(d, g):  cos 2t = |d| / h,
+//     c = sqrt((1 + |d| / h) / 2),  s = sign(d g) |g| / (2 h c)
+// -- the same inner rotation (|t| <= pi/4) as t = sign(z) / (|z| + sqrt(1 + z^2)), z = d / g.
+__device__ __forceinline__ double sd_rsqrt(double x)
+{
+    // v_rsq_f64 (~2^-26 relative) + two Newton steps: full double precision
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+template <int IT>
+__device__ void wave_jacobi_cols(double* A, int m, int n, int ld, int lane, double tol)
+{
+    constexpr int LANES = 4;
+    const int sub = lane % LANES, grp = lane / LANES, ngrp = 64 / LANES;
+    const int np = (n + 1) >> 1, ne = np * 2, mod = ne - 1;
+    double mx = 0.0;
+    for (int c = lane; c < n; c += 64) {
         double s = 0.0;
-        for (int p = 0; p < S; ++p) s += Y0[(size_t)p * T + t1] * Z0[(size_t)p * T + t2];
-        H[idx] = s;
-        H0[idx] = s;
+        for (int i = 0; i < m; ++i) { const double x = A[(size_t)c * ld + i]; s += x * x; }
+        mx = fmax(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    const double null2 = 1e-26 * mx, tol2 = tol * tol;
+    int ri[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) ri[i] = min(sub + LANES * i, m - 1);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int step = 0; step < mod; ++step) {
+            for (int pr0 = 0; pr0 < np; pr0 += ngrp) {
+                const int pr = pr0 + grp;
+                int p = 0, q = n;                                   // q >= n: this group sits the pass out
+                if (pr < np) {
+                    if (pr == 0) { p = step; q = ne - 1; }
+                    else {
+                        p = step + pr; if (p >= mod) p -= mod;
+                        q = step + mod - pr; if (q >= mod) q -= mod;
+                    }
+                    if (p > q) { const int t = p; p = q; q = t; }
+                }
+                const bool act = q < n;
+                double* ap = A + (size_t)(act ? p : 0) * ld;
+                double* aq = A + (size_t)(act ? q : 0) * ld;
+                double x[IT], y[IT];
+#pragma unroll
+                for (int i = 0; i < IT; ++i) { x[i] = ap[ri[i]]; y[i] = aq[ri[i]]; }
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const bool in = act && sub + LANES * i < m;
+                    const double xx = in ? x[i] : 0.0, yy = in ? y[i] : 0.0;
+                    alpha += xx * xx; beta += yy * yy; gamma += xx * yy;
+                }
+                alpha += dpp_f64<SD_DPP_XOR1>(alpha); beta += dpp_f64<SD_DPP_XOR1>(beta); gamma += dpp_f64<SD_DPP_XOR1>(gamma);
+                alpha += dpp_f64<SD_DPP_XOR2>(alpha); beta += dpp_f64<SD_DPP_XOR2>(beta); gamma += dpp_f64<SD_DPP_XOR2>(gamma);
+                const bool rot = act && gamma != 0.0 && gamma * gamma > tol2 * (alpha * beta) &&
+                                 !(alpha < null2 && beta < null2);
+                if (rot) {
+                    const double d = beta - alpha, g = 2.0 * gamma;
+                    const double rh = sd_rsqrt(__builtin_fma(d, d, g * g));          // 1 / hypot(d, g)
+                    const double c2 = __builtin_fma(0.5 * fabs(d), rh, 0.5);          // cos^2 t, in [1/2, 1]
+                    const double rc = sd_rsqrt(c2);
+                    const double c = c2 * rc;
+                    const double sn = copysign(0.5 * fabs(g) * rh * rc, d >= 0.0 ? g : -g);
+#pragma unroll
+                    for (int i = 0; i < IT; ++i)
+                        if (sub + LANES * i < m) {
+                            ap[ri[i]] = c * x[i] - sn * y[i];
+                            aq[ri[i]] = sn * x[i] + c * y[i];
+                        }
+                    rotated = true;
+                }
+                wave_sync();
+            }
+        }
+        if (!__any(rotated)) break;
     }
 }
 
-// Component c, first half: leading eigenpair of H, a = Yd c / s, t = Z c / s, dual
-// weights, scores, pctvar, new basis vector (MGS x 2) scattered for GEMM c.
-// dynamic LDS: T*(T|1) + 2 T + k + 32 + S doubles.
-__global__ __launch_bounds__(256)
-void k_sd_comp_a(SdArgs a)
+// Component step c (see the header): closes component c - 1 when c > 0, opens component c
+// unless c == k.  dynamic LDS: sd_step_lds(S, T, k) doubles per wave.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void k_sd_step(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
-    const int S = a.S, T = a.T, k = a.k, c = a.c, tid = threadIdx.x, NT = blockDim.x;
+    const int S = a.S, T = a.T, k = a.k, c = a.c, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= a.nres) return;
     const int ldh = T | 1;
-    double* Hw = sm_sd;                       // T x ldh
-    double* gv = Hw + (size_t)T * ldh;        // [T]
-    double* cv = gv + T;                      // [T]
-    double* gc = cv + T;                      // [k]
-    double* red = gc + k;                     // [32]
-    double* buf = red + 32;                   // [S]
-    __shared__ int s_flag;
-    const int r = blockIdx.x;
+    double* Hw = sm_sd + (size_t)wave * sd_step_lds(S, T, k);   // [T][ldh] Jacobi work copy of H
+    double* cv = Hw + (size_t)T * ldh;         // [T]
+    double* gv = cv + T;                       // [T]
+    double* gn = gv + T;                       // [T] new row of G
+    double* gc = gn + T;                       // [k]
+    double* mj = gc + k;                       // [k]
+    double* buf = mj + k;                      // [S] scatter buffer
     const int* xs = a.xs + (size_t)r * S;
     const double* Y0 = a.Y0 + (size_t)r * S * T;
     const double* Z0 = a.Z0 + (size_t)r * S * T;
-    const double* BT = a.BT + (size_t)r * k * S;
-    const double* KB = a.KB + (size_t)r * k * S;
+    double* BT = a.BT + (size_t)r * k * S;
+    double* KB = a.KB + (size_t)r * k * S;
     double* va = a.va + (size_t)r * S;
-    double* vt = a.vt + (size_t)r * S;
     const double* kcpos = a.kcpos + (size_t)r * S;
-    const double* H = a.H + (size_t)r * T * T;
+    // H, G, gY0 stay in global memory: every entry is only ever touched by the lane that owns
+    // its index (idx = lane + 64 i for H, t = lane + 64 i for the rows of G / gY0), in this
+    // launch and in the earlier ones, so no value crosses lanes through global memory
+    double* H = a.H + (size_t)r * T * T;
     const double* H0 = a.H0 + (size_t)r * T * T;
-    const double* G = a.G + (size_t)r * k * T;
-    const double* gY0 = a.gY0 + (size_t)r * k * T;
+    double* G = a.G + (size_t)r * k * T;
+    double* gY0 = a.gY0 + (size_t)r * k * T;
     const double ninc = a.scal[(size_t)r * 4], ssY = a.scal[(size_t)r * 4 + 1];
 
-    // leading eigenpair of H (symmetric PSD) by one-sided Jacobi on a copy.  The
-    // rotations need not be accumulated: at convergence column j of the copy is
-    // H v_j = lambda_j v_j, so the eigenvector is that column normalised.
-    for (int idx = tid; idx < T * T; idx += NT) Hw[(idx % T) * ldh + idx / T] = H[idx];
-    __syncthreads();
-    jacobi_cols(Hw, T, Hw, 0, T, ldh, &s_flag, 1e-15);
-    for (int col = tid; col < T; col += NT) {
+    SD_MARK(0);
+    if (c > 0) {
+        // ---- close component cc = c - 1 (after GEMM cc): K beta gathered and centred, the new
+        // ---- basis pair, deflation coefficients g = (K beta)^T Yd, H -= g g^T
+        const int cc = c - 1;
+        const double* Zt = a.Zt + (size_t)r * S;
+        double* btc = BT + (size_t)cc * S;
+        double* kbc = KB + (size_t)cc * S;
+        // Zt gathered through xs (a dependent load): the indices of a tile first, then the values
+        double zs = 0.0;
+        for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+            SD_TILE_PC(pc, p0);
+            int xv[SD_RC];
+            SD_OWN(i) xv[i] = xs[pc[i]];
+            double zv[SD_RC];
+            SD_OWN(i) zv[i] = Zt[max(xv[i], 0)];
+            SD_OWN(i) zs += (SD_IN(p0, i) && xv[i] >= 0) ? zv[i] : 0.0;
+        }
+        const double zmean = wave_sum(zs) / ninc;
+        double part = 0.0;
+        for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+            SD_TILE_PC(pc, p0);
+            int xv[SD_RC];
+            double vv[SD_RC], zv[SD_RC];
+            SD_OWN(i) { xv[i] = xs[pc[i]]; vv[i] = va[pc[i]]; }
+            SD_OWN(i) zv[i] = Zt[max(xv[i], 0)];
+            SD_OWN(i) part += (SD_IN(p0, i) && xv[i] >= 0) ? vv[i] * (zv[i] - zmean) : 0.0;
+        }
+        const double nrm = sqrt(wave_sum(part));
+        for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+            SD_TILE_PC(pc, p0);
+            int xv[SD_RC];
+            double vv[SD_RC], zv[SD_RC];
+            SD_OWN(i) { xv[i] = xs[pc[i]]; vv[i] = va[pc[i]]; }
+            SD_OWN(i) zv[i] = Zt[max(xv[i], 0)];
+            SD_OWN(i) { vv[i] = vv[i] / nrm; zv[i] = xv[i] >= 0 ? (zv[i] - zmean) / nrm : 0.0; }
+            SD_OWN(i) if (SD_IN(p0, i)) { btc[pc[i]] = vv[i]; kbc[pc[i]] = zv[i]; }
+        }
+        SD_MARK(1);
+        // gY0_cc[t] = sum_p KB_cc[p] Y0[p][t];  m_j = KB_cc . BT_j   (four dot products per pass)
+        for (int t0 = 0; t0 < T; t0 += 4) {
+            const double* y0 = Y0 + (size_t)min(t0, T - 1) * S;
+            const double* y1 = Y0 + (size_t)min(t0 + 1, T - 1) * S;
+            const double* y2 = Y0 + (size_t)min(t0 + 2, T - 1) * S;
+            const double* y3 = Y0 + (size_t)min(t0 + 3, T - 1) * S;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                SD_OWN(i) {
+                    const double kv = kbc[pc[i]], kb = SD_IN(p0, i) ? kv : 0.0;
+                    s4[0] += kb * y0[pc[i]]; s4[1] += kb * y1[pc[i]]; s4[2] += kb * y2[pc[i]]; s4[3] += kb * y3[pc[i]];
+                }
+            }
+            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+            if (lane == 0)
+                for (int u = 0; u < 4 && t0 + u < T; ++u) gv[t0 + u] = s4[u];
+        }
+        for (int j0 = 0; j0 < cc; j0 += 4) {
+            const double* b0 = BT + (size_t)min(j0, cc - 1) * S;
+            const double* b1 = BT + (size_t)min(j0 + 1, cc - 1) * S;
+            const double* b2 = BT + (size_t)min(j0 + 2, cc - 1) * S;
+            const double* b3 = BT + (size_t)min(j0 + 3, cc - 1) * S;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                SD_OWN(i) {
+                    const double kv = kbc[pc[i]], kb = SD_IN(p0, i) ? kv : 0.0;
+                    s4[0] += kb * b0[pc[i]]; s4[1] += kb * b1[pc[i]]; s4[2] += kb * b2[pc[i]]; s4[3] += kb * b3[pc[i]];
+                }
+            }
+            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+            if (lane == 0)
+                for (int u = 0; u < 4 && j0 + u < cc; ++u) mj[j0 + u] = s4[u];
+        }
+        SD_MARK(2);
+        wave_sync();
+        for (int t = lane; t < T; t += 64) {
+            double g = gv[t];
+            for (int j = 0; j < cc; ++j) g -= mj[j] * G[(size_t)j * T + t];
+            gn[t] = g;
+            G[(size_t)cc * T + t] = g;
+            gY0[(size_t)cc * T + t] = gv[t];
+        }
+        wave_sync();
+        for (int idx = lane; idx < T * T; idx += 64) {
+            const int t1 = idx / T, t2 = idx - t1 * T;
+            H[idx] -= gn[t1] * gn[t2];
+        }
+    }
+    SD_MARK(3);
+    if (c >= k) return;
+
+    // ---- open component c: leading eigenpair of H (symmetric PSD) by one-sided Jacobi on a
+    // ---- copy.  The rotations need not be accumulated: at convergence column j of the copy is
+    // ---- H v_j = lambda_j v_j, so the eigenvector is that column normalised.
+    for (int idx = lane; idx < T * T; idx += 64) Hw[(idx % T) * ldh + idx / T] = H[idx];
+    wave_sync();
+    SD_MARK(4);
+    // rows per lane of a column (4 lanes per pair): 8 covers T <= 32, 36 the LDS limit of T
+    if (T <= 32) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
+    else if (T <= 64) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
+    else wave_jacobi_cols<36>(Hw, T, T, ldh, lane, 1e-15);
+    SD_MARK(5);
+    for (int col = lane; col < T; col += 64) {
         double s = 0.0;
         for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }
         gv[col] = sqrt(s);
     }
-    __syncthreads();
+    wave_sync();
     int best = 0;
     for (int col = 1; col < T; ++col) if (gv[col] > gv[best]) best = col;
     const double lam = gv[best], si = sqrt(lam);
-    for (int t = tid; t < T; t += NT) {
+    for (int t = lane; t < T; t += 64) {
         cv[t] = Hw[best * ldh + t] / lam;
         a.cvec[((size_t)r * T + t) * k + c] = cv[t];
     }
-    __syncthreads();
-    for (int j = tid; j < c; j += NT) {
-        double s = 0.0;
-        for (int t = 0; t < T; ++t) s += G[(size_t)j * T + t] * cv[t];
-        gc[j] = s;
+    wave_sync();
+    for (int j0 = 0; j0 < c; j0 += 4) {        // gc_j = g_j . c, lanes over t (each reads its own entries of G)
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t = lane; t < T; t += 64) {
+            const double cvt = cv[t];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += G[(size_t)min(j0 + u, c - 1) * T + t] * cvt;
+        }
+        wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+        if (lane == 0)
+            for (int u = 0; u < 4 && j0 + u < c; ++u) gc[j0 + u] = s4[u];
     }
-    __syncthreads();
-    // a = Yd c / s, t = Z c / s in factored form
+    wave_sync();
+    SD_MARK(6);
+    // a = Yd c / s, t = Z c / s in factored form.  Every lane keeps the entries of its own
+    // positions: XW row c doubles as the work vector t, WD row c as a, `va` as beta.
+    double* vt = a.XW + ((size_t)r * k + c) * S;
+    double* wd = a.WD + ((size_t)r * k + c) * S;
     double n2 = 0.0, asum = 0.0;
-    for (int p = tid; p < S; p += NT) {
-        double ya = 0.0, za = 0.0;
-        for (int t = 0; t < T; ++t) { ya += Y0[(size_t)p * T + t] * cv[t]; za += Z0[(size_t)p * T + t] * cv[t]; }
-        for (int j = 0; j < c; ++j) { ya -= BT[(size_t)j * S + p] * gc[j]; za -= KB[(size_t)j * S + p] * gc[j]; }
-        ya /= si; za /= si;
-        va[p] = ya; vt[p] = za;
-        n2 += za * za;
-        if (xs[p] >= 0) asum += ya;
+    const __amdgpu_buffer_rsrc_t rsY = sd_rsrc(Y0), rsZ = sd_rsrc(Z0), rsB = sd_rsrc(BT), rsK = sd_rsrc(KB);
+    const int rowb = S * 8;
+    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+        SD_TILE_PC(pc, p0);
+        int vo[SD_RC];
+        SD_OWN(i) vo[i] = pc[i] * 8;
+        double ya[SD_RC], za[SD_RC];
+        SD_OWN(i) { ya[i] = 0.0; za[i] = 0.0; }
+        for (int t = 0; t < T; ++t) {
+            const double cvt = cv[t];
+            const int so = t * rowb;
+            double yv[SD_RC], zv[SD_RC];
+            SD_OWN(i) { yv[i] = sd_ld(rsY, vo[i], so); zv[i] = sd_ld(rsZ, vo[i], so); }
+            SD_OWN(i) { ya[i] += yv[i] * cvt; za[i] += zv[i] * cvt; }
+        }
+        for (int j = 0; j < c; ++j) {
+            const double g = gc[j];
+            const int so = j * rowb;
+            double bv[SD_RC], kv[SD_RC];
+            SD_OWN(i) { bv[i] = sd_ld(rsB, vo[i], so); kv[i] = sd_ld(rsK, vo[i], so); }
+            SD_OWN(i) { ya[i] -= bv[i] * g; za[i] -= kv[i] * g; }
+        }
+        int xv[SD_RC];
+        SD_OWN(i) xv[i] = xs[pc[i]];
+        SD_OWN(i) {
+            ya[i] /= si; za[i] /= si;
+            if (SD_IN(p0, i)) {
+                n2 += za[i] * za[i];
+                if (xv[i] >= 0) asum += ya[i];
+            }
+        }
+        SD_OWN(i) if (SD_IN(p0, i)) { wd[pc[i]] = ya[i]; vt[pc[i]] = za[i]; }
     }
-    const double normt = sqrt(block_sum(n2, red));
-    const double amean = block_sum(asum, red) / ninc;
+    SD_MARK(7);
+    const double normt = sqrt(wave_sum(n2));
+    const double amean = wave_sum(asum) / ninc;
     double mu = 0.0;
-    for (int p = tid; p < S; p += NT) {
-        const double ac = xs[p] >= 0 ? va[p] - amean : 0.0;
-        a.WD[((size_t)r * k + c) * S + p] = ac / normt;
-        mu += ac * kcpos[p];
+    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+        SD_TILE_PC(pc, p0);
+        double an[SD_RC];
+        SD_OWN(i) {
+            const int x = xs[pc[i]];
+            const double w = wd[pc[i]], kc = kcpos[pc[i]];
+            const double ac = (SD_IN(p0, i) && x >= 0) ? w - amean : 0.0;
+            an[i] = ac / normt;
+            mu += ac * kc;
+        }
+        SD_OWN(i) if (SD_IN(p0, i)) wd[pc[i]] = an[i];
     }
-    mu = block_sum(mu, red) / ninc;            // mean over positions of the un-centred product X[xs] r
-    for (int p = tid; p < S; p += NT) {
-        a.XW[((size_t)r * k + c) * S + p] = xs[p] >= 0 ? (vt[p] + mu) / normt : 0.0;
-        vt[p] /= normt;                        // t_c, then beta
-    }
+    mu = wave_sum(mu) / ninc;                  // mean over positions of the un-centred product X[xs] r
     // y_loadings q = Y0^T t = (H0 c - sum_j gY0_j gc_j) / (s |t|)  -> pctvar
     double q2 = 0.0;
-    for (int t = tid; t < T; t += NT) {
+    for (int t = lane; t < T; t += 64) {
         double s = 0.0;
         for (int u = 0; u < T; ++u) s += H0[(size_t)t * T + u] * cv[u];
         for (int j = 0; j < c; ++j) s -= gY0[(size_t)j * T + t] * gc[j];
         s /= si * normt;
         q2 += s * s;
     }
-    q2 = block_sum(q2, red);
-    if (tid == 0) a.pctvar[(size_t)r * k + c] = q2 / ssY;
-    // basis: beta = t, MGS x 2 against the previous (v_j^T v = (K beta_j)^T beta), centre
-    for (int rep = 0; rep < 2; ++rep)
-        for (int j = 0; j < c; ++j) {
-            double part = 0.0;
-            for (int p = tid; p < S; p += NT) part += KB[(size_t)j * S + p] * vt[p];
-            const double coef = block_sum(part, red);
-            for (int p = tid; p < S; p += NT) vt[p] -= coef * BT[(size_t)j * S + p];
+    q2 = wave_sum(q2);
+    if (lane == 0) a.pctvar[(size_t)r * k + c] = q2 / ssY;
+    SD_MARK(8);
+    // beta starts as t / |t| (in `va`); XW row c = (t + mu) / |t| is final
+    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+        SD_TILE_PC(pc, p0);
+        double b0v[SD_RC], x0v[SD_RC];
+        SD_OWN(i) {
+            const int x = xs[pc[i]];
+            const double z = vt[pc[i]];
+            b0v[i] = z / normt;
+            x0v[i] = x >= 0 ? (z + mu) / normt : 0.0;
         }
+        SD_OWN(i) if (SD_IN(p0, i)) { va[pc[i]] = b0v[i]; vt[pc[i]] = x0v[i]; }
+    }
+    if (c == k - 1) return;                    // last component: no basis vector, no product with K
+    SD_MARK(9);
+    // Gram-Schmidt against the previous basis pairs (v_j^T v = (K beta_j)^T beta), twice: the
+    // coefficients of four basis vectors are taken together (block Gram-Schmidt: classical
+    // inside a block of four, modified across blocks), so a pass is c / 4 reductions deep
+    for (int rep = 0; rep < 2; ++rep)
+        for (int j0 = 0; j0 < c; j0 += 4) {
+            const int j1 = min(j0 + 1, c - 1), j2 = min(j0 + 2, c - 1), j3 = min(j0 + 3, c - 1);
+            const double *k0 = KB + (size_t)j0 * S, *k1 = KB + (size_t)j1 * S, *k2 = KB + (size_t)j2 * S,
+                         *k3 = KB + (size_t)j3 * S;
+            const double *b0 = BT + (size_t)j0 * S, *b1 = BT + (size_t)j1 * S, *b2 = BT + (size_t)j2 * S,
+                         *b3 = BT + (size_t)j3 * S;
+            double cf[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                SD_OWN(i) {
+                    const double bv = va[pc[i]], b = SD_IN(p0, i) ? bv : 0.0;
+                    cf[0] += k0[pc[i]] * b; cf[1] += k1[pc[i]] * b; cf[2] += k2[pc[i]] * b; cf[3] += k3[pc[i]] * b;
+                }
+            }
+            wave_sum4(cf[0], cf[1], cf[2], cf[3]);
+            if (j0 + 1 >= c) cf[1] = 0.0;
+            if (j0 + 2 >= c) cf[2] = 0.0;
+            if (j0 + 3 >= c) cf[3] = 0.0;
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                double bb[SD_RC];
+                SD_OWN(i) {
+                    double b = va[pc[i]];
+                    b -= cf[0] * b0[pc[i]]; b -= cf[1] * b1[pc[i]]; b -= cf[2] * b2[pc[i]]; b -= cf[3] * b3[pc[i]];
+                    bb[i] = b;
+                }
+                SD_OWN(i) if (SD_IN(p0, i)) va[pc[i]] = bb[i];
+            }
+        }
+    SD_MARK(10);
     double bs = 0.0;
-    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) bs += vt[p];
-    const double bmean = block_sum(bs, red) / ninc;
-    for (int i = tid; i < S; i += NT) buf[i] = 0.0;
-    __syncthreads();
-    for (int p = tid; p < S; p += NT) {
-        const double bc = xs[p] >= 0 ? vt[p] - bmean : 0.0;
-        va[p] = bc;                            // centred beta, consumed by k_sd_comp_b
-        if (xs[p] >= 0) atomicAdd(&buf[xs[p]], bc);
+    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+        SD_TILE_PC(pc, p0);
+        SD_OWN(i) {
+            const int x = xs[pc[i]];
+            const double b = va[pc[i]];
+            bs += (SD_IN(p0, i) && x >= 0) ? b : 0.0;
+        }
     }
-    __syncthreads();
-    for (int i = tid; i < S; i += NT) a.Wt[(size_t)r * S + i] = buf[i];
-}
-
-// Component c, second half (after GEMM c): K beta gathered and centred, the new
-// basis pair, deflation coefficients g = (K beta)^T Yd, H -= g g^T.
-// dynamic LDS: 4 T + k + 32 doubles.
-__global__ __launch_bounds__(256)
-void k_sd_comp_b(SdArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
-    const int S = a.S, T = a.T, k = a.k, c = a.c, tid = threadIdx.x, NT = blockDim.x;
-    double* gq = sm_sd;                       // [4][T] quarter sums
-    double* mj = gq + 4 * T;                  // [k]
-    double* red = mj + k;                     // [32]
-    const int r = blockIdx.x;
-    const int* xs = a.xs + (size_t)r * S;
-    const double* Y0 = a.Y0 + (size_t)r * S * T;
-    const double* Zt = a.Zt + (size_t)r * S;
-    double* BT = a.BT + (size_t)r * k * S;
-    double* KB = a.KB + (size_t)r * k * S;
-    const double* bcv = a.va + (size_t)r * S;
-    double* G = a.G + (size_t)r * k * T;
-    double* gY0 = a.gY0 + (size_t)r * k * T;
-    double* H = a.H + (size_t)r * T * T;
-    const double ninc = a.scal[(size_t)r * 4];
-    double part = 0.0;
-    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += Zt[xs[p]];
-    const double zmean = block_sum(part, red) / ninc;
-    part = 0.0;
-    for (int p = tid; p < S; p += NT) if (xs[p] >= 0) part += bcv[p] * (Zt[xs[p]] - zmean);
-    const double nrm = sqrt(block_sum(part, red));
-    for (int p = tid; p < S; p += NT) {
-        BT[(size_t)c * S + p] = bcv[p] / nrm;
-        KB[(size_t)c * S + p] = xs[p] >= 0 ? (Zt[xs[p]] - zmean) / nrm : 0.0;
+    const double bmean = wave_sum(bs) / ninc;
+    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+        SD_TILE_PC(pc, p0);
+        double bc[SD_RC];
+        SD_OWN(i) {
+            const int x = xs[pc[i]];
+            const double b = va[pc[i]];
+            bc[i] = x >= 0 ? b - bmean : 0.0;
+        }
+        SD_OWN(i) if (SD_IN(p0, i)) va[pc[i]] = bc[i];
     }
-    __syncthreads();
-    // gY0_c[t] = sum_p KB_c[p] Y0[p][t]: four quarters of the rows per column, fixed order
-    for (int idx = tid; idx < 4 * T; idx += NT) {
-        const int q = idx / T, t = idx - q * T;
-        const int p0 = (int)((long long)S * q / 4), p1 = (int)((long long)S * (q + 1) / 4);
-        double s = 0.0;
-        for (int p = p0; p < p1; ++p) s += KB[(size_t)c * S + p] * Y0[(size_t)p * T + t];
-        gq[idx] = s;
-    }
-    for (int j = tid; j < c; j += NT) {
-        double s = 0.0;
-        for (int p = 0; p < S; ++p) s += KB[(size_t)c * S + p] * BT[(size_t)j * S + p];
-        mj[j] = s;
-    }
-    __syncthreads();
-    for (int t = tid; t < T; t += NT) {
-        const double gy = gq[t] + gq[T + t] + gq[2 * T + t] + gq[3 * T + t];
-        gY0[(size_t)c * T + t] = gy;
-        double g = gy;
-        for (int j = 0; j < c; ++j) g -= mj[j] * G[(size_t)j * T + t];
-        G[(size_t)c * T + t] = g;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < T * T; idx += NT) {
-        const int t1 = idx / T, t2 = idx - t1 * T;
-        H[idx] -= G[(size_t)c * T + t1] * G[(size_t)c * T + t2];
-    }
+    SD_MARK(11);
+    // centred beta (consumed by the next launch) scattered to subject space for GEMM c
+    sd_scatter(buf, xs, S, lane, a.Wt + (size_t)r * S, [&](int p) { return va[p]; });
+    SD_MARK(12);
 }
 
 // Outputs for the bootstrap: y_loadings (unsigned) = Y[ys]^T (X[xs] W), Y NOT
 // re-centred (regression.py:325); dual weights scattered into k_xprod's A operand.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_final(SdArgs a)
 {
-    const int S = a.S, T = a.T, k = a.k, tid = threadIdx.x, NT = blockDim.x;
-    const int r = blockIdx.x;
+    const int S = a.S, T = a.T, k = a.k, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
+    const int r = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (r >= a.nres) return;
     const int* xs = a.xs + (size_t)r * S;
     const int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
     const double* XW = a.XW + (size_t)r * k * S;
     const double* WD = a.WD + (size_t)r * k * S;
-    for (int idx = tid; idx < T * k; idx += NT) {
-        const int t = idx / k, c = idx - t * k;
-        double s = 0.0;
-        for (int p = 0; p < S; ++p) if (xs[p] >= 0) s += Ysrc[(size_t)ys[p] * T + t] * XW[(size_t)c * S + p];
-        a.yload[((size_t)r * T + t) * k + c] = s;
-    }
+    for (int t = 0; t < T; ++t)
+        for (int c0 = 0; c0 < k; c0 += 4) {
+            const double *w0 = XW + (size_t)min(c0, k - 1) * S, *w1 = XW + (size_t)min(c0 + 1, k - 1) * S,
+                         *w2 = XW + (size_t)min(c0 + 2, k - 1) * S, *w3 = XW + (size_t)min(c0 + 3, k - 1) * S;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                SD_OWN(i) {
+                    const int x = xs[pc[i]], yy = ys[pc[i]];
+                    const double yv = Ysrc[(size_t)yy * T + t];
+                    const double y = (SD_IN(p0, i) && x >= 0) ? yv : 0.0;
+                    s4[0] += y * w0[pc[i]]; s4[1] += y * w1[pc[i]]; s4[2] += y * w2[pc[i]]; s4[3] += y * w3[pc[i]];
+                }
+            }
+            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+            if (lane == 0)
+                for (int u = 0; u < 4 && c0 + u < k; ++u) a.yload[((size_t)r * T + t) * k + c0 + u] = s4[u];
+        }
     if (a.Afrag) {
         const int g = r / a.lay.n, rr = r % a.lay.n;
         double* A = a.Afrag + (size_t)g * a.group_stride;
-        for (int idx = tid; idx < S * k; idx += NT) {
+        for (int idx = lane; idx < S * k; idx += 64) {
             const int c = idx / S, p = idx - c * S;
             if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
         }

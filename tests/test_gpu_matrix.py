@@ -137,7 +137,7 @@ def test_regression_components(n_components):
     if k <= 15:
         assert_close(res.varexp, want['varexp'], 1e-5, what='varexp all')
         assert_close(res.permres.pvals, want['permres']['pvals'], 0, what='pvals')
-        assert_close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-4, what='bsr')
+        assert_close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-5, what='bsr')
 
 
 @pytest.mark.parametrize('aggfunc', ['mean', 'median', 'sum'])
@@ -243,7 +243,7 @@ def test_behavioral_wide_y(n_groups, n_cond, n_split):
     assert_close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-6, what='perm')
     assert_close(res.permres.pvals, want['permres']['pvals'], 0, what='pvals')
     lead = slice(0, 20)
-    assert_close(res.bootres.x_weights_normed[:, lead], want['bootres']['x_weights_normed'][:, lead], 1e-4, what='bsr')
+    assert_close(res.bootres.x_weights_normed[:, lead], want['bootres']['x_weights_normed'][:, lead], 1e-5, what='bsr')
     assert_close(res.cvres.pearson_r, cv_r, 1e-6, what='cv r')
     assert_close(res.cvres.r_squared, cv_r2, 1e-6, what='cv r2')
     if n_split:

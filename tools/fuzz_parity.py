@@ -119,7 +119,7 @@ def regression_case(rs, idx):
     for key in ('x_weights', 'y_loadings', 'varexp'):
         close(res[key], want[key], 1e-5, key)
     close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-5, 'perm varexp')
-    close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-4, 'bsr')
+    close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-5, 'bsr')
     close(res.bootres.y_loadings_boot, want['bootres']['y_loadings_boot'], 1e-5, 'y_loadings_boot')
     return desc, 'ok'
 

@@ -55,6 +55,8 @@ struct plsx_ctx {
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
+    Buf ScT, out_row_w;                                 // single-pass bootstrap (unscaled modes): scores^T (L x S), row -> l map
+    int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf status;                                         // device word: numerical status bits of the small solvers
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
@@ -975,7 +977,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1225,6 +1227,16 @@ int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv, con
                        ctx->L, nullptr, 0, 0, 0, ctx->B, 1, ptr<double>(ctx->Xc) + ctx->B, 0, ctx->Bpad,
                        nullptr, 0, 0, st))
         return e;
+    // scores^T (L x S, pitch round_up(S, 8)): the B operand of P_r = A_r . scores in the single-pass
+    // bootstrap of the unscaled modes (boot_single_pass)
+    {
+        const int Sd = round_up(ctx->S, 8);
+        if (int e = ensure(ctx, ctx->ScT, (size_t)ctx->L * Sd * 8, true)) return e;
+        HIPCHK(hipMemsetAsync(ctx->ScT.p, 0, (size_t)ctx->L * Sd * 8, st));
+        hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ctx->L, 32), ceil_div(ctx->S, 32)), dim3(32, 8), 0, st,
+                           ptr<double>(ctx->Xc) + ctx->B, ctx->S, ctx->L, ctx->Bpad, ptr<double>(ctx->ScT), Sd);
+        LAUNCHCHK();
+    }
     ctx->has_orig = true;
     return PLSX_OK;
 }
@@ -1350,6 +1362,134 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
 
 }  // namespace
 
+}  // extern "C"
+
+namespace {
+// Single-pass bootstrap of the UNSCALED modes (mean-centred PLS, behavioral PLS in covariance
+// mode).  Without per-feature scaling R_r = A_r Xc is linear in the fixed feature matrix, so
+//   G_r = R_r R_r^T = A_r K A_r^T            (K = Xc Xc^T, S x S: the kernel of the dual permutation route)
+//   P_r = R_r U0   = A_r (Xc U0) = A_r Sc    (Sc = the score columns appended to Xc; also = gen_distrib)
+// need no pass over the features, and with M_r from the small solver
+//   U_r = R_r^T M_r = Xc^T (A_r^T M_r) = Xc^T W_r
+// is ONE cross-product pass whose epilogue adds U_r and U_r^2 over the resamples of a group
+// (k_xprod EPI = 2): no R matrix is written, no Gram pass and no rotation pass read it back.
+// Same statistics to rounding as the two-pass route (tests: test_single_pass_bootstrap_*).
+int boot_single_pass(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
+                     double* d_distrib, hipStream_t st)
+{
+    const int S = ctx->S, Tp = ctx->Tp, L = ctx->L, Sd = round_up(S, 8), MT = 24;
+    const int npg_w = (MT * 16) / L;
+    const size_t gstride = (size_t)ctx->nks * MT * 64;
+    if (!ctx->has_Kd) {
+        if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
+        const double* Xf = ptr<double>(ctx->Xc);
+        if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
+                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
+            return e;
+        ctx->has_Kd = 1;
+    }
+    if (ctx->npg_w != npg_w) {
+        std::vector<int> lmap(MT * 16, -1);
+        for (int rr = 0; rr < npg_w; ++rr)
+            for (int l = 0; l < L; ++l) lmap[rr * L + l] = l;
+        if (int e = ensure(ctx, ctx->out_row_w, lmap.size() * sizeof(int))) return e;
+        HIPCHK(hipMemcpy(ctx->out_row_w.p, lmap.data(), lmap.size() * sizeof(int), hipMemcpyHostToDevice));
+        ctx->npg_w = npg_w;
+    }
+    // resamples per pass: partial (sum, sum of squares) tiles of every group [groups][B][L] x 2 within a
+    // quarter of the scratch budget, dense operands within 2 GB, grid limits of the tiled GEMM
+    const double per_group = 2.0 * ctx->B * (double)L * 8.0;
+    long long gmax = (long long)(ctx->scratch_gb * 1073741824.0 / 4.0 / per_group);
+    gmax = std::max<long long>(1, std::min<long long>(gmax, 512));
+    long long nb = gmax * npg_w;
+    nb = std::min<long long>(nb, (2LL << 30) / ((long long)Tp * Sd * 8));
+    nb = std::min<long long>(nb, 60000LL * 64 / ((long long)Tp * ceil_div(S, 64)));
+    nb = std::max<long long>(npg_w, (nb / npg_w) * npg_w);
+    GroupLayout lay;
+    memset(&lay, 0, sizeof(lay));
+    lay.n = 1; lay.Tp = Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT; lay.Tpp = ctx->Tpp;
+    const size_t mstride = (size_t)ctx->nks_t * ctx->LT * 64;
+    for (int off = 0; off < n; off += (int)nb) {
+        const int m = std::min<int>((int)nb, n - off);
+        const int groups = ceil_div(m, npg_w);
+        const size_t abytes = (size_t)m * Tp * Sd * 8;
+        if (int e = ensure(ctx, ctx->Ad, abytes)) return e;
+        if (int e = ensure(ctx, ctx->Wd, abytes)) return e;
+        if (int e = ensure(ctx, ctx->Gm, (size_t)m * Tp * Tp * 8)) return e;
+        if (int e = ensure(ctx, ctx->Pm, (size_t)m * Tp * L * 8)) return e;
+        if (int e = ensure(ctx, ctx->Mfrag, (size_t)m * mstride * 8 + 1024)) return e;
+        if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * gstride * 8 + 4096)) return e;
+        if (int e = ensure(ctx, ctx->psum, (size_t)groups * ctx->B * L * 8)) return e;
+        if (int e = ensure(ctx, ctx->psq, (size_t)groups * ctx->B * L * 8)) return e;
+        if (ctx->timing) ctx->timed_units += m;
+        HIPCHK(hipMemsetAsync(ctx->Ad.p, 0, abytes, st));
+        const int* idx = d_boot_idx + (size_t)off * S;
+        {
+            KTimer tm(ctx, KC_BUILD, st);
+            if (ctx->method == PLSX_BEHAVIORAL)
+                hipLaunchKernelGGL(k_build_A_behav, dim3(m, ctx->J), dim3(256), (size_t)2 * ctx->T * 8, st,
+                                   ptr<double>(ctx->Y), 0LL, ctx->T, S, ptr<int>(ctx->cell_start),
+                                   ptr<int>(ctx->cell_len), idx, idx, lay, ctx->cov, 0, ptr<double>(ctx->Ad),
+                                   (size_t)0, (double*)nullptr, 0, Sd);
+            else
+                hipLaunchKernelGGL(k_build_A_mc, dim3(m), dim3(256), 0, st, S, ctx->J, ctx->n_cond, ctx->mc,
+                                   ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd);
+            LAUNCHCHK();
+        }
+        // W = A K (all resamples stacked), G_r = W_r A_r^T, P_r = A_r Sc
+        if (int e = run_nt(ctx, ptr<double>(ctx->Ad), 0, Sd, m * Tp, ptr<double>(ctx->Kd), 0, Sd, S,
+                           nullptr, 0, 0, 0, S, 1, ptr<double>(ctx->Wd), 0, Sd, nullptr, 0, 0, st))
+            return e;
+        if (int e = run_nt(ctx, ptr<double>(ctx->Wd), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->Ad),
+                           (long long)Tp * Sd, Sd, Tp, nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Gm),
+                           (long long)Tp * Tp, Tp, nullptr, 0, 0, st))
+            return e;
+        if (int e = run_nt(ctx, ptr<double>(ctx->Ad), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->ScT), 0, Sd, L,
+                           nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Pm), (long long)Tp * L, L, nullptr, 0, 0, st))
+            return e;
+        SmallArgs a = small_args(ctx, SMALL_BOOT);
+        if (int e = run_small(ctx, a, m, st)) return e;
+        // gen_distrib of a resample is its cross-product with the score columns: P_r itself
+        HIPCHK(hipMemcpyAsync(d_distrib + (size_t)off * Tp * L, ctx->Pm.p, (size_t)m * Tp * L * 8,
+                              hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups * gstride * 8, st));
+        {
+            KTimer tm(ctx, KC_BUILD, st);
+            hipLaunchKernelGGL(k_build_W, dim3(m), dim3(256), (size_t)Tp * L * 8, st, ptr<double>(ctx->Ad), Sd, S, Tp, L,
+                               ptr<double>(ctx->Mfrag), ctx->nks_t, ctx->LT, npg_w, MT, ptr<double>(ctx->Afrag), gstride);
+            LAUNCHCHK();
+        }
+        {
+            constexpr int NW = 4, KT = 1;
+            const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
+            const size_t epi = (size_t)2 * L * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4;
+            const size_t lds = std::max(stage, epi);
+            HIPCHK(set_lds(k_xprod<24, NW, KT, 0, 2>, lds));
+            const int ncolblk = ctx->Bpad / (NW * 16);
+            SplitEpi se;
+            memset(&se, 0, sizeof(se));
+            se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
+            KTimer tm(ctx, KC_XPROD, st);
+            hipLaunchKernelGGL((k_xprod<24, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
+                               ptr<double>(ctx->Afrag), gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                               (double*)nullptr, ctx->Bpad, 0, ptr<int>(ctx->out_row_w), (const int*)nullptr,
+                               (const double*)nullptr, 0, groups, ncolblk, (double*)nullptr, se, 1);
+            LAUNCHCHK();
+        }
+        {
+            KTimer tm(ctx, KC_UROT, st);          // the fixed-order sum over groups (what k_urot's splits do)
+            const long long count = (long long)ctx->B * L;
+            hipLaunchKernelGGL(k_add_splits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                               ptr<double>(ctx->psum), ptr<double>(ctx->psq), groups, count, d_usum, d_usq);
+            LAUNCHCHK();
+        }
+    }
+    return PLSX_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
                     double* d_distrib, void* stream)
 {
@@ -1358,6 +1498,10 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
+    // unscaled modes: one pass over the features per bootstrap (see boot_single_pass)
+    if (!ctx->scaled && ctx->dual && ctx->gps == 0 && ctx->L == ctx->Tp && ctx->Tp <= PLSX_JACOBI_TP &&
+        2 * (size_t)ctx->L * PLSX_ACC_PITCH * 8 <= 72 * 1024 && !getenv("PLSX_TWO_PASS_BOOT"))
+        return boot_single_pass(ctx, d_boot_idx, n, d_usum, d_usq, d_distrib, st);
     const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);

@@ -271,6 +271,47 @@ __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
     }
 }
 
+// Single-pass bootstrap of the unscaled modes: W_r^T = (A_r^T M_r)^T  (L x S) into the A operand
+// of k_xprod (rows rr * L + l of the resample's group), from the dense A_r (T' x S, pitch ld) and
+// the rotation operand M_r (T' x L) that the small solver left in k_urot's fragment order.
+// grid (n_resamples), block 256; dynamic LDS T' * L doubles.
+__device__ __forceinline__ size_t mfrag_index(int t, int l, int nks_t, int LT)
+{
+    const int chunk = (l >> 4) / PLSX_LT_CHUNK, lt = (l >> 4) - chunk * PLSX_LT_CHUNK;
+    const int ltc = min(PLSX_LT_CHUNK, LT - chunk * PLSX_LT_CHUNK);
+    return (size_t)chunk * PLSX_LT_CHUNK * nks_t * 64 + ((size_t)(t >> 2) * ltc + lt) * 64 + (t & 3) * 16 + (l & 15);
+}
+
+__global__ __launch_bounds__(256)
+void k_build_W(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
+               const double* __restrict__ Mfrag, int nks_t, int LT, int npg_w, int MT,
+               double* __restrict__ Afrag, size_t group_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) double sM[];      // [Tp][L]
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const double* M = Mfrag + (size_t)r * nks_t * LT * 64;
+    for (int idx = tid; idx < Tp * L; idx += blockDim.x) {
+        const int t = idx / L, l = idx - t * L;
+        sM[idx] = M[mfrag_index(t, l, nks_t, LT)];
+    }
+    __syncthreads();
+    const double* A = Adense + (size_t)r * Tp * ld;
+    double* out = Afrag + (size_t)(r / npg_w) * group_stride;
+    const int row0 = (r % npg_w) * L;
+    for (int i = tid; i < S; i += blockDim.x)
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < Tp; ++t) {
+                const double a = A[(size_t)t * ld + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] += a * sM[t * L + min(l0 + u, L - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (l0 + u < L) out[afrag_off(row0 + l0 + u, i, MT)] = w[u];
+        }
+}
+
 // Column sums of Xc and Xc^2 per cell: S1[j][b], S2[j][b] (full-sample moments
 // the fused split-half epilogue subtracts the first half's from).
 __global__ void k_cell_moments(const double* __restrict__ Xc, int ldx, int B, int J,
@@ -309,6 +350,10 @@ struct SplitEpi {
     int nmu;                 // moment rows in use (splits per group x cells)
     int off_pre;             // > 0: doubles offset of the LDS region that receives this block's tile of
                              // Rfull ([Tpp][64]) and its row constants by DMA at kernel start
+    // EPI == 2 (accumulating epilogue, see k_xprod): per-group partial sums [group][B][L]
+    double* acc_sum;
+    double* acc_sq;
+    int accL, accB;
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
@@ -449,7 +494,15 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 // NSQ = number of second-moment tiles; they are the LAST NSQ tiles of the block
 // (static split: no per-tile operand select in the MFMA loop -- VALU work between
 // fp64 MFMAs costs matrix-pipe issue slots on gfx950, measured 8 %).
-template <int MT, int NW, int KT, int NSQ, bool SPLIT = false>
+// EPI selects the epilogue: 0 = store R (scaled by 1/std when the group carries moment rows),
+// 1 = fused split-half (both halves from the first half's raw sums, SplitEpi),
+// 2 = accumulate: the group's data rows are rows l = 0..L-1 of ITS resamples (out_row[row] = l),
+//     nothing is stored per resample; the block adds its resamples' values and squares per
+//     (l, column) in LDS and writes one partial (sum, sum of squares) tile per group -- the
+//     single-pass bootstrap of the unscaled modes, where the A operand already holds
+//     W_r^T = (A_r^T M_r)^T and the product IS the rotated bootstrap weights U_r = X^T W_r.
+#define PLSX_ACC_PITCH 80        // LDS pitch of an l-row (64 columns + 16: rows l, l+1 of one MFMA register land in different banks)
+template <int MT, int NW, int KT, int NSQ, int EPI = 0>
 __global__ __launch_bounds__(NW * 64, 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
@@ -499,6 +552,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
     const int nkt = nks / KT;
+    constexpr bool SPLIT = (EPI == 1);
     if constexpr (SPLIT) {
         // Fused split-half: the epilogue needs this block's (Tpp x 64) tile of the
         // arrangement's full-sample R and the group's row constants.  Fetched here by
@@ -566,6 +620,39 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
     // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
+    if constexpr (EPI == 2) {
+        // accumulate over the resamples of the group: LDS [2][L][PLSX_ACC_PITCH] (the A stages are dead)
+        const int L = se.accL;
+        double* sU = smem;
+        double* sV = smem + (size_t)L * PLSX_ACC_PITCH;
+        int* s_l = reinterpret_cast<int*>(sV + (size_t)L * PLSX_ACC_PITCH);
+        for (int i = tid; i < 2 * L * PLSX_ACC_PITCH; i += NT) smem[i] = 0.0;
+        for (int i = tid; i < MT * 16; i += NT) s_l[i] = out_row[i];
+        __syncthreads();
+        const int cw = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = s_l[m * 16 + kq + 4 * i];
+                if (l < 0) continue;
+                const double v = acc[m][i];
+                atomicAdd(&sU[l * PLSX_ACC_PITCH + cw], v);
+                atomicAdd(&sV[l * PLSX_ACC_PITCH + cw], v * v);
+            }
+        __syncthreads();
+        const int b0 = colblk * (NW * 16);
+        double* ps = se.acc_sum + (size_t)grp * se.accB * L;
+        double* pq = se.acc_sq + (size_t)grp * se.accB * L;
+        for (int idx = tid; idx < NW * 16 * L; idx += NT) {
+            const int c = idx / L, l = idx - c * L;
+            if (b0 + c < se.accB) {
+                ps[(size_t)(b0 + c) * L + l] = sU[l * PLSX_ACC_PITCH + c];
+                pq[(size_t)(b0 + c) * L + l] = sV[l * PLSX_ACC_PITCH + c];
+            }
+        }
+        return;
+    }
     if constexpr (SPLIT && NSQ > 0) {
         // fused split-half: both halves from the first half's raw sums (see SplitEpi)
         const int nmu = se.nmu;

@@ -260,3 +260,58 @@ def test_randomised_parity_sweep():
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     assert 'failures: 0 of 40' in proc.stdout
+
+
+@pytest.mark.parametrize('case', ['mc0', 'mc1', 'mc2', 'cov', 'cov_2g2c'])
+def test_single_pass_bootstrap_equals_two_pass(case, monkeypatch):
+    """Unscaled modes (mean-centred PLS, covariance-mode behavioral PLS): the bootstrap takes ONE
+    pass over the features per resample (G, P from the S x S kernel, U = X^T (A^T M) accumulated in the
+    cross-product epilogue; plsx_api.hip boot_single_pass).  Same sum U, sum U^2, distrib as the
+    two-pass route (R written, Gram pass, rotation pass) and as the oracle."""
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(17)
+    if case.startswith('mc'):
+        groups, n_cond, mc = [14, 11, 12], 3, int(case[2])
+        S, B = sum(groups) * n_cond, 3000
+        cells = rsmp.cell_of_row(groups, n_cond)
+        X = rs.randn(S, B) + 0.5 * rs.randn(len(groups) * n_cond, B)[cells]
+        Y, method, spec = None, 1, ref.Spec('meancentered', groups, n_cond, False, mc)
+    else:
+        groups, n_cond, mc = ([60], 1, 0) if case == 'cov' else ([21, 24], 2, 0)
+        S, B, T = sum(groups) * n_cond, 2500, 6
+        cells = rsmp.cell_of_row(groups, n_cond)
+        X = rs.randn(S, B) * (1.0 + rs.rand(1, B))
+        Y = rs.randn(S, T) * np.array([1, 2, .5, 3, 1, .7]) + 0.5 * X[:, :T]
+        method, spec = 0, ref.Spec('behavioral', groups, n_cond, True, 0)
+    Yo = Y if Y is not None else spec.dummy.astype(float)
+    boots = rsmp.gen_bootsamp(groups, n_cond, 130, seed=5)
+    U, d, V = ref.decompose(spec, X, Yo)
+    out = {}
+    for route in ('single', 'two'):
+        if route == 'two':
+            monkeypatch.setenv('PLSX_TWO_PASS_BOOT', '1')
+        eng = _engine()
+        eng.set_data(X, Y, cells, len(groups), n_cond, method, mean_centering=mc, covariance=(method == 0))
+        eng.set_original(U, np.diag(d), V)
+        usum, usq, dist = eng.boot(boots)
+        out[route] = (usum.cpu().numpy(), usq.cpu().numpy(), dist)
+    monkeypatch.delenv('PLSX_TWO_PASS_BOOT')
+    live = ref.live_lvs(d)
+    for a, b, what in zip(out['single'], out['two'], ('sum U', 'sum U^2', 'distrib')):
+        assert_close(a[:, live] if a.ndim == 2 else a[:, live], b[:, live] if b.ndim == 2 else b[:, live], 1e-9,
+                     what=what + ' single pass vs two pass')
+    n = 12                                                  # and against the oracle on a sample
+    usum, usq, dist = eng.boot(boots[:, :n])                # (eng = the two-pass engine; run the single-pass one too)
+    ws, wq, wd = np.zeros_like(U), np.zeros_like(U), []
+    for i in range(n):
+        dd, ub = ref.single_boot(spec, X, Yo, boots[:, i], U, d)
+        ws += ub
+        wq += ub ** 2
+        wd.append(dd)
+    eng1 = _engine()
+    eng1.set_data(X, Y, cells, len(groups), n_cond, method, mean_centering=mc, covariance=(method == 0))
+    eng1.set_original(U, np.diag(d), V)
+    usum, usq, dist = eng1.boot(boots[:, :n])
+    assert_close(usum.cpu().numpy()[:, live], ws[:, live], 1e-8, what='single-pass sum U vs oracle')
+    assert_close(usq.cpu().numpy()[:, live], wq[:, live], 1e-8, what='single-pass sum U^2 vs oracle')
+    assert_close(dist[:, live], np.stack(wd, -1)[:, live], 1e-8, what='single-pass distrib vs oracle')

@@ -509,9 +509,13 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     const size_t bytes = (size_t)nchunk * batch * 2 * tiles * 4096 * 8;
     if (int e = ensure(ctx, ctx->part, bytes)) return e;
     a.part = ptr<double>(ctx->part);
-    dim3 grid(nchunk, tiles, batch), block(256);
     KTimer tm(ctx, KC_NT, st);
-    hipLaunchKernelGGL(k_nt_gemm, grid, block, 0, st, a);
+    if (a.mtiles >= 2 && !B2) {
+        // two tile rows per block (32 x 64 per wave): the S x S products of the dual paths
+        hipLaunchKernelGGL(k_nt_gemm<2>, dim3(nchunk, ceil_div(a.mtiles, 2) * a.ntiles, batch), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_nt_gemm<1>, dim3(nchunk, tiles, batch), dim3(256), 0, st, a);
+    }
     LAUNCHCHK();
     {
         dim3 g(ceil_div(Ma * N1, 256), batch);

@@ -790,18 +790,23 @@ struct NtArgs {
     int batch;
 };
 
+// RM = 64-row output tiles per block (1 or 2).  With RM = 2 a wave owns 32 rows x 64 columns: two
+// A fragments against four B fragments per k-step, 8 MFMAs per 6 LDS reads -- with 16 rows per
+// wave (RM = 1: 4 MFMAs per 5 reads) three resident blocks ask the LDS for 240 B / cycle of the
+// 128 it delivers, and the S x S products of the dual paths ran at a third of the matrix rate.
+template <int RM>
 __global__ __launch_bounds__(256)
 void k_nt_gemm(NtArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double sA[64 * NT_LD];
+    __shared__ __attribute__((aligned(16))) double sA[RM * 64 * NT_LD];
     __shared__ __attribute__((aligned(16))) double sB1[64 * NT_LD];
-    __shared__ __attribute__((aligned(16))) double sB2[64 * NT_LD];
+    __shared__ __attribute__((aligned(16))) double sB2[RM == 1 ? 64 * NT_LD : 2];     // second product: RM = 1 only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
-    const int tile = blockIdx.y;
     const int b = blockIdx.z;
-    const int tm = tile / a.ntiles, tn = tile % a.ntiles;
-    const bool two = (a.B2 != nullptr);
+    // blockIdx.y enumerates (block row, column tile); a block row is RM tile rows
+    const int tmb = blockIdx.y / a.ntiles, tn = blockIdx.y % a.ntiles;
+    const bool two = RM == 1 && (a.B2 != nullptr);
     const int k0 = chunk * a.kchunk;
     const int k1 = min(a.K, k0 + a.kchunk);
 
@@ -811,22 +816,32 @@ void k_nt_gemm(NtArgs a)
 
     const int seg = tid & 15;       // double2 slot inside a 32-column row piece
     const int rbase = tid >> 4;     // 0..15
-    d4 acc1[4], acc2[4];
+    // wave -> rows of the block: RM = 1: 16 rows (wave * 16); RM = 2: 32 rows (wave * 32)
+    constexpr int RW = RM;          // A fragments (16-row pieces) per wave
+    d4 acc1[RW][4], acc2[RW][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc1[i] = (d4){0, 0, 0, 0}; acc2[i] = (d4){0, 0, 0, 0}; }
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc1[r][i] = (d4){0, 0, 0, 0}; acc2[r][i] = (d4){0, 0, 0, 0}; }
 
     for (int kk = k0; kk < k1; kk += NT_KB) {
         const int c = kk + seg * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4 * RM; ++i) {
             const int rl = rbase + 16 * i;
-            d2 va = (d2){0, 0}, v1 = (d2){0, 0}, v2 = (d2){0, 0};
-            const int ra = tm * 64 + rl;
+            d2 va = (d2){0, 0};
+            const int ra = tmb * (RM * 64) + rl;
             if (ra < a.Ma) {
                 const double* p = Ab + (size_t)ra * a.lda + c;
                 if (c + 1 < k1) va = *reinterpret_cast<const d2*>(p);
                 else if (c < k1) va = (d2){p[0], 0.0};
             }
+            *reinterpret_cast<d2*>(&sA[rl * NT_LD + seg * 2]) = va;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = rbase + 16 * i;
+            d2 v1 = (d2){0, 0}, v2 = (d2){0, 0};
             const int rb = tn * 64 + rl;
             if (rb < a.N1) {
                 const double* p = B1b + (size_t)rb * a.ldb1 + c;
@@ -838,7 +853,6 @@ void k_nt_gemm(NtArgs a)
                 if (c + 1 < k1) v2 = *reinterpret_cast<const d2*>(p);
                 else if (c < k1) v2 = (d2){p[0], 0.0};
             }
-            *reinterpret_cast<d2*>(&sA[rl * NT_LD + seg * 2]) = va;
             *reinterpret_cast<d2*>(&sB1[rl * NT_LD + seg * 2]) = v1;
             if (two) *reinterpret_cast<d2*>(&sB2[rl * NT_LD + seg * 2]) = v2;
         }
@@ -846,25 +860,40 @@ void k_nt_gemm(NtArgs a)
 #pragma unroll
         for (int ks = 0; ks < NT_KB / 4; ++ks) {
             const int off = (lane & 15) * NT_LD + ks * 4 + (lane >> 4);
-            const double fa = sA[wave * 16 * NT_LD + off];
+            double fa[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) fa[r] = sA[(wave * RW + r) * 16 * NT_LD + off];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                acc1[nt] = mfma_f64(fa, sB1[nt * 16 * NT_LD + off], acc1[nt]);
-                if (two) acc2[nt] = mfma_f64(fa, sB2[nt * 16 * NT_LD + off], acc2[nt]);
+                const double fb1 = sB1[nt * 16 * NT_LD + off];
+#pragma unroll
+                for (int r = 0; r < RW; ++r) acc1[r][nt] = mfma_f64(fa[r], fb1, acc1[r][nt]);
+                if (two) {
+                    const double fb2 = sB2[nt * 16 * NT_LD + off];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc2[r][nt] = mfma_f64(fa[r], fb2, acc2[r][nt]);
+                }
             }
         }
         __syncthreads();
     }
     const size_t tiles = (size_t)a.mtiles * a.ntiles;
-    double* out = a.part + ((((size_t)chunk * a.batch + b) * 2) * tiles + tile) * 4096;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int r = 0; r < RW; ++r) {
+        const int rowb = (wave * RW + r) * 16;                 // row of the block
+        const int tm = tmb * RM + rowb / 64;                     // 64-row output tile
+        if (tm >= a.mtiles) continue;
+        const int tile = tm * a.ntiles + tn;
+        double* out = a.part + ((((size_t)chunk * a.batch + b) * 2) * tiles + tile) * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = wave * 16 + (lane >> 4) + 4 * i, n = nt * 16 + (lane & 15);
-            out[m * 64 + n] = acc1[nt][i];
-            if (two) out[tiles * 4096 + m * 64 + n] = acc2[nt][i];
-        }
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (rowb & 63) + (lane >> 4) + 4 * i, n = nt * 16 + (lane & 15);
+                out[m * 64 + n] = acc1[r][nt][i];
+                if (two) out[tiles * 4096 + m * 64 + n] = acc2[r][nt][i];
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -25,10 +25,15 @@ S x S dual-space shortcut (no pass over X per permutation; SURVEY.md section
 with the permutations forced through the feature pass R_p = A_p X -- the
 north-star pipeline -- measured in a second timed region of the same run.
 
-``--mode strong``: one step = ONE analysis of --n-perm + --n-boot resamples
-(default 10000 + 10000) split over the ranks with parallel.shard_bounds; the
-seed-compatible host index generation, the H2D copies of the index shards and
-the one all-gather are inside the clock.
+``--mode strong``: one step = ONE analysis of --perms + --boots resamples
+(default 10000 + 10000) split over the ranks with parallel.shard_bounds, run
+the way the front-end runs it: one RandomState drawn on a host thread in the
+reference's order while the rank ships its shard to the device chunk by chunk
+(resampling.IndexStream); index generation, the H2D copies of the shards and
+the one all-gather are inside the clock.  ``--emulate-world 1,2,4,8`` (one
+GPU): critical path of one analysis on rank 0 and rank N-1 of an emulated
+world N, both permutation routes, with the implied efficiency -- an emulation,
+not a hardware scaling curve.
 
 ``--config`` selects another BASELINE config (bench lines for the record; the
 driver runs the default): c2, c3, c5, c4split.

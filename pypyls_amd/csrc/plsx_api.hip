@@ -55,6 +55,7 @@ struct plsx_ctx {
     Buf momout, R2, cvc, Qm, Vs, ds, ybar, pred;        // cross-validation scratch
     Buf Xn, out_row_f, mom_idx_f;                       // fixed-X fast path
     Buf Kd, Ad, Wd;                                     // dual permutation path (S x S kernel)
+    Buf Qs;                                             // SIMPLS: Xc . W0c^T (S x k), sign alignment of the bootstrap in dual space
     Buf ScT, out_row_w;                                 // single-pass bootstrap (unscaled modes): scores^T (L x S), row -> l map
     int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
@@ -981,7 +982,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1047,6 +1048,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     }
     ctx->has_data = ctx->has_orig = false;
     ctx->has_Kd = 0;
+    ctx->npg_w = 0;                                    // the row -> LV map of the accumulating epilogue follows L
     // a re-bound context keeps its scratch: the padding rows (t >= T') of every R slot must
     // read as zero under the new layout too
     if (ctx->R.p) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
@@ -1797,7 +1799,7 @@ extern "C" {
 namespace {
 int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, bool scatter,
                     double* pctvar, double* yload, double* cvec, hipStream_t st,
-                    const double* ystack = nullptr)
+                    const double* ystack = nullptr, bool align_signs = false)
 {
     const int S = ctx->S, T = ctx->T, k = ctx->ncomp;
     const int groups = ceil_div(nres, ctx->npg);
@@ -1880,8 +1882,9 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
                 return e;
     }
     {
+        a.Qs = align_signs ? ptr<double>(ctx->Qs) : nullptr;
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_final, grid, block, 0, st, a);
+        hipLaunchKernelGGL(k_sd_final, grid, block, (size_t)wpb * k * 8, st, a);
         LAUNCHCHK();
     }
 #ifdef PLSX_SD_PROBE
@@ -1898,6 +1901,15 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     }
 #endif
     return 0;
+}
+}  // namespace
+
+namespace {
+// single-pass form of the SIMPLS bootstrap: signs aligned in dual space (k_sd_final), the feature
+// pass accumulates the aligned weights and their squares (k_xprod EPI = 2)
+bool simpls_single_pass(const plsx_ctx* ctx)
+{
+    return (size_t)2 * ctx->ncomp * PLSX_ACC_PITCH * 8 <= 72 * 1024 && ctx->Qs.p && !getenv("PLSX_TWO_PASS_BOOT");
 }
 }  // namespace
 
@@ -1927,6 +1939,11 @@ int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream)
     HIPCHK(hipMemsetAsync(ctx->U0T.p, 0, (size_t)ctx->L * ctx->Bpad * 8, st));
     HIPCHK(hipMemcpy2DAsync(ctx->U0T.p, (size_t)ctx->Bpad * 8, d_w0cT, (size_t)ctx->B * 8, (size_t)ctx->B * 8,
                             ctx->ncomp, hipMemcpyDeviceToDevice, st));
+    // Qs = Xc . W0c^T (S x k): what the sign alignment of a bootstrap needs in dual space
+    if (int e = ensure(ctx, ctx->Qs, (size_t)ctx->S * ctx->ncomp * 8)) return e;
+    if (int e = run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, ctx->S, ptr<double>(ctx->U0T), 0, ctx->Bpad, ctx->ncomp,
+                       nullptr, 0, 0, 0, ctx->B, 1, ptr<double>(ctx->Qs), 0, ctx->ncomp, nullptr, 0, 0, st))
+        return e;
     ctx->has_orig = true;
     return PLSX_OK;
 }
@@ -1996,8 +2013,56 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const doubl
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
         double* yl = d_yload + (size_t)off * T * k;
         const double* yst = d_ystack ? d_ystack + (size_t)off * ctx->S * T : nullptr;
-        if (int e = run_simpls_dual(ctx, idx, idx, ms, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st, yst))
+        const bool single = simpls_single_pass(ctx);
+        if (int e = run_simpls_dual(ctx, idx, idx, ms, true, ptr<double>(ctx->spct), yl, ptr<double>(ctx->sc), st, yst,
+                                    single))
             return e;
+        if (single) {
+            // ONE feature pass, no R: x_weights = X0_r^T (flip . Wd) accumulated per group in the epilogue
+            const int MT = 24, NW = 4, npg_w = (MT * 16) / k;
+            if (npg_w != ctx->npg) return fail(ctx, PLSX_ERR_STATE, "simpls single pass: group layout mismatch");
+            if (ctx->npg_w != npg_w || ctx->out_row_w.bytes < (size_t)MT * 16 * sizeof(int)) {
+                std::vector<int> lmap(MT * 16, -1);
+                for (int rr = 0; rr < npg_w; ++rr)
+                    for (int l = 0; l < k; ++l) lmap[rr * k + l] = l;
+                if (int e = ensure(ctx, ctx->out_row_w, lmap.size() * sizeof(int))) return e;
+                HIPCHK(hipMemcpy(ctx->out_row_w.p, lmap.data(), lmap.size() * sizeof(int), hipMemcpyHostToDevice));
+                ctx->npg_w = npg_w;
+            }
+            const int gtot = ceil_div(ms, npg_w);
+            // groups per pass: partial (sum, sum of squares) tiles [groups][B][k] x 2 within a quarter of the scratch
+            const double per_group = 2.0 * ctx->B * (double)k * 8.0;
+            const int gmax = (int)std::max(1.0, std::min(512.0, ctx->scratch_gb * 1073741824.0 / 4.0 / per_group));
+            for (int g0 = 0; g0 < gtot; g0 += gmax) {
+                const int groups = std::min(gmax, gtot - g0);
+                if (int e = ensure(ctx, ctx->psum, (size_t)groups * ctx->B * k * 8)) return e;
+                if (int e = ensure(ctx, ctx->psq, (size_t)groups * ctx->B * k * 8)) return e;
+                if (ctx->timing) ctx->timed_units += std::min(ms - g0 * npg_w, groups * npg_w);
+                const size_t stage = (size_t)2 * (((size_t)MT * 64 + 127) / 128) * 128 * 8;
+                const size_t epi = (size_t)2 * k * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4;
+                const size_t lds = std::max(stage, epi);
+                HIPCHK(set_lds(k_xprod<24, 4, 1, 0, 2>, lds));
+                const int ncolblk = ctx->Bpad / (NW * 16);
+                SplitEpi se;
+                memset(&se, 0, sizeof(se));
+                se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = k; se.accB = ctx->B;
+                {
+                    KTimer tm(ctx, KC_XPROD, st);
+                    hipLaunchKernelGGL((k_xprod<24, 4, 1, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
+                                       ptr<double>(ctx->Afrag) + (size_t)g0 * ctx->group_stride, ctx->group_stride,
+                                       ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks, (double*)nullptr, ctx->Bpad, 0,
+                                       ptr<int>(ctx->out_row_w), (const int*)nullptr, (const double*)nullptr, 0, groups,
+                                       ncolblk, (double*)nullptr, se, 1);
+                    LAUNCHCHK();
+                }
+                KTimer tm(ctx, KC_UROT, st);
+                const long long count = (long long)ctx->B * k;
+                hipLaunchKernelGGL(k_add_splits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,
+                                   ptr<double>(ctx->psum), ptr<double>(ctx->psq), groups, count, d_usum, d_usq);
+                LAUNCHCHK();
+            }
+            continue;
+        }
         for (int o2 = 0; o2 < ms; o2 += nb) {
             const int m = std::min(nb, ms - o2);
             ctx->afrag_group0 = o2 / ctx->npg;

@@ -113,6 +113,7 @@ struct SdArgs {
     double* yload;              // [nres][T][k]  Y[ys]^T (X[xs] W), signs not yet aligned
     double* cvec;               // [nres][T][k]  right singular vectors c_c (sign rule when B <= T)
     double* Afrag;              // dual weights scattered into k_xprod's A operand (or nullptr)
+    const double* Qs;           // [S][k] Xc . W0c^T (centred original weights): bootstrap sign alignment in dual space, or nullptr
     size_t group_stride;
     GroupLayout lay;
 };
@@ -698,19 +699,54 @@ void k_sd_step(SdArgs a)
     SD_MARK(12);
 }
 
-// Outputs for the bootstrap: y_loadings (unsigned) = Y[ys]^T (X[xs] W), Y NOT
-// re-centred (regression.py:325); dual weights scattered into k_xprod's A operand.
+// Outputs for the bootstrap: y_loadings = Y[ys]^T (X[xs] W), Y NOT re-centred
+// (regression.py:325); dual weights scattered into k_xprod's A operand.
+// With a.Qs the sign alignment of regression.py:317-320 happens HERE, in dual space:
+//   flip_c = sign(corr(w_c, w0_c)) = sign(sum_b w_c[b] w0c_c[b]),  w_c = X0_r^T wd_c
+//          = sign(sum_p wd_c[p] (Xc w0c_c)[xs_p]) = sign(sum_p WD[c][p] Qs[xs_p][c])
+// (w0c centred over the features, wd_c centred over the positions), so the feature pass can
+// accumulate the aligned weights directly (k_xprod EPI = 2) instead of writing them, forming
+// their cross-Gram with the original and reading them back for the sign and the sums.
+// dynamic LDS: k doubles per wave.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_final(SdArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) double sm_sd[];
     const int S = a.S, T = a.T, k = a.k, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
     const int r = blockIdx.x * (blockDim.x >> 6) + wave;
     if (r >= a.nres) return;
+    double* flip = sm_sd + (size_t)wave * k;
     const int* xs = a.xs + (size_t)r * S;
     const int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
     const double* XW = a.XW + (size_t)r * k * S;
     const double* WD = a.WD + (size_t)r * k * S;
+    for (int c0 = 0; c0 < k; c0 += 4) {
+        double s4[4] = {1.0, 1.0, 1.0, 1.0};
+        if (a.Qs) {
+            const double *w0 = WD + (size_t)min(c0, k - 1) * S, *w1 = WD + (size_t)min(c0 + 1, k - 1) * S,
+                         *w2 = WD + (size_t)min(c0 + 2, k - 1) * S, *w3 = WD + (size_t)min(c0 + 3, k - 1) * S;
+            s4[0] = s4[1] = s4[2] = s4[3] = 0.0;
+            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                SD_TILE_PC(pc, p0);
+                int xv[SD_RC];
+                SD_OWN(i) xv[i] = xs[pc[i]];
+                SD_OWN(i) {
+                    const bool ok = SD_IN(p0, i) && xv[i] >= 0;
+                    const double* q = a.Qs + (size_t)max(xv[i], 0) * k;
+                    const double q0 = q[min(c0, k - 1)], q1 = q[min(c0 + 1, k - 1)], q2 = q[min(c0 + 2, k - 1)],
+                                 q3 = q[min(c0 + 3, k - 1)];
+                    s4[0] += ok ? w0[pc[i]] * q0 : 0.0; s4[1] += ok ? w1[pc[i]] * q1 : 0.0;
+                    s4[2] += ok ? w2[pc[i]] * q2 : 0.0; s4[3] += ok ? w3[pc[i]] * q3 : 0.0;
+                }
+            }
+            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+        }
+        if (lane == 0)
+            for (int u = 0; u < 4 && c0 + u < k; ++u)
+                flip[c0 + u] = (s4[u] > 0.0) ? 1.0 : ((s4[u] < 0.0) ? -1.0 : 0.0);
+    }
+    wave_sync();
     for (int t = 0; t < T; ++t)
         for (int c0 = 0; c0 < k; c0 += 4) {
             const double *w0 = XW + (size_t)min(c0, k - 1) * S, *w1 = XW + (size_t)min(c0 + 1, k - 1) * S,
@@ -727,14 +763,15 @@ void k_sd_final(SdArgs a)
             }
             wave_sum4(s4[0], s4[1], s4[2], s4[3]);
             if (lane == 0)
-                for (int u = 0; u < 4 && c0 + u < k; ++u) a.yload[((size_t)r * T + t) * k + c0 + u] = s4[u];
+                for (int u = 0; u < 4 && c0 + u < k; ++u)
+                    a.yload[((size_t)r * T + t) * k + c0 + u] = s4[u] * flip[c0 + u];
         }
     if (a.Afrag) {
         const int g = r / a.lay.n, rr = r % a.lay.n;
         double* A = a.Afrag + (size_t)g * a.group_stride;
         for (int idx = lane; idx < S * k; idx += 64) {
             const int c = idx / S, p = idx - c * S;
-            if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), WD[(size_t)c * S + p]);
+            if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), flip[c] * WD[(size_t)c * S + p]);
         }
     }
 }

@@ -253,9 +253,13 @@ def test_randomised_parity_sweep():
     """tools/fuzz_parity.py: random designs / shapes / options (behavioral with and
     without covariance, mean-centred with every centring, 1-3 groups x 1-3
     conditions, B from 3 to 1500, rotate on / off, split-half) against the oracle."""
+    import gc
     import subprocess
     import sys
+    import torch
     from conftest import ROOT
+    gc.collect()                                        # engines of earlier tests hold tens of GB of device scratch;
+    torch.cuda.empty_cache()                            # the sweep runs in its own process on the same GPU
     proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'fuzz_parity.py'), '40', '123'],
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]

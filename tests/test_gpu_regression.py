@@ -141,3 +141,28 @@ def test_regression_errors():
     assert 'singvals' not in res or res.get('singvals') is None
     assert res.bootres.y_loadings_boot.shape == (3, 2, 4)
     assert res.permres.perm_singval.shape == (2, 4)
+
+
+def test_single_pass_bootstrap_equals_two_pass(monkeypatch):
+    """The SIMPLS bootstrap aligns its signs in dual space and takes one feature pass whose
+    epilogue accumulates the aligned weights (plsx_simpls_boot_batch, k_xprod EPI = 2); the
+    two-pass route (weights written, cross-Gram with the original, rotation pass) gives the
+    same bootstrap ratios and y_loadings -- also with NaN rows and more bootstraps than one
+    solver batch."""
+    import pypyls_amd as pls
+    rs = np.random.RandomState(11)
+    S, B, T, k = 70, 2600, 9, 6
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T) + 0.5 * X[:, :T]
+    X[5] = np.nan
+    Y[9] = np.nan
+    out = {}
+    for route in ('single', 'two'):
+        if route == 'two':
+            monkeypatch.setenv('PLSX_TWO_PASS_BOOT', '1')
+        out[route] = pls.pls_regression(X, Y, n_components=k, n_perm=10, n_boot=700, seed=99, verbose=False)
+    monkeypatch.delenv('PLSX_TWO_PASS_BOOT')
+    a, b = out['single'], out['two']
+    np.testing.assert_array_equal(a.bootres.bootsamples, b.bootres.bootsamples)
+    for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
+        assert_close(a['bootres'][key], b['bootres'][key], 1e-9, what='single vs two pass ' + key)

@@ -1,10 +1,11 @@
 #!/bin/bash
 # usage: tools/record_round.sh <rNN>   (GPU box, repo root): clean bench lines of every config for the record
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out
 run() { name=$1; shift; python bench.py "$@" > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err; head -c 400 gpurun_out/${tag}_bench_${name}.json; echo; }
 run c4 --steps 20 --warmup 5
 run c4_strong --mode strong --steps 3 --warmup 1
+run c4_strong_emulation --mode strong --steps 2 --warmup 1 --emulate-world 1,2,4,8 --cpu-sample 0
 run c2 --config c2 --steps 10 --warmup 2
 run c3 --config c3 --steps 5 --warmup 2
 run c5 --config c5 --steps 5 --warmup 2

@@ -263,7 +263,12 @@ class PLSC(object):
         # the resamples of a group share one pass over X, so the algorithmic-byte rate may
         # exceed the HBM peak; a kernel is not bound by a roof it exceeds -> MFMA then
         mf = f_m >= f_h or f_h > 1.0
-        return {'bound': 'mfma' if mf else 'hbm', 'kernel': 'k_xprod<{}>'.format(int(tm.get('m_tiles', 0))),
+        mom_ms = kt.get('k_xprod_moments', (0.0, 0))[0] / max(steps, 1)
+        kname = 'k_xprod<{}>'.format(int(tm.get('m_tiles', 0)))
+        if mom_ms > 0:
+            kname += ' (data-only blocks; the feature moments of all (resample, cell) pairs come from moment-only ' \
+                     'blocks, k_xprod_moments: {:.2f} ms per step, not in this kernel\'s time)'.format(mom_ms)
+        return {'bound': 'mfma' if mf else 'hbm', 'kernel': kname,
                 'achieved': tf if mf else tb * 1e3, 'peak': PEAK_FP64_MFMA_TFLOPS if mf else PEAK_HBM_TBS * 1e3,
                 'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': f_m if mf else f_h,
                 'frac_mfma': f_m, 'frac_hbm_algorithmic': f_h,

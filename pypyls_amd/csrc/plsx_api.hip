@@ -37,6 +37,11 @@ struct plsx_ctx {
     int MT = 24, npg = 0, w0 = 0, sq0 = 0, nmom_pad = 0, scaled = 0, momrows = 0, Gcap = 0, Galloc = 0;
     int nks_t = 0, LT = 0, cv_mom = 0;
     int afrag_group0 = 0;                               // first group of Afrag a prebuilt cross-product launch reads
+    // separate-moments layout of the correlation mode (sepmom): data-only groups of MTd tiles holding
+    // npg_d resamples, the feature moments of all (resample, cell) pairs from moment-only blocks
+    int sepmom = 0, MTd = 0, npg_d = 0, sepmom_used = 0;
+    size_t group_stride_d = 0;
+    Buf out_row_d, mom_idx_d, Afrag_m, momn_m, scale;
     size_t group_stride = 0;
     // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
     int gps = 0;
@@ -149,9 +154,9 @@ hipError_t set_lds(F* fn, size_t bytes)
 }
 
 // kernel classes of plsx_kernel_timing()
-enum { KC_XPROD = 0, KC_GRAM, KC_SMALL, KC_UROT, KC_NT, KC_UCORR, KC_SIMPLS, KC_BUILD, KC_COUNT };
+enum { KC_XPROD = 0, KC_GRAM, KC_SMALL, KC_UROT, KC_NT, KC_UCORR, KC_SIMPLS, KC_BUILD, KC_MOM, KC_COUNT };
 const char* const kKernelClassNames[KC_COUNT] = {"k_xprod", "k_gram", "k_small", "k_urot", "k_nt_gemm",
-                                                 "k_ucorr_partial", "k_simpls_dual", "k_build_A"};
+                                                 "k_ucorr_partial", "k_simpls_dual", "k_build_A", "k_xprod_moments"};
 
 // Brackets the launches of one kernel class with two events when timing is on.
 struct KTimer {
@@ -292,6 +297,39 @@ int upload_rowmaps(plsx_ctx* ctx)
     return 0;
 }
 
+// Separate-moments layout (correlation mode, plain layout): choose the data block height and
+// upload its row maps.  In-block moments cost 2 of 24 tiles for 7 + 7 rows at the headline shape.
+int plan_sepmom(plsx_ctx* ctx)
+{
+    ctx->sepmom = 0;
+    if (!ctx->scaled || ctx->gps > 0 || getenv("PLSX_INBLOCK_MOMENTS")) return 0;
+    int best_mt = 0, best_n = 0;
+    double best_fill = 0.0;
+    for (int mt : {24, 22, 16}) {
+        const int n = (mt * 16) / ctx->Tp;
+        if (n < 1) continue;
+        // rows used per tile; a lower block re-reads X more often: it has to win by 3 %
+        const double fill = (double)n * ctx->Tp / (mt * 16.0) * (mt == 24 ? 1.0 : (mt == 22 ? 0.985 : 0.955));
+        if (fill > best_fill) { best_fill = fill; best_mt = mt; best_n = n; }
+    }
+    if (best_n < ctx->npg || best_n * ctx->J * 64 * 8 > 48 * 1024) return 0;     // scale tile of a block in LDS
+    ctx->MTd = best_mt; ctx->npg_d = best_n;
+    ctx->group_stride_d = (size_t)ctx->nks * best_mt * 64;
+    const int rows = best_mt * 16;
+    std::vector<int> orow(rows, -1), mrow(rows, -1);
+    for (int rr = 0; rr < best_n; ++rr)
+        for (int t = 0; t < ctx->Tp; ++t) {
+            orow[rr * ctx->Tp + t] = rr * ctx->Tpp + t;
+            mrow[rr * ctx->Tp + t] = rr * ctx->J + t / ctx->T;
+        }
+    if (ensure(ctx, ctx->out_row_d, rows * sizeof(int))) return PLSX_ERR_HIP;
+    if (ensure(ctx, ctx->mom_idx_d, rows * sizeof(int))) return PLSX_ERR_HIP;
+    HIPCHK(hipMemcpy(ctx->out_row_d.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->mom_idx_d.p, mrow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    ctx->sepmom = 1;
+    return 0;
+}
+
 // scratch for `groups` groups of resamples
 int ensure_scratch(plsx_ctx* ctx, int groups)
 {
@@ -416,6 +454,76 @@ int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, co
     return 0;
 }
 
+// Correlation mode, separate-moments layout: data-only blocks (MTd tiles, npg_d resamples) scaled by
+// 1 / std from a table that moment-only blocks (192 (resample, cell) pairs each) write first.
+template <int MT>
+int launch_xprod_data(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
+{
+    constexpr int NW = 4, KT = 1;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
+    const size_t epi = (size_t)se.npairs * NW * 16 * 8 + (size_t)2 * MT * 16 * 4;
+    const size_t lds = std::max(stage, epi);
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 3>, lds));
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 3>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
+                       ptr<double>(ctx->Afrag), ctx->group_stride_d, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                       ptr<double>(ctx->R), ctx->Bpad, ctx->npg_d * ctx->Tpp, ptr<int>(ctx->out_row_d),
+                       ptr<int>(ctx->mom_idx_d), (const double*)nullptr, 0, groups, ncolblk, (double*)nullptr, se, 1);
+    LAUNCHCHK();
+    return 0;
+}
+
+int run_xprod_sepmom(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
+                     const double* ystack, long long ystride)
+{
+    const int npairs = nres * ctx->J;
+    const int groups_d = ceil_div(nres, ctx->npg_d), groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
+    const size_t mstride = (size_t)ctx->nks * 24 * 64;
+    if (int e = ensure(ctx, ctx->Afrag_m, (size_t)groups_m * mstride * 8 + 4096)) return e;
+    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, PLSX_MOM_PAIRS) * 8)) return e;
+    if (int e = ensure(ctx, ctx->scale, (size_t)round_up(std::max(npairs, groups_d * ctx->npg_d * ctx->J), 8) * ctx->Bpad * 8))
+        return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)groups_d * ctx->group_stride_d * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->Afrag_m.p, 0, (size_t)groups_m * mstride * 8, st));
+    GroupLayout lay;
+    lay.n = ctx->npg_d; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MTd;
+    lay.w0 = ctx->MTd; lay.sq0 = ctx->MTd; lay.Tpp = ctx->Tpp;
+    {
+        KTimer tm(ctx, KC_BUILD, st);
+        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, ctx->J), dim3(256), (size_t)2 * ctx->T * 8, st,
+                           ystack ? ystack : ptr<double>(ctx->Y), ystack ? ystride : 0LL, ctx->T, ctx->S,
+                           ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay, ctx->cov, 1,
+                           ptr<double>(ctx->Afrag), ctx->group_stride_d, ptr<double>(ctx->momn_m), 0, 0,
+                           ptr<double>(ctx->Afrag_m), mstride);
+        LAUNCHCHK();
+    }
+    SplitEpi se;
+    memset(&se, 0, sizeof(se));
+    se.scale = ptr<double>(ctx->scale);
+    {
+        // moment-only blocks: 12 weight tiles against X, the same 12 against X^2
+        constexpr int NW = 4;
+        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
+        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 4>, lds));
+        const int ncolblk = ctx->Bpad / (NW * 16);
+        se.npairs = npairs;
+        KTimer tm(ctx, KC_MOM, st);
+        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 4>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                           ptr<double>(ctx->momn_m), 0, groups_m, ncolblk, (double*)nullptr, se, 1);
+        LAUNCHCHK();
+    }
+    se.npairs = ctx->npg_d * ctx->J;
+    se.accB = nres * ctx->Tpp;
+    switch (ctx->MTd) {
+        case 24: return launch_xprod_data<24>(ctx, groups_d, se, st);
+        case 22: return launch_xprod_data<22>(ctx, groups_d, se, st);
+        default: return launch_xprod_data<16>(ctx, groups_d, se, st);
+    }
+}
+
 // Build the A operands of `nres` resamples and run the cross-product kernel:
 // afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
 // [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
@@ -430,6 +538,17 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
     if (ctx->timing) ctx->timed_units += nres;
     const int pgroups = phys_groups(ctx, groups);
     if (prebuilt) return launch_xprod(ctx, pgroups, st);       // A already scattered by the caller
+    if (ctx->sepmom && ctx->method == PLSX_BEHAVIORAL && !ctx->mom_out_arg) {
+        // tile passes of the launch in either layout; the separate-moments layout has to win by 2 %
+        // (one more launch, the scale table): it does at the headline shape (1728 -> 1656 per 504
+        // bootstraps), not for a handful of resamples or for small T' (c2: 32 vs 38 resamples a block)
+        const long long cost_a = (long long)groups * ctx->MT;
+        const long long cost_b = (long long)ceil_div(nres, ctx->npg_d) * ctx->MTd +
+                                 (long long)ceil_div(nres * ctx->J, PLSX_MOM_PAIRS) * 24;
+        ctx->sepmom_used = cost_b * 102 < cost_a * 100;
+        if (ctx->sepmom_used)
+            return run_xprod_sepmom(ctx, xsrc, ysrc, nres, st, ystack, ystride);
+    }
     HIPCHK(hipMemsetAsync(ctx->Afrag.p, 0, (size_t)pgroups * ctx->group_stride * 8, st));
     GroupLayout lay;
     lay.n = ctx->npg; lay.Tp = ctx->Tp; lay.J = ctx->J; lay.T = ctx->T; lay.MT = ctx->MT;
@@ -982,7 +1101,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1105,6 +1224,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
                     "cannot lay out the rows of a resample (with their per-cell moment rows) over cross-product blocks");
     if (int e = upload_rowmaps(ctx)) return e;
+    if (int e = plan_sepmom(ctx)) return e;
     ctx->fix = 0; ctx->has_Xn = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
     {
         const char* nf = getenv("PLSX_NO_FIXED_X");
@@ -2170,7 +2290,7 @@ int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
             ms += t;
         ++launches;
     }
-    double vals[7] = {ms, (double)launches, (double)ctx->npg, (double)ctx->MT,
+    double vals[7] = {ms, (double)launches, (double)(ctx->sepmom_used ? ctx->npg_d : ctx->npg), (double)(ctx->sepmom_used ? ctx->MTd : ctx->MT),
                       (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual};
     int n = std::min(cap, 7);
     for (int i = 0; i < n; ++i) out[i] = vals[i];

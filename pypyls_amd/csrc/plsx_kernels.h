@@ -39,6 +39,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_UROT_KC 20         // k-steps (of 4 rows of T') per LDS stage of the rotation operand when it is staged in pieces
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
+#define PLSX_MOM_PAIRS 192       // (resample, cell) pairs per moment-only cross-product block (12 + 12 tiles)
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
 {
@@ -130,8 +131,13 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
                                 const int* __restrict__ xsrc, const int* __restrict__ ysrc,
                                 GroupLayout lay, int covariance, int scaled,
                                 double* __restrict__ Afrag, size_t group_stride,
-                                double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0)
+                                double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0,
+                                double* __restrict__ Amom = nullptr, size_t mom_stride = 0)
 {
+    // Amom != nullptr (separate-moments layout): the weight rows of (resample, cell) pair
+    // q = r * J + j go to group q / PLSX_MOM_PAIRS of Amom -- moment-only blocks of 24 tiles, rows
+    // [0, 192) against X and rows [192, 384) against X^2 -- instead of riding in the data group;
+    // mom_n is then indexed by the pair.
     // dense_ld != 0: write plain row-major (T' x dense_ld) matrices, one per
     // resample, instead of k_xprod's fragment order (dual permutation path)
     extern __shared__ double sm_b[];
@@ -212,6 +218,18 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
             }
             if (tid == 0) mom_n[gg * nmom_pad + mrow] = (double)cnt;
         }
+    } else if (scaled && Amom) {
+        const int pair = r * lay.J + j;
+        double* Am = Amom + (size_t)(pair / PLSX_MOM_PAIRS) * mom_stride;
+        const int mrow = pair % PLSX_MOM_PAIRS;
+        for (int pl = tid; pl < len; pl += blockDim.x) {
+            int p = start + pl;
+            int xi = xs ? xs[p] : p;
+            if (xi < 0) continue;
+            atomicAdd(Am + afrag_off(mrow, xi, 24), 1.0);
+            atomicAdd(Am + afrag_off(PLSX_MOM_PAIRS + mrow, xi, 24), 1.0);
+        }
+        if (tid == 0) mom_n[pair] = (double)cnt;
     } else if (scaled) {
         for (int pl = tid; pl < len; pl += blockDim.x) {
             int p = start + pl;
@@ -354,6 +372,11 @@ struct SplitEpi {
     double* acc_sum;
     double* acc_sq;
     int accL, accB;
+    // EPI == 3 / 4 (separate-moments layout): 1 / std of every (resample, cell) pair and column,
+    // [pair][ldr]; written by the moment-only blocks (EPI 4), read by the data blocks (EPI 3)
+    double* scale;
+    int npairs;              // EPI 4: pairs of the launch;  EPI 3: pairs per data group (resamples x cells);
+                             // EPI 3 also takes accB = R rows of the launch (resamples x Tpp)
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
@@ -501,6 +524,10 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 //     (l, column) in LDS and writes one partial (sum, sum of squares) tile per group -- the
 //     single-pass bootstrap of the unscaled modes, where the A operand already holds
 //     W_r^T = (A_r^T M_r)^T and the product IS the rotated bootstrap weights U_r = X^T W_r.
+// 3 = data-only block of the separate-moments layout: R scaled by 1 / std from a table (se.scale),
+// 4 = moment-only block (MT = 2 NSQ: weight tiles against X, then against X^2) writing that table.
+//     Correlation mode with in-block moments spends 2 of 24 tiles on 7 + 7 moment rows; here the
+//     moments of 192 (resample, cell) pairs fill a block and the data blocks carry data only.
 #define PLSX_ACC_PITCH 80        // LDS pitch of an l-row (64 columns + 16: rows l, l+1 of one MFMA register land in different banks)
 template <int MT, int NW, int KT, int NSQ, int EPI = 0>
 __global__ __launch_bounds__(NW * 64, 2)
@@ -620,6 +647,61 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
     // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
+    if constexpr (EPI == 4) {
+        // moment-only block (W0 = 0): tile j holds the first moments of pairs j * 16 .. + 15, tile
+        // NSQ + j their second moments; 1 / std (ddof 1) of the resampled feature inside the cell
+        // straight from the accumulators to the scale table
+        static_assert(MT == 2 * NSQ, "EPI 4 is the moment-only instantiation");
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pair = grp * (NSQ * 16) + j * 16 + kq + 4 * i;
+                if (pair >= se.npairs) continue;
+                const double m1 = acc[j][i], m2 = acc[NSQ + j][i];
+                const double nn = mom_n[pair];
+                const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);
+                se.scale[(size_t)pair * ldr + col] = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+            }
+        return;
+    }
+    if constexpr (EPI == 3) {
+        // data-only block: the scales of the group's (resample, cell) pairs for this block's 64 columns
+        // come from the table, all loads up front (a load waited for between the stores below would
+        // drain them: loads and stores share vmcnt on gfx950)
+        const int nmu = se.npairs;
+        double* sS3 = smem;                               // [nmu][64]
+        int* s_out = reinterpret_cast<int*>(smem + (size_t)nmu * (NW * 16));
+        int* s_mom = s_out + MT * 16;
+        const double* sc0 = se.scale + (size_t)grp * nmu * ldr + colblk * (NW * 16);
+        for (int idx = tid; idx < nmu * (NW * 16); idx += NT) {
+            const int mi = idx / (NW * 16), c = idx - mi * (NW * 16);
+            sS3[idx] = sc0[(size_t)mi * ldr + c];
+        }
+        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+        __syncthreads();
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+        const int cw = wave * 16 + (lane & 15);
+        // the last group may hold fewer resamples than its block has room for: their rows (zero A
+        // rows, no scale) are not stored -- the R scratch is sized for the resamples of the launch
+        const int rows_valid = min(rows_per_group, se.accB - grp * rows_per_group);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int orow[4];
+            double sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m * 16 + kq + 4 * i;
+                orow[i] = s_out[row];
+                const int mi = s_mom[row];
+                sc[i] = mi >= 0 ? sS3[mi * (NW * 16) + cw] : 1.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
+        }
+        return;
+    }
     if constexpr (EPI == 2) {
         // accumulate over the resamples of the group: LDS [2][L][PLSX_ACC_PITCH] (the A stages are dead)
         const int L = se.accL;

@@ -901,16 +901,16 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 }
 
 // One launch of the rotation kernel for the chunk of L tiles [lt0, lt0 + LT).
-template <int LT, int NKS>
+template <int LT, int NKS, bool TAIL = false>
 int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
                 double* ps, double* pq, hipStream_t st)
 {
     const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
     // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
     const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
-    HIPCHK(set_lds(k_urot<LT, NKS>, lds));
+    HIPCHK(set_lds(k_urot<LT, NKS, TAIL>, lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
-    hipLaunchKernelGGL((k_urot<LT, NKS>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
                        ctx->L, lt0 * 16, usum, usq, out, rps, ps, pq);
     LAUNCHCHK();
@@ -959,9 +959,12 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     int rc = -1;
     // square case (L tiles follow from T'): k-step count compiled in, fragments of the
     // next resample prefetched
+    // the last tile of L on the 4x4x4 shape when it holds at most 4 live columns (see k_urot)
+    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !getenv("PLSX_UROT_NO_TAIL4");
     if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
-#define UCASE(N) case N: rc = launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;
+#define UCASE(N) case N: rc = tail4 ? launch_urot<(N + 3) / 4, N, true>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
+                                    : launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;
         UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
         UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
 #undef UCASE

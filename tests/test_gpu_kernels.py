@@ -234,16 +234,19 @@ def test_dual_perm_path_equals_feature_pass(case, rotate, monkeypatch):
 @pytest.mark.parametrize('shape', [(60, 4000, 13, [60], 1), (60, 2500, 10, [15, 15], 2), (64, 3001, 50, [64], 1),
                                    (40, 300, 6, [40], 1)])
 def test_bootstrap_kernel_variants_agree(shape, monkeypatch):
-    """The 4x4x4-MFMA Gram kernel vs the 16x16x4 one (PLSX_NO_GRAM4), and the
-    software-pipelined rotation kernel vs the generic one (PLSX_UROT_GENERIC):
+    """The 4x4x4-MFMA Gram kernel vs the 16x16x4 one (PLSX_NO_GRAM4), the
+    software-pipelined rotation kernel vs the generic one (PLSX_UROT_GENERIC, bit for bit when
+    both multiply the last tile of L on 16x16x4: PLSX_UROT_NO_TAIL4), and the rotation kernel
+    with that tile on the 4x4x4 shape (L mod 16 in 1..4: T' = 50, 20) vs without:
     same bootstraps, same sums."""
     from pypyls_amd import resampling as rsmp
     S, B, T, groups, n_cond = shape
     X, Y, rs = _data(S, B, T, seed=11)
     boots = rsmp.gen_bootsamp(groups, n_cond, 12, seed=4)
     got = {}
-    for key, env in (('default', {}), ('gram16', {'PLSX_NO_GRAM4': '1'}), ('urot_generic', {'PLSX_UROT_GENERIC': '1'})):
-        for k in ('PLSX_NO_GRAM4', 'PLSX_UROT_GENERIC'):
+    for key, env in (('default', {}), ('gram16', {'PLSX_NO_GRAM4': '1'}), ('urot_generic', {'PLSX_UROT_GENERIC': '1'}),
+                     ('no_tail4', {'PLSX_UROT_NO_TAIL4': '1'})):
+        for k in ('PLSX_NO_GRAM4', 'PLSX_UROT_GENERIC', 'PLSX_UROT_NO_TAIL4'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -253,8 +256,10 @@ def test_bootstrap_kernel_variants_agree(shape, monkeypatch):
         eng.set_original(U, np.diag(d), V)
         usum, usq, dist = eng.boot(boots)
         got[key] = (usum.cpu().numpy(), usq.cpu().numpy(), dist)
-    for a, b in zip(got['default'], got['urot_generic']):
+    for a, b in zip(got['no_tail4'], got['urot_generic']):
         assert np.array_equal(a, b)                       # same arithmetic, same order
+    for a, b in zip(got['default'], got['no_tail4']):
+        assert_close(a, b, 1e-12, what='4x4x4 tail tile vs 16x16x4')
     for a, b in zip(got['default'], got['gram16']):
         assert_close(a, b, 1e-9, what='gram4 vs gram16')
 

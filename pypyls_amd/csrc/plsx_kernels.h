@@ -1477,6 +1477,33 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
     C[(size_t)b * strideC + (size_t)mo * ldc + no] = s;
 }
 
+// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS round trip):
+// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies; row_half_mirror and
+// row_mirror pair the quads / halves of a 16-lane row, which is all a SUM needs once every
+// lane of a quad (half) already holds that quad's (half's) total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define SD_DPP_XOR1 0xB1
+#define SD_DPP_XOR2 0x4E
+#define SD_DPP_HALF_MIRROR 0x141
+#define SD_DPP_ROW_MIRROR 0x140
+
+__device__ __forceinline__ double sd_rsqrt(double x)
+{
+    // v_rsq_f64 (~2^-26 relative) + two Newton steps: full double precision
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+
 // ---------------------------------------------------------------------------
 // K4-K6: small dense solver, one block per resample.
 // ---------------------------------------------------------------------------
@@ -1610,16 +1637,19 @@ __device__ void jacobi_cols_reg(double* A, int m, double* V, int mv, int n, int 
                     const double xx = ok ? x[i] : 0.0, yy = ok ? y[i] : 0.0;
                     alpha += xx * xx; beta += yy * yy; gamma += xx * yy;
                 }
-#pragma unroll
-                for (int o = 1; o < LANES; o <<= 1) {
-                    alpha += __shfl_xor(alpha, o);
-                    beta += __shfl_xor(beta, o);
-                    gamma += __shfl_xor(gamma, o);
-                }
-                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                static_assert(LANES == 8, "group sums below: two quad butterflies + the half-row mirror");
+                alpha += dpp_f64<SD_DPP_XOR1>(alpha); beta += dpp_f64<SD_DPP_XOR1>(beta); gamma += dpp_f64<SD_DPP_XOR1>(gamma);
+                alpha += dpp_f64<SD_DPP_XOR2>(alpha); beta += dpp_f64<SD_DPP_XOR2>(beta); gamma += dpp_f64<SD_DPP_XOR2>(gamma);
+                alpha += dpp_f64<SD_DPP_HALF_MIRROR>(alpha); beta += dpp_f64<SD_DPP_HALF_MIRROR>(beta);
+                gamma += dpp_f64<SD_DPP_HALF_MIRROR>(gamma);
+                if (gamma == 0.0 || gamma * gamma <= (tol * tol) * (alpha * beta) || (alpha < null2 && beta < null2)) continue;
+                // the inner rotation from two reciprocal square roots (see wave_jacobi_cols in plsx_simpls.h)
+                const double dd = beta - alpha, gg = 2.0 * gamma;
+                const double rh = sd_rsqrt(__builtin_fma(dd, dd, gg * gg));
+                const double c2 = __builtin_fma(0.5 * fabs(dd), rh, 0.5);
+                const double rc = sd_rsqrt(c2);
+                const double c = c2 * rc;
+                const double sn = copysign(0.5 * fabs(gg) * rh * rc, dd >= 0.0 ? gg : -gg);
 #pragma unroll
                 for (int i = 0; i < IT; ++i)
                     if (sub + LANES * i < m) {

@@ -46,23 +46,6 @@
 #pragma once
 #include "plsx_kernels.h"
 
-// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS round trip):
-// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies; row_half_mirror and
-// row_mirror pair the quads / halves of a 16-lane row, which is all a SUM needs once every
-// lane of a quad (half) already holds that quad's (half's) total.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-#define SD_DPP_XOR1 0xB1
-#define SD_DPP_XOR2 0x4E
-#define SD_DPP_HALF_MIRROR 0x141
-#define SD_DPP_ROW_MIRROR 0x140
-
 __device__ __forceinline__ double wave_sum(double v)
 {
     v += dpp_f64<SD_DPP_XOR1>(v);
@@ -315,15 +298,6 @@ void k_sd_post0(SdArgs a)
 //     d = beta - alpha, g = 2 gamma, h = hypot(d, g):  cos 2t = |d| / h,
 //     c = sqrt((1 + |d| / h) / 2),  s = sign(d g) |g| / (2 h c)
 // -- the same inner rotation (|t| <= pi/4) as t = sign(z) / (|z| + sqrt(1 + z^2)), z = d / g.
-__device__ __forceinline__ double sd_rsqrt(double x)
-{
-    // v_rsq_f64 (~2^-26 relative) + two Newton steps: full double precision
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
-    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
-    return y;
-}
-
 template <int IT>
 __device__ void wave_jacobi_cols(double* A, int m, int n, int ld, int lane, double tol)
 {

@@ -993,12 +993,12 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
 }
 
 // Split-half feature-axis sums: same chunking of L.
-template <int LT, int NKS, class... Args>
+template <int LT, int NKS, bool TAIL = false, class... Args>
 int launch_ucorr_t(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, Args... args)
 {
     const size_t lds = NKS < 0 ? 0 : (size_t)ctx->nks_t * LT * 64 * 8;
-    HIPCHK(set_lds(k_ucorr_partial<LT, NKS>, lds));
-    hipLaunchKernelGGL((k_ucorr_partial<LT, NKS>), grid, block, lds, st, args...);
+    HIPCHK(set_lds(k_ucorr_partial<LT, NKS, TAIL>, lds));
+    hipLaunchKernelGGL((k_ucorr_partial<LT, NKS, TAIL>), grid, block, lds, st, args...);
     return 0;
 }
 
@@ -1022,9 +1022,12 @@ int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, const dou
     const int nks = ctx->nks_t, LT = ctx->LT, lpad = LT * 16;
     const double* R = ptr<double>(ctx->R);
     KTimer tm(ctx, KC_UCORR, st);
+    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !getenv("PLSX_UROT_NO_TAIL4");
     if (LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
-#define UCASE(N) case N: return launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
+#define UCASE(N) case N: return tail4 ? launch_ucorr_t<(N + 3) / 4, N, true>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
+                    nks, M, ctx->B, tpc, part, npairs, 0, lpad) \
+                                     : launch_ucorr_t<(N + 3) / 4, N>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
                     nks, M, ctx->B, tpc, part, npairs, 0, lpad);
         UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
         UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)

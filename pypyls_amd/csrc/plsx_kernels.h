@@ -50,6 +50,33 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
 // data preparation
 // ---------------------------------------------------------------------------
 
+// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS round trip):
+// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies; row_half_mirror and
+// row_mirror pair the quads / halves of a 16-lane row, which is all a SUM needs once every
+// lane of a quad (half) already holds that quad's (half's) total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+#define SD_DPP_XOR1 0xB1
+#define SD_DPP_XOR2 0x4E
+#define SD_DPP_HALF_MIRROR 0x141
+#define SD_DPP_ROW_MIRROR 0x140
+
+__device__ __forceinline__ double sd_rsqrt(double x)
+{
+    // v_rsq_f64 (~2^-26 relative) + two Newton steps: full double precision
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+    return y;
+}
+
+
 // Column means of X (S x B, ld = B) -> mean[B]; one thread per column, rows
 // summed in order (deterministic).
 __global__ void k_colmean(const double* __restrict__ X, int S, int B, double* __restrict__ mean)
@@ -661,7 +688,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const double m1 = acc[j][i], m2 = acc[NSQ + j][i];
                 const double nn = mom_n[pair];
                 const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);
-                se.scale[(size_t)pair * ldr + col] = (var > 0.0) ? 1.0 / sqrt(var) : 0.0;
+                se.scale[(size_t)pair * ldr + col] = (var > 0.0) ? sd_rsqrt(var) : 0.0;
             }
         return;
     }
@@ -1477,33 +1504,6 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
     C[(size_t)b * strideC + (size_t)mo * ldc + no] = s;
 }
 
-// Cross-lane moves on the DPP path (a few cycles) instead of ds_bpermute (an LDS round trip):
-// quad_perm [1,0,3,2] / [2,3,0,1] are the xor-1 / xor-2 butterflies; row_half_mirror and
-// row_mirror pair the quads / halves of a 16-lane row, which is all a SUM needs once every
-// lane of a quad (half) already holds that quad's (half's) total.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-#define SD_DPP_XOR1 0xB1
-#define SD_DPP_XOR2 0x4E
-#define SD_DPP_HALF_MIRROR 0x141
-#define SD_DPP_ROW_MIRROR 0x140
-
-__device__ __forceinline__ double sd_rsqrt(double x)
-{
-    // v_rsq_f64 (~2^-26 relative) + two Newton steps: full double precision
-    double y = __builtin_amdgcn_rsq(x);
-    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
-    y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
-    return y;
-}
-
-
 // ---------------------------------------------------------------------------
 // K4-K6: small dense solver, one block per resample.
 // ---------------------------------------------------------------------------
@@ -1536,60 +1536,6 @@ __device__ double jacobi_null2(const double* A, int m, int n, int ld, double* re
     const double r = *red;
     __syncthreads();
     return 1e-26 * r;
-}
-
-__device__ void jacobi_cols(double* A, int m, double* V, int mv, int n, int ld, int* flag, double tol)
-{
-    const int tid = threadIdx.x;
-    const int sub = tid & 7, grp = tid >> 3, ngrp = blockDim.x >> 3;
-    const int np = (n + 1) >> 1, ne = np * 2;
-    __shared__ double s_amax;
-    const double null2 = jacobi_null2(A, m, n, ld, &s_amax);
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        if (tid == 0) *flag = 0;
-        __syncthreads();
-        for (int step = 0; step < ne - 1; ++step) {
-            for (int pr = grp; pr < np; pr += ngrp) {
-                int p, q;
-                if (pr == 0) { p = step; q = ne - 1; }
-                else { p = (step + pr) % (ne - 1); q = (step + ne - 1 - pr) % (ne - 1); }
-                if (p > q) { int t = p; p = q; q = t; }
-                if (q >= n) continue;
-                double* ap = A + (size_t)p * ld;
-                double* aq = A + (size_t)q * ld;
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int i = sub; i < m; i += 8) {
-                    double x = ap[i], y = aq[i];
-                    alpha += x * x; beta += y * y; gamma += x * y;
-                }
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) {
-                    alpha += __shfl_xor(alpha, o);
-                    beta += __shfl_xor(beta, o);
-                    gamma += __shfl_xor(gamma, o);
-                }
-                if (gamma == 0.0 || fabs(gamma) <= tol * sqrt(alpha * beta) || (alpha < null2 && beta < null2)) continue;
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int i = sub; i < m; i += 8) {
-                    double x = ap[i], y = aq[i];
-                    ap[i] = c * x - s * y; aq[i] = s * x + c * y;
-                }
-                double* vp = V + (size_t)p * ld;
-                double* vq = V + (size_t)q * ld;
-                for (int i = sub; i < mv; i += 8) {
-                    double x = vp[i], y = vq[i];
-                    vp[i] = c * x - s * y; vq[i] = s * x + c * y;
-                }
-                if (sub == 0) *flag = 1;
-            }
-            __syncthreads();
-        }
-        const int any = *flag;
-        __syncthreads();
-        if (!any) break;
-    }
 }
 
 // Register-blocked pair update for work matrices in LDS: both columns of A and of V
@@ -2376,7 +2322,8 @@ __global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restr
 // LT = tiles of this launch's chunk of L, k0 = its first column, lpad = padded L
 // (row pitch of the partial sums).  NKS < 0: M read from global memory (too
 // large for LDS).
-template <int LT, int NKS>
+// TAIL (NKS > 0): the last tile of L holds <= 4 live columns and goes through the 4x4x4 shape, as in k_urot.
+template <int LT, int NKS, bool TAIL = false>
 __global__ __launch_bounds__(256)
 void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                      const double* __restrict__ Mfrag, int B, int tiles_per_chunk,
@@ -2424,20 +2371,36 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
             }
         };
         if (t0 + wave < t1) load_tile(t0 + wave, a1, a2);
+        constexpr int LF = TAIL ? LT - 1 : LT;
+        const int toff = (LT - 1) * 64 + (lane & 48) + (lane & 3) - lane;   // tail operand: lane -> 16 k + j of the last tile
         for (int tile = t0 + wave; tile < t1; tile += 4) {
             double n1[NKS], n2[NKS];
             load_tile(tile + 4, n1, n2);
             d4 e1[LT], e2[LT];
+            double e1t = 0.0, e2t = 0.0;
 #pragma unroll
             for (int l = 0; l < LT; ++l) { e1[l] = (d4){0, 0, 0, 0}; e2[l] = (d4){0, 0, 0, 0}; }
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
+            for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-                for (int l = 0; l < LT; ++l) {
+                for (int l = 0; l < LF; ++l) {
                     const double mv = sM[(ks * LT + l) * 64];
                     e1[l] = mfma_f64(a1[ks], mv, e1[l]);
                     e2[l] = mfma_f64(a2[ks], mv, e2[l]);
                 }
+                if constexpr (TAIL) {
+                    const double mt = sM[ks * LT * 64 + toff];
+                    e1t = mfma_f64_4x4(a1[ks], mt, e1t);
+                    e2t = mfma_f64_4x4(a2[ks], mt, e2t);
+                }
+            }
+            if constexpr (TAIL) {
+                // D[blk][i][j] in lane 16 i + 4 blk + j: feature tile * 16 + 4 blk + i, column 16 (LT - 1) + j;
+                // its sums ride in the last tile's scalars and are folded over (i, blk) below
+                const bool ok = (tile * 16 + 4 * ((lane >> 2) & 3) + (lane >> 4)) < B;
+                const double x = ok ? e1t : 0.0, y = ok ? e2t : 0.0;
+                s1[LT - 1] += x; s2[LT - 1] += y; s11[LT - 1] += x * x; s22[LT - 1] += y * y; s12[LT - 1] += x * y;
+            }
             accumulate(tile * 16, e1, e2);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) { a1[ks] = n1[ks]; a2[ks] = n2[ks]; }
@@ -2484,6 +2447,17 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
 #pragma unroll
             for (int u = 0; u < KP; ++u) { a1[u] = n1[u]; a2[u] = n2[u]; }
         }
+    }
+    if constexpr (TAIL && NKS > 0) {
+        // tail sums: fold the four feature groups (blk = lane bits 2..3); the row-group fold below does
+        // bits 4..5; lanes 0..3 then hold the columns 16 (LT - 1) + j, the tile's other columns are dead
+#pragma unroll
+        for (int o = 4; o < 16; o <<= 1) {
+            s1[LT - 1] += __shfl_xor(s1[LT - 1], o); s2[LT - 1] += __shfl_xor(s2[LT - 1], o);
+            s11[LT - 1] += __shfl_xor(s11[LT - 1], o); s22[LT - 1] += __shfl_xor(s22[LT - 1], o);
+            s12[LT - 1] += __shfl_xor(s12[LT - 1], o);
+        }
+        if ((lane & 15) >= 4) s1[LT - 1] = s2[LT - 1] = s11[LT - 1] = s22[LT - 1] = s12[LT - 1] = 0.0;
     }
     // reduce over the four row groups of the wave (lanes l, l+16, l+32, l+48)
 #pragma unroll

@@ -177,6 +177,7 @@ struct KTimer {
 };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Physical cross-product groups of `rgroups` resample groups.
@@ -246,7 +247,9 @@ int plan_groups(plsx_ctx* c)
     // covers the chip many times over and (b) the latency-bound small-solver
     // launch (one block per resample) has >= 2 blocks per CU to overlap.
     int g = round_up(std::max(1, ceil_div(2048, ncolblk)), 8);
-    g = std::max(g, round_up(ceil_div(512, std::max(best, 1)), 8));
+    // ... and (c) small shapes amortise their launches: 4096 resamples per super-batch where the budget
+    // allows (c2: 512 -> 4096 per batch, 1.72 M -> 1.91 M resamples/s; the headline shape is budget bound)
+    g = std::max(g, round_up(ceil_div(env_int("PLSX_MIN_BATCH", 4096), std::max(best, 1)), 8));
     g = std::min(std::max(g, 8), 128);
     const double budget = c->scratch_gb * 1073741824.0;
     while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);

@@ -548,7 +548,8 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
         const long long cost_a = (long long)groups * ctx->MT;
         const long long cost_b = (long long)ceil_div(nres, ctx->npg_d) * ctx->MTd +
                                  (long long)ceil_div(nres * ctx->J, PLSX_MOM_PAIRS) * 24;
-        ctx->sepmom_used = cost_b * 102 < cost_a * 100;
+        static const bool force_b = getenv("PLSX_SEPMOM_ALWAYS") != nullptr;     // tests: the layout at any launch size
+        ctx->sepmom_used = force_b || cost_b * 102 < cost_a * 100;
         if (ctx->sepmom_used)
             return run_xprod_sepmom(ctx, xsrc, ysrc, nres, st, ystack, ystride);
     }

@@ -286,3 +286,58 @@ def test_split_half_fused_equals_two_pass(shape, monkeypatch):
     for a, b in zip(got['fused'], got['two_pass']):
         for x, y in zip(a, b):
             assert_close(x, y, 1e-9, what='fused vs two-pass split-half')
+
+
+@pytest.mark.parametrize('shape', [(64, 3001, 50, [64], 1), (60, 2500, 10, [15, 15], 2), (90, 1300, 7, [10, 12, 8], 3)])
+def test_separate_moments_layout_equals_in_block(shape):
+    """Correlation mode: data-only cross-product blocks scaled from the table that moment-only blocks
+    write (k_xprod EPI 3 / 4; chosen per launch by tile passes, here forced: PLSX_SEPMOM_ALWAYS) against
+    in-block moment rows (PLSX_INBLOCK_MOMENTS) and the oracle -- R itself, bootstraps, and the two-pass
+    split-half route (masked resamples: rows with xsrc = -1).  Own processes: the switches are read once."""
+    import subprocess
+    import sys
+    import json
+    from conftest import ROOT
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from pypyls_amd import resampling as rsmp
+from pypyls_amd.engine import Engine
+S, B, T, groups, n_cond = %r
+rs = np.random.RandomState(3)
+X = rs.randn(S, B) * (0.5 + rs.rand(1, B)); Y = rs.randn(S, T) + 0.4 * X[:, :T]
+eng = Engine()
+eng.set_data(X, Y, rsmp.cell_of_row(groups, n_cond), len(groups), n_cond, 0)
+boots = rsmp.gen_bootsamp(groups, n_cond, 45, seed=4)
+R = eng.crosscov(xsrc=boots, ysrc=boots)
+xw, sv, yw = eng.decompose()
+eng.set_original(xw, sv, yw)
+usum, usq, dist = eng.boot(boots)
+masks = rsmp.gen_splits(groups, n_cond, 6, seed=9)
+uc, vc = eng.split_half(masks)
+np.savez(sys.argv[1], R=R, usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist, uc=uc, vc=vc, sv=sv)
+""" % (ROOT, shape)
+    import os
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for key, env in (('sep', {'PLSX_SEPMOM_ALWAYS': '1', 'PLSX_NO_SPLIT_FUSE': '1'}),
+                         ('inblock', {'PLSX_INBLOCK_MOMENTS': '1', 'PLSX_NO_SPLIT_FUSE': '1'})):
+            path = os.path.join(tmp, key + '.npz')
+            proc = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env),
+                                  capture_output=True, text=True, timeout=600)
+            assert proc.returncode == 0, proc.stderr[-2000:]
+            out[key] = dict(np.load(path))
+    for k in ('R', 'sv', 'usum', 'usq', 'dist', 'uc', 'vc'):
+        assert_close(out['sep'][k], out['inblock'][k], 1e-11, what='separate vs in-block moments: ' + k)
+    # and R against the oracle
+    from pypyls_amd import resampling as rsmp
+    S, B, T, groups, n_cond = shape
+    rs = np.random.RandomState(3)
+    X = rs.randn(S, B) * (0.5 + rs.rand(1, B))
+    Y = rs.randn(S, T) + 0.4 * X[:, :T]
+    boots = rsmp.gen_bootsamp(groups, n_cond, 45, seed=4)
+    spec = ref.Spec('behavioral', groups, n_cond)
+    for i in (0, 17, 44):
+        want = ref.gen_covcorr(spec, X[boots[:, i]], Y[boots[:, i]], spec.dummy)
+        assert_close(out['sep']['R'][i], want, 1e-10, what='separate-moments R vs oracle')

@@ -616,9 +616,11 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
            const double* B1, long long strideB1, int ldb1, int N1,
            const double* B2, long long strideB2, int ldb2, int N2, int K, int batch,
            double* C1, long long strideC1, int ldc1, double* C2, long long strideC2, int ldc2,
-           hipStream_t st)
+           hipStream_t st, bool sym = false)
 {
+    // sym: B1 is A itself (K = X X^T): only the blocks on and above the diagonal are multiplied
     NtArgs a;
+    a.sym = (sym && !B2 && A == B1 && Ma == N1) ? 1 : 0;
     a.A = A; a.strideA = strideA; a.lda = lda; a.Ma = Ma;
     a.B1 = B1; a.strideB1 = strideB1; a.ldb1 = ldb1; a.N1 = N1;
     a.B2 = B2; a.strideB2 = strideB2; a.ldb2 = ldb2; a.N2 = N2;
@@ -644,7 +646,7 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     {
         dim3 g(ceil_div(Ma * N1, 256), batch);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,
-                           a.ntiles, 0, C1, strideC1, ldc1, Ma, N1, 0);
+                           a.ntiles, 0, C1, strideC1, ldc1, Ma, N1, a.sym ? 6 : 0);
         LAUNCHCHK();
     }
     if (B2) {
@@ -1276,7 +1278,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
         // K = Xc Xc^T (S x S): the only B-sized work the dual-space SIMPLS solver needs
         if (int e = ensure(ctx, ctx->Kmat, (size_t)S * S * 8)) return e;
         if (int e = run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, S, ptr<double>(ctx->Xc), 0, ctx->Bpad, S,
-                           nullptr, 0, 0, 0, B, 1, ptr<double>(ctx->Kmat), 0, S, nullptr, 0, 0, st))
+                           nullptr, 0, 0, 0, B, 1, ptr<double>(ctx->Kmat), 0, S, nullptr, 0, 0, st, true))
             return e;
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -1422,7 +1424,7 @@ int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, 
         if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
         const double* Xf = ctx->has_Xn ? ptr<double>(ctx->Xn) : ptr<double>(ctx->Xc);
         if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
-                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
+                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st, true))
             return e;
         ctx->has_Kd = 1;
     }
@@ -1520,7 +1522,7 @@ int boot_single_pass(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_
         if (int e = ensure(ctx, ctx->Kd, (size_t)S * Sd * 8, true)) return e;
         const double* Xf = ptr<double>(ctx->Xc);
         if (int e = run_nt(ctx, Xf, 0, ctx->Bpad, S, Xf, 0, ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, 1,
-                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st))
+                           ptr<double>(ctx->Kd), 0, Sd, nullptr, 0, 0, st, true))
             return e;
         ctx->has_Kd = 1;
     }

@@ -897,6 +897,7 @@ struct NtArgs {
     int mtiles, ntiles;  // 64-tiles of the output
     double* part;     // [nchunk][batch][2][mtiles*ntiles][64*64]
     int batch;
+    int sym;          // 1: A == B1 (C symmetric): blocks wholly below the diagonal are skipped, k_reduce_part mirrors
 };
 
 // RM = 64-row output tiles per block (1 or 2).  With RM = 2 a wave owns 32 rows x 64 columns: two
@@ -915,6 +916,7 @@ void k_nt_gemm(NtArgs a)
     const int b = blockIdx.z;
     // blockIdx.y enumerates (block row, column tile); a block row is RM tile rows
     const int tmb = blockIdx.y / a.ntiles, tn = blockIdx.y % a.ntiles;
+    if (a.sym && tmb * RM > tn) return;           // every tile row of the block lies below the diagonal
     const bool two = RM == 1 && (a.B2 != nullptr);
     const int k0 = chunk * a.kchunk;
     const int k1 = min(a.K, k0 + a.kchunk);

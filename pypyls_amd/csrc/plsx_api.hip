@@ -42,6 +42,8 @@ struct plsx_ctx {
     int sepmom = 0, MTd = 0, npg_d = 0, sepmom_used = 0;
     size_t group_stride_d = 0;
     Buf out_row_d, mom_idx_d, Afrag_m, momn_m, scale;
+    Buf Afrag_c, rank_c, rowtab_c, m1_c, m2_c, out_row_c, mom_idx_c;     // compact split-half (one split per block)
+    int has_compact_maps = 0;
     size_t group_stride = 0;
     // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
     int gps = 0;
@@ -1113,7 +1115,8 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Rfull, &ctx->Vp, &ctx->dp, &ctx->Mvd, &ctx->Cm, &ctx->srcx, &ctx->srcy, &ctx->part2,
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
-                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale})
+                   &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
+                   &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1180,6 +1183,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     ctx->has_data = ctx->has_orig = false;
     ctx->has_Kd = 0;
     ctx->npg_w = 0;                                    // the row -> LV map of the accumulating epilogue follows L
+    ctx->has_compact_maps = 0;
     // a re-bound context keeps its scratch: the padding rows (t >= T') of every R slot must
     // read as zero under the new layout too
     if (ctx->R.p) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
@@ -1689,11 +1693,128 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
     return 0;
 }
 
+// Compact fused split-half (T' <= 64): ONE split per cross-product block, contracting over the rows of its
+// first half only (the fused epilogue derives the second half from the full-sample cross-product, so the
+// zeros that the 7-splits-per-block layout multiplies for the other half are half of its MFMA work: seven
+// random halves cover every subject between them, a block of its own covers S / 2).  Data blocks of
+// ceil(T'/16) tiles with KT k-steps per LDS stage (24 tile-steps per barrier, as in the big blocks), X rows
+// through a per-split row table (k_xprod IDX), first-half feature moments from moment-only blocks over all
+// (split, cell) pairs of the pass (full K: 16 tile-steps per split).  432 -> 272 tile-steps per split at
+// the headline shape; the price is one pass over half of X per split (0.4 GB): the leg turns HBM bound.
+template <int MT, int KT>
+int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st)
+{
+    constexpr int NW = 4;
+    const int J = ctx->J;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128;          // doubles, both stages
+    const size_t tab = (size_t)(nks_c * 4 + 1) / 2;                                       // row table behind the stages
+    const size_t epi0 = (size_t)5 * J * NW * 16 + (size_t)MT * 16;                        // w5 + row maps (ints, 2 per double)
+    const size_t pre0 = round_up((int)std::max(stage + tab, epi0), 128);
+    const size_t rcpad = (size_t)((MT * 16 * 5 + 127) / 128) * 128;
+    const size_t pre_total = pre0 + (size_t)ctx->Tpp * NW * 16 + rcpad;
+    se.off_pre = (getenv("PLSX_SPLIT_PRE") && pre_total * 8 <= 80 * 1024) ? (int)pre0 : 0;
+    const size_t lds = se.off_pre ? pre_total * 8 : std::max(stage + tab, epi0 + rcpad) * 8;
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 5, true>, lds));
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 5, true>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(NW * 64), lds, st,
+                       ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
+                       ptr<double>(ctx->R), ctx->Bpad, 2 * ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
+                       ptr<double>(ctx->momn_m), 0, m, ncolblk, (double*)nullptr, se, 1);
+    LAUNCHCHK();
+    return 0;
+}
+
+int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
+                      hipStream_t st, const double* Yarr)
+{
+    const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = 24 / (MTc == 3 ? 3 : MTc), rows = MTc * 16;
+    if (!ctx->has_cellS) {
+        if (int e = ensure(ctx, ctx->cellS, (size_t)2 * J * ctx->Bpad * 8, true)) return e;
+        hipLaunchKernelGGL(k_cell_moments, dim3(ceil_div(ctx->B, 256)), dim3(256), 0, st, ptr<double>(ctx->Xc),
+                           ctx->Bpad, ctx->B, J, ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len),
+                           ptr<double>(ctx->cellS), ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad);
+        LAUNCHCHK();
+        ctx->has_cellS = 2;                             // (the 7-per-block row map of run_split_fused is not uploaded)
+    }
+    if (!ctx->has_compact_maps) {
+        std::vector<int> orow(rows, -1), mrow(rows, -1);
+        for (int t = 0; t < ctx->Tp; ++t) { orow[t] = t; mrow[t] = t / ctx->T; }
+        if (int e = ensure(ctx, ctx->out_row_c, rows * sizeof(int))) return e;
+        if (int e = ensure(ctx, ctx->mom_idx_c, rows * sizeof(int))) return e;
+        HIPCHK(hipMemcpy(ctx->out_row_c.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->mom_idx_c.p, mrow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+        ctx->has_compact_maps = 1;
+    }
+    // the tables are sized for a first half of all S rows; a block contracts over its own count
+    const int nks_c = round_up(ceil_div(S, 4), KT);
+    const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;
+    const int npairs = m * J, groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
+    if (int e = ensure_scratch(ctx, std::min(ctx->Gcap, ceil_div(2 * m, ctx->npg)))) return e;
+    if ((size_t)2 * m * ctx->strideR * 8 > ctx->R.bytes) return fail(ctx, PLSX_ERR_STATE, "compact split: R scratch too small");
+    if (int e = ensure(ctx, ctx->Afrag_c, (size_t)m * astride * 8 + 4096)) return e;
+    if (int e = ensure(ctx, ctx->rank_c, (size_t)m * S * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->rowtab_c, ((size_t)m * nks_c * 4 + m) * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->Afrag_m, (size_t)groups_m * mstride * 8 + 4096)) return e;
+    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, PLSX_MOM_PAIRS) * 8)) return e;
+    if (int e = ensure(ctx, ctx->m1_c, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
+    if (int e = ensure(ctx, ctx->m2_c, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
+    if (int e = ensure(ctx, ctx->rowc, ((size_t)m * rows * 5 + 256) * 8)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag_c.p, 0, (size_t)m * astride * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->Afrag_m.p, 0, (size_t)groups_m * mstride * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->rowc.p, 0, ((size_t)m * rows * 5 + 256) * 8, st));
+    {
+        KTimer tm(ctx, KC_BUILD, st);
+        hipLaunchKernelGGL(k_split_rank, dim3(m), dim3(64), 0, st, masks, S, nks_c * 4, ptr<int>(ctx->rank_c),
+                           ptr<int>(ctx->rowtab_c), ptr<int>(ctx->rowtab_c) + (size_t)m * nks_c * 4);
+        LAUNCHCHK();
+        GroupLayout lay;
+        lay.n = 1; lay.Tp = ctx->Tp; lay.J = J; lay.T = ctx->T; lay.MT = MTc; lay.w0 = MTc; lay.sq0 = MTc; lay.Tpp = ctx->Tpp;
+        hipLaunchKernelGGL(k_build_A_split, dim3(m, J), dim3(256), 0, st, Yarr ? Yarr : ptr<double>(ctx->Y), ctx->T, S,
+                           ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), perm, masks, lay,
+                           ptr<double>(ctx->Afrag_c), astride, ptr<double>(ctx->momn_m), 0, ptr<double>(ctx->rowc),
+                           ptr<int>(ctx->rank_c), ptr<double>(ctx->Afrag_m), mstride);
+        LAUNCHCHK();
+    }
+    SplitEpi se;
+    memset(&se, 0, sizeof(se));
+    se.scale = ptr<double>(ctx->m1_c); se.scale2 = ptr<double>(ctx->m2_c);
+    {
+        constexpr int NW = 4;
+        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
+        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 6>, lds));
+        const int ncolblk = ctx->Bpad / (NW * 16);
+        se.npairs = npairs;
+        KTimer tm(ctx, KC_MOM, st);
+        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 6>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                           (const double*)nullptr, 0, groups_m, ncolblk, (double*)nullptr, se, 1);
+        LAUNCHCHK();
+    }
+    se.Rfull = Rfull;
+    se.cellS1 = ptr<double>(ctx->cellS);
+    se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
+    se.cell_len = ptr<int>(ctx->cell_len);
+    se.rowc = ptr<double>(ctx->rowc);
+    se.J = J; se.Tpp = ctx->Tpp;
+    se.row_tab = ptr<int>(ctx->rowtab_c);
+    se.row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)m * nks_c * 4;
+    switch (MTc) {
+        case 1: return launch_xprod_compact<1, 24>(ctx, m, nks_c, se, st);
+        case 2: return launch_xprod_compact<2, 12>(ctx, m, nks_c, se, st);
+        case 3: return launch_xprod_compact<3, 8>(ctx, m, nks_c, se, st);
+        default: return launch_xprod_compact<4, 6>(ctx, m, nks_c, se, st);
+    }
+}
+
 int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
                     hipStream_t st, const double* Yarr)
 {
+    if (ctx->Tp <= 64 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) && !getenv("PLSX_SPLIT_INBLOCK"))
+        return run_split_compact(ctx, perm, masks, m, Rfull, st, Yarr);
     const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
-    if (!ctx->has_cellS) {
+    if (ctx->has_cellS != 1) {
         if (int e = ensure(ctx, ctx->cellS, (size_t)2 * J * ctx->Bpad * 8, true)) return e;
         hipLaunchKernelGGL(k_cell_moments, dim3(ceil_div(ctx->B, 256)), dim3(256), 0, st, ptr<double>(ctx->Xc),
                            ctx->Bpad, ctx->B, J, ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len),

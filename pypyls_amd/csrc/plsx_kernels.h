@@ -404,6 +404,12 @@ struct SplitEpi {
     double* scale;
     int npairs;              // EPI 4: pairs of the launch;  EPI 3: pairs per data group (resamples x cells);
                              // EPI 3 also takes accB = R rows of the launch (resamples x Tpp)
+    // compact split-half (EPI 5 data blocks / EPI 6 moment blocks, IDX row table): raw first-half
+    // moments m1 = scale, m2 = scale2 of every (split, cell) pair and column; row_tab[group][nks * 4]
+    // = the X row behind compact contraction index k (the rows of the first half, padded with row 0)
+    double* scale2;
+    const int* row_tab;
+    const int* row_cnt;      // [group]: rows of the first half (the block's own contraction length)
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
@@ -412,8 +418,13 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
                      const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                      const int* __restrict__ perm, const uint8_t* __restrict__ masks,
                      GroupLayout lay, double* __restrict__ Afrag, size_t group_stride,
-                     double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc)
+                     double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc,
+                     const int* __restrict__ rank = nullptr, double* __restrict__ Amom = nullptr,
+                     size_t mom_stride = 0)
 {
+    // rank != nullptr (compact layout, one split per group): the contraction index of position p is
+    // its rank among the split's first-half rows (k_split_rank), and the weight rows of pair
+    // (split, cell) go to the moment-only groups of Amom at the subject index (full K).
     const int i = blockIdx.x, j = blockIdx.y;
     const int g = i / lay.n, rr = i % lay.n;
     const int start = cell_start[j], len = cell_len[j];
@@ -479,8 +490,22 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
             const double mF = s_mean[tl];
             const int row = rr * lay.Tp + j * T + t;
             for (int p = p0; p < p1; ++p)
-                if (mk[p]) A[afrag_off(row, p, lay.MT)] = Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
+                if (mk[p]) A[afrag_off(row, rank ? rank[(size_t)i * S + p] : p, lay.MT)] =
+                               Y[(size_t)(perm ? perm[p] : p) * T + t] - mF;
         }
+    }
+    if (rank) {
+        const int pair = i * lay.J + j;
+        double* Am = Amom + (size_t)(pair / PLSX_MOM_PAIRS) * mom_stride;
+        const int mrow = pair % PLSX_MOM_PAIRS;
+        for (int pl = tid; pl < len; pl += blockDim.x) {
+            const int p = start + pl;
+            if (!mk[p]) continue;
+            Am[afrag_off(mrow, p, 24)] = 1.0;
+            Am[afrag_off(PLSX_MOM_PAIRS + mrow, p, 24)] = 1.0;
+        }
+        if (tid == 0) mom_n[pair] = (double)s_n1;
+        return;
     }
     const int mrow = rr * lay.J + j;
     for (int pl = tid; pl < len; pl += blockDim.x) {
@@ -490,6 +515,31 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
         A[afrag_off(lay.sq0 * 16 + mrow, p, lay.MT)] = 1.0;
     }
     if (tid == 0) mom_n[(size_t)g * nmom_pad + mrow] = (double)s_n1;
+}
+
+// Compact split-half: rank[split][p] = number of first-half positions before p (the contraction
+// index of position p in the split's own cross-product block), row_tab[split][k] = the position of
+// rank k (the X row that block loads at contraction index k; padding entries -> row 0, whose A
+// column is zero).  grid (n_splits), block 64.
+__global__ void k_split_rank(const uint8_t* __restrict__ masks, int S, int ktot,
+                             int* __restrict__ rank, int* __restrict__ row_tab, int* __restrict__ row_cnt)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const uint8_t* mk = masks + (size_t)i * S;
+    int* rk = rank + (size_t)i * S;
+    int* rt = row_tab + (size_t)i * ktot;
+    int base = 0;
+    for (int p0 = 0; p0 < S; p0 += 64) {
+        const int p = p0 + lane;
+        const bool on = p < S && mk[p] != 0;
+        const unsigned long long bal = __ballot(on);
+        const int r = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (p < S) rk[p] = r;
+        if (on) rt[r] = p;
+        base += __popcll(bal);
+    }
+    for (int k = base + lane; k < ktot; k += 64) rt[k] = 0;
+    if (lane == 0) row_cnt[i] = base;
 }
 
 // ---------------------------------------------------------------------------
@@ -556,8 +606,12 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 //     Correlation mode with in-block moments spends 2 of 24 tiles on 7 + 7 moment rows; here the
 //     moments of 192 (resample, cell) pairs fill a block and the data blocks carry data only.
 #define PLSX_ACC_PITCH 80        // LDS pitch of an l-row (64 columns + 16: rows l, l+1 of one MFMA register land in different banks)
-template <int MT, int NW, int KT, int NSQ, int EPI = 0>
-__global__ __launch_bounds__(NW * 64, 2)
+// 5 = fused split-half on COMPACT blocks (one split per group, contraction over the rows of its first half
+//     only: IDX row table), first-half moments from the tables the EPI 6 moment blocks write,
+// 6 = moment-only block writing the raw moments m1, m2 (se.scale, se.scale2).
+// IDX: the X row behind contraction index k comes from se.row_tab (loaded to LDS once per block).
+template <int MT, int NW, int KT, int NSQ, int EPI = 0, bool IDX = false>
+__global__ __launch_bounds__(NW * 64, IDX ? 4 : 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
              double* __restrict__ R, int ldr, int rows_per_group,
@@ -582,11 +636,21 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // A last, partial sweep (n_groups % 8 = rem groups) would leave 8 - rem XCDs
     // idle: its rem * ncolblk tiles are dealt out as eight contiguous ranges
     // instead, one per XCD (each XCD then touches at most two groups' A).
-    const int sweep = blockIdx.x / (8 * ncolblk);
-    const int within = blockIdx.x - sweep * (8 * ncolblk);
+    // IDX (compact split-half, one split per group): every group reads its OWN half of the rows of X, so
+    // the groups of a column block share its rows only through L2 -- the 8 groups of a sweep go to ONE
+    // XCD per column block (slots s, s+1, .. of XCD x: groups 0..7 of column block (s / 8) * 8 + x), their
+    // sorted row lists advance together and each row of the column block comes from HBM once per sweep.
+    const int ncb = IDX ? ((ncolblk + 7) & ~7) : ncolblk;
+    const int sweep = blockIdx.x / (8 * ncb);
+    const int within = blockIdx.x - sweep * (8 * ncb);
     int grp = sweep * 8 + (within & 7);
     int colblk = within >> 3;
-    if (sweep * 8 + 8 > n_groups) {
+    if constexpr (IDX) {
+        const int slot = within >> 3;
+        grp = sweep * 8 + (slot & 7);
+        colblk = (slot >> 3) * 8 + (within & 7);
+        if (grp >= n_groups || colblk >= ncolblk) return;
+    } else if (sweep * 8 + 8 > n_groups) {
         const int rem = n_groups - sweep * 8;
         const int cnt = (rem * ncolblk + 7) >> 3;
         const int id = (within & 7) * cnt + colblk;
@@ -605,8 +669,19 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int nkt = nks / KT;
-    constexpr bool SPLIT = (EPI == 1);
+    // (compact blocks contract over their own first half: any mask is legal, the table is sized for S rows)
+    const int nkt = IDX ? max(1, (se.row_cnt[grp] + 4 * KT - 1) / (4 * KT)) : nks / KT;
+    constexpr bool SPLIT = (EPI == 1 || EPI == 5);
+    int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE_LDS);       // IDX: [nks * 4] X rows of this group
+    if constexpr (IDX) {
+        for (int i = tid; i < nks * 4; i += NT) s_tab[i] = se.row_tab[(size_t)grp * nks * 4 + i];
+        __syncthreads();
+    }
+    // byte offset of this lane's X element at contraction step k (k-step granularity: 4 rows)
+    auto x_off = [&](int kstep) -> int {
+        if constexpr (IDX) return (s_tab[kstep * 4 + kq] * ldx + col) * 8;
+        else return 0;
+    };
     if constexpr (SPLIT) {
         // Fused split-half: the epilogue needs this block's (Tpp x 64) tile of the
         // arrangement's full-sample R and the group's row constants.  Fetched here by
@@ -625,7 +700,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                     rsF, (__attribute__((address_space(3))) void*)(sRf + j * 128), 16, vo, j * 2 * ldr * 8, 0, 0);
             __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(se.rowc + (size_t)grp * MT * 16 * 5), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
-            for (int pc = swave; pc < MT * 16 * 5 / 128; pc += NW)
+            for (int pc = swave; pc < (MT * 16 * 5 + 127) / 128; pc += NW)     // (whole 1 KB pieces: rowc carries slack)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rsC, (__attribute__((address_space(3))) void*)(sRc + pc * 128), 16, lane * 16, pc * 1024, 0, 0);
         }
@@ -634,7 +709,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
     double xb[KT];
 #pragma unroll
-    for (int s = 0; s < KT; ++s) xb[s] = load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
+    for (int s = 0; s < KT; ++s)
+        xb[s] = IDX ? load_x_buf(X, x_off(s)) : load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
     // Force the first X fragments to be resident before the loop: a load still
     // pending at the loop header makes hipcc place a near-draining
     // s_waitcnt vmcnt(1) right after the next stage's loads are issued.
@@ -653,7 +729,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         // the barrier that ended the previous pass.
         stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid, swave);
 #pragma unroll
-        for (int s = 0; s < KT; ++s) xn[s] = load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
+        for (int s = 0; s < KT; ++s)
+            xn[s] = IDX ? load_x_buf(X, x_off(kn * KT + s)) : load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
@@ -674,6 +751,96 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // tile W0+j holds m1 of moment row j*16 + kq + 4*i and the same lane / reg
     // of tile SQ0+j holds m2 of that row.  The A stages are dead: reuse LDS.
     constexpr int W0 = MT - 2 * NSQ, SQ0 = MT - NSQ, NMOM = NSQ * 16;
+    if constexpr (EPI == 6) {
+        // moment-only block writing the RAW first / second moments of its pairs (compact split-half)
+        static_assert(MT == 2 * NSQ, "EPI 6 is a moment-only instantiation");
+#pragma unroll
+        for (int j = 0; j < NSQ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pair = grp * (NSQ * 16) + j * 16 + kq + 4 * i;
+                if (pair >= se.npairs) continue;
+                se.scale[(size_t)pair * ldr + col] = acc[j][i];
+                se.scale2[(size_t)pair * ldr + col] = acc[NSQ + j][i];
+            }
+        return;
+    }
+    if constexpr (EPI == 5) {
+        // fused split-half of ONE split (compact block): both halves from the first half's raw sums as in
+        // EPI 1, the first half's feature moments from the tables.  LDS: w5 [5][J][64], row maps, and
+        // (prefetched by DMA at kernel start) the tile of Rfull and the row constants.
+        const int J = se.J;
+        const bool pre = se.off_pre > 0 && NW == 4;
+        double* w5 = smem;                                        // u1, v1, u2, v2, sF : [5][J][64]
+        int* s_out = reinterpret_cast<int*>(smem + 5 * J * (NW * 16));
+        int* s_mom = s_out + MT * 16;
+        const double* sRf = smem + se.off_pre;
+        double* s_rc = pre ? smem + se.off_pre + se.Tpp * (NW * 16)
+                           : reinterpret_cast<double*>(s_mom + MT * 16);
+        const int pitch2 = 2 * se.Tpp;
+        for (int i = tid; i < MT * 16; i += NT) {
+            const int orw = out_row[i];
+            s_out[i] = orw < 0 ? -1 : (orw | ((orw % pitch2) << 20));
+            s_mom[i] = mom_idx[i];
+        }
+        if (!pre)
+            for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
+        const int cb0 = colblk * (NW * 16);
+        for (int idx = tid; idx < J * (NW * 16); idx += NT) {
+            const int jc = idx / (NW * 16), c = idx - jc * (NW * 16);
+            const size_t pair = (size_t)grp * J + jc;
+            const double n1 = mom_n[pair];
+            const double m1 = se.scale[pair * ldr + cb0 + c], m2 = se.scale2[pair * ldr + cb0 + c];
+            const double nF = (double)se.cell_len[jc];
+            const double SF = se.cellS1[(size_t)jc * ldr + cb0 + c], SFF = se.cellS2[(size_t)jc * ldr + cb0 + c];
+            const double n2 = nF - n1;
+            const bool ok = n1 > 1.5 && n2 > 1.5;
+            const double var1 = ok ? (m2 - m1 * m1 / n1) / (n1 - 1.0) : 0.0;
+            const double s2x = SF - m1, s2xx = SFF - m2;
+            const double var2 = ok ? (s2xx - s2x * s2x / n2) / (n2 - 1.0) : 0.0;
+            const double varF = (SFF - SF * SF / nF) / (nF - 1.0);
+            const int o = jc * (NW * 16) + c;
+            w5[0 * J * (NW * 16) + o] = ok ? m1 / n1 : 0.0;
+            w5[1 * J * (NW * 16) + o] = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
+            w5[2 * J * (NW * 16) + o] = ok ? s2x / n2 : 0.0;
+            w5[3 * J * (NW * 16) + o] = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
+            w5[4 * J * (NW * 16) + o] = (varF > 0.0) ? sqrt(varF) : 0.0;
+        }
+        __syncthreads();
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+        const int cw = wave * 16 + (lane & 15), JW = J * (NW * 16);
+        // without the LDS prefetch (more blocks per CU) the tile of Rfull comes from L2, every load
+        // issued before the first store (loads and stores share vmcnt)
+        double rfv[MT][4];
+        if (!pre) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int packed = s_out[m * 16 + kq + 4 * i];
+                    rfv[m][i] = packed < 0 ? 0.0 : se.Rfull[(size_t)(packed >> 20) * ldr + col];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m * 16 + kq + 4 * i;
+                const int packed = s_out[row];
+                if (packed < 0) continue;
+                const int orow = packed & 0xfffff, t = packed >> 20;
+                const int o = s_mom[row] * (NW * 16) + cw;
+                const double* rc = s_rc + row * 5;
+                const double c1 = acc[m][i];
+                const double rf = pre ? sRf[t * (NW * 16) + cw] : rfv[m][i];
+                const double cf = rf * rc[4] * w5[4 * JW + o];
+                const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * JW + o];
+                const double r2 = ((cf - c1) - rc[2] * w5[2 * JW + o]) * rc[3] * w5[3 * JW + o];
+                __builtin_nontemporal_store(r1, &Rg[(size_t)orow * ldr]);
+                __builtin_nontemporal_store(r2, &Rg[(size_t)(orow + se.Tpp) * ldr]);
+            }
+        return;
+    }
     if constexpr (EPI == 4) {
         // moment-only block (W0 = 0): tile j holds the first moments of pairs j * 16 .. + 15, tile
         // NSQ + j their second moments; 1 / std (ddof 1) of the resampled feature inside the cell

@@ -1701,7 +1701,7 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
 // through a per-split row table (k_xprod IDX), first-half feature moments from moment-only blocks over all
 // (split, cell) pairs of the pass (full K: 16 tile-steps per split).  432 -> 272 tile-steps per split at
 // the headline shape; the price is one pass over half of X per split (0.4 GB): the leg turns HBM bound.
-template <int MT, int KT>
+template <int MT, int KT, bool TAIL = false>
 int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st)
 {
     constexpr int NW = 4;
@@ -1714,10 +1714,10 @@ int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream
     const size_t pre_total = pre0 + (size_t)ctx->Tpp * NW * 16 + rcpad;
     se.off_pre = (getenv("PLSX_SPLIT_PRE") && pre_total * 8 <= 80 * 1024) ? (int)pre0 : 0;
     const size_t lds = se.off_pre ? pre_total * 8 : std::max(stage + tab, epi0 + rcpad) * 8;
-    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 5, true>, lds));
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 5, true, TAIL>, lds));
     const int ncolblk = ctx->Bpad / (NW * 16);
     KTimer tm(ctx, KC_XPROD, st);
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 5, true>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(NW * 64), lds, st,
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 5, true, TAIL>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(NW * 64), lds, st,
                        ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
                        ptr<double>(ctx->R), ctx->Bpad, 2 * ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
                        ptr<double>(ctx->momn_m), 0, m, ncolblk, (double*)nullptr, se, 1);
@@ -1800,11 +1800,16 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     se.J = J; se.Tpp = ctx->Tpp;
     se.row_tab = ptr<int>(ctx->rowtab_c);
     se.row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)m * nks_c * 4;
+    // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
+    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !getenv("PLSX_SPLIT_NO_TAIL4");
     switch (MTc) {
         case 1: return launch_xprod_compact<1, 24>(ctx, m, nks_c, se, st);
-        case 2: return launch_xprod_compact<2, 12>(ctx, m, nks_c, se, st);
-        case 3: return launch_xprod_compact<3, 8>(ctx, m, nks_c, se, st);
-        default: return launch_xprod_compact<4, 6>(ctx, m, nks_c, se, st);
+        case 2: return tail ? launch_xprod_compact<2, 12, true>(ctx, m, nks_c, se, st)
+                            : launch_xprod_compact<2, 12>(ctx, m, nks_c, se, st);
+        case 3: return tail ? launch_xprod_compact<3, 8, true>(ctx, m, nks_c, se, st)
+                            : launch_xprod_compact<3, 8>(ctx, m, nks_c, se, st);
+        default: return tail ? launch_xprod_compact<4, 6, true>(ctx, m, nks_c, se, st)
+                             : launch_xprod_compact<4, 6>(ctx, m, nks_c, se, st);
     }
 }
 

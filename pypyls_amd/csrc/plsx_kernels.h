@@ -46,6 +46,12 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// four independent 4x4x4 products: A lane 16 k + 4 blk + i, B lane 16 k + 4 blk + j, D lane 16 i + 4 blk + j
+__device__ __forceinline__ double mfma_f64_4x4(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------
 // data preparation
 // ---------------------------------------------------------------------------
@@ -610,7 +616,10 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 //     only: IDX row table), first-half moments from the tables the EPI 6 moment blocks write,
 // 6 = moment-only block writing the raw moments m1, m2 (se.scale, se.scale2).
 // IDX: the X row behind contraction index k comes from se.row_tab (loaded to LDS once per block).
-template <int MT, int NW, int KT, int NSQ, int EPI = 0, bool IDX = false>
+// TAIL (EPI 5): the last data tile holds <= 4 live rows and goes through the 4x4x4 shape (16 instead of 64
+// matrix-pipe cycles; A = the tile's rows 0..3 for every block, B = the X fragment as it is, the result lands
+// where register 0 of the 16x16 tile would).
+template <int MT, int NW, int KT, int NSQ, int EPI = 0, bool IDX = false, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, IDX ? 4 : 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
@@ -668,6 +677,9 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     d4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
+    double acct = 0.0;
+    const int toff = (lane & 48) + (lane & 3) - lane;     // TAIL: lane 16 k + 4 blk + i -> fragment position 16 k + i
+    static_assert(!TAIL || (EPI == 5 && NSQ == 0), "the 4x4x4 tail is wired for the compact split-half blocks");
 
     // (compact blocks contract over their own first half: any mask is legal, the table is sized for S rows)
     const int nkt = IDX ? max(1, (se.row_cnt[grp] + 4 * KT - 1) / (4 * KT)) : nks / KT;
@@ -737,8 +749,9 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < (TAIL ? MT - 1 : MT); ++m)
                 acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
+            if constexpr (TAIL) acct = mfma_f64_4x4(sA[(s * MT + MT - 1) * 64 + toff], b, acct);
         }
 #pragma unroll
         for (int s = 0; s < KT; ++s) xb[s] = xn[s];
@@ -831,7 +844,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const int orow = packed & 0xfffff, t = packed >> 20;
                 const int o = s_mom[row] * (NW * 16) + cw;
                 const double* rc = s_rc + row * 5;
-                const double c1 = acc[m][i];
+                if (TAIL && m == MT - 1 && i > 0) continue;
+                const double c1 = (TAIL && m == MT - 1) ? acct : acc[m][i];
                 const double rf = pre ? sRf[t * (NW * 16) + cw] : rfv[m][i];
                 const double cf = rf * rc[4] * w5[4 * JW + o];
                 const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * JW + o];
@@ -1501,11 +1515,6 @@ void k_gram_lds(const double* __restrict__ R, long long strideR, int ldr, int Tp
 // statically over the 4 waves (wave W owns the U blocks u = W mod 4 and a
 // contiguous range of the G pairs) so every accumulator index is a constant.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double mfma_f64_4x4(double a, double b, double c)
-{
-    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-
 constexpr int g4_nu(int nlb, int w) { return nlb > w ? (nlb - w + 3) / 4 : 0; }
 constexpr int g4_gcount(int nb, int nlb, int w, bool wg = true)
 {

@@ -42,7 +42,7 @@ struct plsx_ctx {
     int sepmom = 0, MTd = 0, npg_d = 0, sepmom_used = 0;
     size_t group_stride_d = 0;
     Buf out_row_d, mom_idx_d, Afrag_m, momn_m, scale;
-    Buf Afrag_c, rank_c, rowtab_c, m1_c, m2_c, out_row_c, mom_idx_c;     // compact split-half (one split per block)
+    Buf Afrag_c, rank_c, rowtab_c, m1_c, m2_c, out_row_c, mom_idx_c, mask_c;     // compact blocks (one split / bootstrap per block)
     int has_compact_maps = 0;
     size_t group_stride = 0;
     // sliced layout (T' > PLSX_BLOCK_TP): gps groups per resample, 0 = plain
@@ -529,20 +529,135 @@ int run_xprod_sepmom(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, 
     }
 }
 
+// Row maps of a compact block (one resample / split per group): data row t -> R row t, moment index = its cell.
+int ensure_compact_maps(plsx_ctx* ctx)
+{
+    if (ctx->has_compact_maps) return 0;
+    const int rows = ceil_div(ctx->Tp, 16) * 16;
+    std::vector<int> orow(rows, -1), mrow(rows, -1);
+    for (int t = 0; t < ctx->Tp; ++t) { orow[t] = t; mrow[t] = t / ctx->T; }
+    if (int e = ensure(ctx, ctx->out_row_c, rows * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->mom_idx_c, rows * sizeof(int))) return e;
+    HIPCHK(hipMemcpy(ctx->out_row_c.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->mom_idx_c.p, mrow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
+    ctx->has_compact_maps = 1;
+    return 0;
+}
+
+// Compact bootstraps (correlation mode, T' <= 64): a bootstrap draws ~63 % of the rows of X; the 7-per-block
+// layout contracts every block over all S rows (the union of seven draws), i.e. multiplies 37 % zeros.
+// Here every bootstrap has a block of its own that contracts over the rows it draws (k_xprod IDX: row table,
+// multiplicities folded into A), scaled by the 1 / std table of the moment-only blocks as in the
+// separate-moments layout.  ceil(T'/16) tiles x ~0.632 S/4 k-steps instead of 24 tiles x S/4 k-steps per 7.
+template <int MT, int KT, bool TAIL = false>
+int launch_xprod_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st)
+{
+    constexpr int NW = 4;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8 + (size_t)nks_c * 4 * sizeof(int);
+    const size_t epi = (size_t)se.npairs * NW * 16 * 8 + (size_t)2 * MT * 16 * 4;
+    const size_t lds = std::max(stage, epi);
+    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 3, true, TAIL>, lds));
+    const int ncolblk = ctx->Bpad / (NW * 16);
+    KTimer tm(ctx, KC_XPROD, st);
+    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 3, true, TAIL>), dim3(round_up(ncolblk, 8) * round_up(nres, 8)), dim3(NW * 64),
+                       lds, st, ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
+                       ptr<double>(ctx->R), ctx->Bpad, ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
+                       (const double*)nullptr, 0, nres, ncolblk, (double*)nullptr, se, 1);
+    LAUNCHCHK();
+    return 0;
+}
+
+bool compact_boot_ok(const plsx_ctx* ctx)
+{
+    return ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 64 && !ctx->mom_out_arg &&
+           ctx->J * 64 * 8 <= 48 * 1024 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) &&
+           !getenv("PLSX_NO_COMPACT_BOOT");
+}
+
+int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
+                    const double* ystack, long long ystride)
+{
+    const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = 24 / (MTc == 3 ? 3 : MTc);
+    const int nks_c = round_up(ceil_div(S, 4), KT);
+    const int npairs = nres * J, groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
+    const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;
+    if (int e = ensure_compact_maps(ctx)) return e;
+    if (int e = ensure(ctx, ctx->Afrag_c, (size_t)nres * astride * 8 + 4096)) return e;
+    if (int e = ensure(ctx, ctx->mask_c, (size_t)nres * S)) return e;
+    if (int e = ensure(ctx, ctx->rank_c, (size_t)nres * S * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->rowtab_c, ((size_t)nres * nks_c * 4 + nres) * sizeof(int))) return e;
+    if (int e = ensure(ctx, ctx->Afrag_m, (size_t)groups_m * mstride * 8 + 4096)) return e;
+    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, PLSX_MOM_PAIRS) * 8)) return e;
+    if (int e = ensure(ctx, ctx->scale, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
+    HIPCHK(hipMemsetAsync(ctx->Afrag_c.p, 0, (size_t)nres * astride * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->Afrag_m.p, 0, (size_t)groups_m * mstride * 8, st));
+    HIPCHK(hipMemsetAsync(ctx->mask_c.p, 0, (size_t)nres * S, st));
+    int* row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)nres * nks_c * 4;
+    {
+        KTimer tm(ctx, KC_BUILD, st);
+        hipLaunchKernelGGL(k_drawn_mask, dim3(ceil_div(S, 256), nres), dim3(256), 0, st, xsrc, S, ptr<uint8_t>(ctx->mask_c));
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_split_rank, dim3(nres), dim3(64), 0, st, ptr<uint8_t>(ctx->mask_c), S, nks_c * 4,
+                           ptr<int>(ctx->rank_c), ptr<int>(ctx->rowtab_c), row_cnt);
+        LAUNCHCHK();
+        GroupLayout lay;
+        lay.n = 1; lay.Tp = ctx->Tp; lay.J = J; lay.T = ctx->T; lay.MT = MTc; lay.w0 = MTc; lay.sq0 = MTc; lay.Tpp = ctx->Tpp;
+        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, J), dim3(256), (size_t)2 * ctx->T * 8, st,
+                           ystack ? ystack : ptr<double>(ctx->Y), ystack ? ystride : 0LL, ctx->T, S,
+                           ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay, ctx->cov, 1,
+                           ptr<double>(ctx->Afrag_c), astride, ptr<double>(ctx->momn_m), 0, 0,
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<int>(ctx->rank_c));
+        LAUNCHCHK();
+    }
+    SplitEpi se;
+    memset(&se, 0, sizeof(se));
+    se.scale = ptr<double>(ctx->scale);
+    {
+        constexpr int NW = 4;
+        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
+        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 4>, lds));
+        const int ncolblk = ctx->Bpad / (NW * 16);
+        se.npairs = npairs;
+        KTimer tm(ctx, KC_MOM, st);
+        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 4>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                           ptr<double>(ctx->momn_m), 0, groups_m, ncolblk, (double*)nullptr, se, 1);
+        LAUNCHCHK();
+    }
+    se.npairs = J;
+    se.accB = nres * ctx->Tpp;
+    se.row_tab = ptr<int>(ctx->rowtab_c);
+    se.row_cnt = row_cnt;
+    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && MTc >= 2;
+    switch (MTc) {
+        case 1: return launch_xprod_cboot<1, 24>(ctx, nres, nks_c, se, st);
+        case 2: return tail ? launch_xprod_cboot<2, 12, true>(ctx, nres, nks_c, se, st)
+                            : launch_xprod_cboot<2, 12>(ctx, nres, nks_c, se, st);
+        case 3: return tail ? launch_xprod_cboot<3, 8, true>(ctx, nres, nks_c, se, st)
+                            : launch_xprod_cboot<3, 8>(ctx, nres, nks_c, se, st);
+        default: return tail ? launch_xprod_cboot<4, 6, true>(ctx, nres, nks_c, se, st)
+                             : launch_xprod_cboot<4, 6>(ctx, nres, nks_c, se, st);
+    }
+}
+
 // Build the A operands of `nres` resamples and run the cross-product kernel:
 // afterwards R[r] (r < nres) holds gen_covcorr of resample r in columns
 // [0, B) and its gen_distrib in columns [B, B+L) (once the original is set).
 // ystack: per-resample behaviour matrices (S x T each, `ystride` doubles apart; ystride 0 =
 // one matrix shared by all resamples of the call, e.g. the halves of one pre-permuted Y).
 int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
-              bool prebuilt = false, const double* ystack = nullptr, long long ystride = -1)
+              bool prebuilt = false, const double* ystack = nullptr, long long ystride = -1, bool sparse_rows = false)
 {
+    // sparse_rows: the caller's resamples draw a good part of the rows of X more than once or not at all
+    // (bootstraps): compact blocks when the shape allows
     if (ystride < 0) ystride = (long long)ctx->S * ctx->T;
     const int groups = ceil_div(nres, ctx->npg);
     if (int e = ensure_scratch(ctx, groups)) return e;
     if (ctx->timing) ctx->timed_units += nres;
     const int pgroups = phys_groups(ctx, groups);
     if (prebuilt) return launch_xprod(ctx, pgroups, st);       // A already scattered by the caller
+    if (sparse_rows && xsrc && compact_boot_ok(ctx)) return run_xprod_cboot(ctx, xsrc, ysrc, nres, st, ystack, ystride);
     if (ctx->sepmom && ctx->method == PLSX_BEHAVIORAL && !ctx->mom_out_arg) {
         // tile passes of the launch in either layout; the separate-moments layout has to win by 2 %
         // (one more launch, the scale table): it does at the headline shape (1728 -> 1656 per 504
@@ -1116,7 +1231,7 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
-                   &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c})
+                   &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1648,7 +1763,7 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;
-        if (int e = run_xprod(ctx, idx, idx, m, st)) return e;
+        if (int e = run_xprod(ctx, idx, idx, m, st, false, nullptr, -1, true)) return e;
         if (int e = run_gram(ctx, m, true, st)) return e;
         const double* R = ptr<double>(ctx->R);
         SmallArgs a = small_args(ctx, SMALL_BOOT);
@@ -1737,15 +1852,7 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
         LAUNCHCHK();
         ctx->has_cellS = 2;                             // (the 7-per-block row map of run_split_fused is not uploaded)
     }
-    if (!ctx->has_compact_maps) {
-        std::vector<int> orow(rows, -1), mrow(rows, -1);
-        for (int t = 0; t < ctx->Tp; ++t) { orow[t] = t; mrow[t] = t / ctx->T; }
-        if (int e = ensure(ctx, ctx->out_row_c, rows * sizeof(int))) return e;
-        if (int e = ensure(ctx, ctx->mom_idx_c, rows * sizeof(int))) return e;
-        HIPCHK(hipMemcpy(ctx->out_row_c.p, orow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(ctx->mom_idx_c.p, mrow.data(), rows * sizeof(int), hipMemcpyHostToDevice));
-        ctx->has_compact_maps = 1;
-    }
+    if (int e = ensure_compact_maps(ctx)) return e;
     // the tables are sized for a first half of all S rows; a block contracts over its own count
     const int nks_c = round_up(ceil_div(S, 4), KT);
     const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;

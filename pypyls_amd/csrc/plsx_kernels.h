@@ -165,8 +165,12 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
                                 GroupLayout lay, int covariance, int scaled,
                                 double* __restrict__ Afrag, size_t group_stride,
                                 double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0,
-                                double* __restrict__ Amom = nullptr, size_t mom_stride = 0)
+                                double* __restrict__ Amom = nullptr, size_t mom_stride = 0,
+                                const int* __restrict__ rank = nullptr)
 {
+    // rank != nullptr (compact layout, one resample per group, with Amom): the contraction index of source
+    // row xi is its rank among the rows the resample draws (k_split_rank over k_drawn_mask); the weight
+    // rows keep the subject index (moment-only blocks contract over all of X).
     // Amom != nullptr (separate-moments layout): the weight rows of (resample, cell) pair
     // q = r * J + j go to group q / PLSX_MOM_PAIRS of Amom -- moment-only blocks of 24 tiles, rows
     // [0, 192) against X and rows [192, 384) against X^2 -- instead of riding in the data group;
@@ -233,7 +237,7 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
             const int grow = j * T + t;
             atomicAdd(Afrag + ((size_t)r * lay.gps + lay.row_slice[grow]) * group_stride +
                       afrag_off(lay.row_local[grow], xi, lay.MT), v);
-        } else atomicAdd(A + afrag_off(row, xi, lay.MT), v);
+        } else atomicAdd(A + afrag_off(row, rank ? rank[(size_t)r * S + xi] : xi, lay.MT), v);
     }
     if (scaled && sliced) {
         // every slice that holds rows of cell j carries the cell's moment rows
@@ -523,6 +527,16 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
     if (tid == 0) mom_n[(size_t)g * nmom_pad + mrow] = (double)s_n1;
 }
 
+// Compact bootstraps: mask[r][s] = 1 when resample r draws source row s (mask zeroed by the caller).
+// grid (ceil(S / 256), n_resamples).
+__global__ void k_drawn_mask(const int* __restrict__ xsrc, int S, uint8_t* __restrict__ mask)
+{
+    const int r = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= S) return;
+    const int xi = xsrc[(size_t)r * S + p];
+    if (xi >= 0) mask[(size_t)r * S + xi] = 1;
+}
+
 // Compact split-half: rank[split][p] = number of first-half positions before p (the contraction
 // index of position p in the split's own cross-product block), row_tab[split][k] = the position of
 // rank k (the X row that block loads at contraction index k; padding entries -> row 0, whose A
@@ -616,11 +630,11 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 //     only: IDX row table), first-half moments from the tables the EPI 6 moment blocks write,
 // 6 = moment-only block writing the raw moments m1, m2 (se.scale, se.scale2).
 // IDX: the X row behind contraction index k comes from se.row_tab (loaded to LDS once per block).
-// TAIL (EPI 5): the last data tile holds <= 4 live rows and goes through the 4x4x4 shape (16 instead of 64
+// TAIL (EPI 5 / 3, compact blocks): the last data tile holds <= 4 live rows and goes through the 4x4x4 shape (16 instead of 64
 // matrix-pipe cycles; A = the tile's rows 0..3 for every block, B = the X fragment as it is, the result lands
 // where register 0 of the 16x16 tile would).
 template <int MT, int NW, int KT, int NSQ, int EPI = 0, bool IDX = false, bool TAIL = false>
-__global__ __launch_bounds__(NW * 64, IDX ? 4 : 2)
+__global__ __launch_bounds__(NW * 64, IDX ? 5 : 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
              double* __restrict__ R, int ldr, int rows_per_group,
@@ -679,10 +693,11 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
     double acct = 0.0;
     const int toff = (lane & 48) + (lane & 3) - lane;     // TAIL: lane 16 k + 4 blk + i -> fragment position 16 k + i
-    static_assert(!TAIL || (EPI == 5 && NSQ == 0), "the 4x4x4 tail is wired for the compact split-half blocks");
+    static_assert(!TAIL || ((EPI == 5 || EPI == 3) && NSQ == 0), "the 4x4x4 tail is wired for the compact blocks");
 
     // (compact blocks contract over their own first half: any mask is legal, the table is sized for S rows)
-    const int nkt = IDX ? max(1, (se.row_cnt[grp] + 4 * KT - 1) / (4 * KT)) : nks / KT;
+    const int ksteps = IDX ? max(1, (se.row_cnt[grp] + 3) >> 2) : nks;       // (the last stage of a compact block may be partial)
+    const int nkt = IDX ? (ksteps + KT - 1) / KT : nks / KT;
     constexpr bool SPLIT = (EPI == 1 || EPI == 5);
     int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE_LDS);       // IDX: [nks * 4] X rows of this group
     if constexpr (IDX) {
@@ -746,6 +761,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
+            if (IDX && kt * KT + s >= ksteps) break;
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
@@ -905,8 +921,11 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 sc[i] = mi >= 0 ? sS3[mi * (NW * 16) + cw] : 1.0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
+            for (int i = 0; i < 4; ++i) {
+                if (TAIL && m == MT - 1 && i > 0) break;
+                const double v = (TAIL && m == MT - 1) ? acct : acc[m][i];
+                if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = v * sc[i];
+            }
         }
         return;
     }

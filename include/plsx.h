@@ -246,7 +246,9 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops);
  * [1] its launch count, [2] resamples per launch group, [3] M tiles per block,
  * [4] super-batch size, [5] resamples those launches covered, [6] 1 if
  * permutations take the dual (S x S kernel) path and launch no cross-product
- * kernel. Returns the number written. */
+ * kernel, [7] compact blocks (one bootstrap per block contracting over the
+ * rows it draws): contracted rows / S of the last launch, 0 when the last
+ * launch used the dense layouts. Returns the number written. */
 int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
 /* Scratch budget of the resampling super-batches (default 48 GB; the R block
  * of one bootstrap is 8 T' B bytes).  fixed = 1: every launch uses budget-sized

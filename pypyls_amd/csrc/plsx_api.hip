@@ -80,6 +80,7 @@ struct plsx_ctx {
     struct TimedEv { int cls; hipEvent_t e0, e1; };
     std::vector<TimedEv> events;
     long long timed_units = 0;
+    int last_compact_n = 0, last_compact_ktot = 0;   // compact launch behind the last run_xprod (0: none)
     double scratch_gb = 48.0;                           // super-batch scratch budget
     int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
                           // resamples covered by the timed launches
@@ -569,9 +570,20 @@ int launch_xprod_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStrea
 
 bool compact_boot_ok(const plsx_ctx* ctx)
 {
-    return ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 64 && !ctx->mom_out_arg &&
-           ctx->J * 64 * 8 <= 48 * 1024 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) &&
-           !getenv("PLSX_NO_COMPACT_BOOT");
+    if (!(ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 64 && !ctx->mom_out_arg &&
+          ctx->J * 64 * 8 <= 48 * 1024 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31)))
+        return false;
+    static const int force = getenv("PLSX_COMPACT_BOOT_ALWAYS") ? 1 : (getenv("PLSX_NO_COMPACT_BOOT") ? -1 : 0);
+    if (force) return force > 0;
+    // matrix-pipe cycles per bootstrap in units of (S / 4 k-steps x one 16-row tile): a compact block contracts
+    // ~0.66 S rows (distinct draws, rounded to k-steps) on its own tiles at ~0.8 of the dense blocks' pipe
+    // utilisation (measured at the headline shape); a dense block shares its tiles between its resamples.
+    // A dense block that packs many resamples (small T') also re-reads X that much less often: keep it.
+    const int mt = ceil_div(ctx->Tp, 16);
+    const double rows = (mt >= 2 && ctx->Tp - (mt - 1) * 16 <= 4) ? (mt - 1) * 16 + 4 : mt * 16;
+    const double cost_c = 0.66 * 1.25 * rows / 16.0;
+    const int npg_dense = ctx->sepmom ? ctx->npg_d : ctx->npg, mt_dense = ctx->sepmom ? ctx->MTd : ctx->MT;
+    return cost_c * 1.1 < (double)mt_dense / npg_dense && npg_dense <= 16;
 }
 
 int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
@@ -593,6 +605,7 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
     HIPCHK(hipMemsetAsync(ctx->Afrag_m.p, 0, (size_t)groups_m * mstride * 8, st));
     HIPCHK(hipMemsetAsync(ctx->mask_c.p, 0, (size_t)nres * S, st));
     int* row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)nres * nks_c * 4;
+    ctx->last_compact_n = nres; ctx->last_compact_ktot = nks_c * 4;
     {
         KTimer tm(ctx, KC_BUILD, st);
         hipLaunchKernelGGL(k_drawn_mask, dim3(ceil_div(S, 256), nres), dim3(256), 0, st, xsrc, S, ptr<uint8_t>(ctx->mask_c));
@@ -656,6 +669,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
     if (int e = ensure_scratch(ctx, groups)) return e;
     if (ctx->timing) ctx->timed_units += nres;
     const int pgroups = phys_groups(ctx, groups);
+    ctx->last_compact_n = 0;
     if (prebuilt) return launch_xprod(ctx, pgroups, st);       // A already scattered by the caller
     if (sparse_rows && xsrc && compact_boot_ok(ctx)) return run_xprod_cboot(ctx, xsrc, ysrc, nres, st, ystack, ystride);
     if (ctx->sepmom && ctx->method == PLSX_BEHAVIORAL && !ctx->mom_out_arg) {
@@ -2535,9 +2549,22 @@ int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
             ms += t;
         ++launches;
     }
-    double vals[7] = {ms, (double)launches, (double)(ctx->sepmom_used ? ctx->npg_d : ctx->npg), (double)(ctx->sepmom_used ? ctx->MTd : ctx->MT),
-                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual};
-    int n = std::min(cap, 7);
+    // compact blocks: k-steps x 4 rows a block of the last launch contracted over, as a fraction of S (0: the
+    // last launch was not compact) -- the issued share of the dense S-row contraction
+    double crows = 0.0;
+    if (ctx->last_compact_n > 0) {
+        std::vector<int> cnt(ctx->last_compact_n);
+        if (hipMemcpy(cnt.data(), ptr<int>(ctx->rowtab_c) + (size_t)ctx->last_compact_n * ctx->last_compact_ktot,
+                      cnt.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int c : cnt) crows += 4.0 * ((std::max(c, 1) + 3) / 4);
+            crows /= (double)cnt.size() * ctx->S;
+        }
+    }
+    const bool cmp = ctx->last_compact_n > 0;
+    double vals[8] = {ms, (double)launches, (double)(cmp ? 1 : (ctx->sepmom_used ? ctx->npg_d : ctx->npg)),
+                      (double)(cmp ? ceil_div(ctx->Tp, 16) : (ctx->sepmom_used ? ctx->MTd : ctx->MT)),
+                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual, crows};
+    int n = std::min(cap, 8);
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
 }

@@ -533,5 +533,5 @@ class Engine(object):
         buf = (ctypes.c_double * 8)()
         n = self.lib.plsx_last_timing(self.ctx, buf, 8)
         keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch',
-                'xprod_resamples', 'dual_perm']
+                'xprod_resamples', 'dual_perm', 'compact_row_fraction']
         return {k: buf[i] for i, k in enumerate(keys[:max(n, 0)])}

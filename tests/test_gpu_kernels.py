@@ -321,8 +321,9 @@ np.savez(sys.argv[1], R=R, usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=
     import tempfile
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for key, env in (('sep', {'PLSX_SEPMOM_ALWAYS': '1', 'PLSX_NO_SPLIT_FUSE': '1'}),
-                         ('inblock', {'PLSX_INBLOCK_MOMENTS': '1', 'PLSX_NO_SPLIT_FUSE': '1'})):
+        for key, env in (('sep', {'PLSX_SEPMOM_ALWAYS': '1', 'PLSX_NO_SPLIT_FUSE': '1', 'PLSX_NO_COMPACT_BOOT': '1'}),
+                         ('inblock', {'PLSX_INBLOCK_MOMENTS': '1', 'PLSX_NO_SPLIT_FUSE': '1',
+                                      'PLSX_NO_COMPACT_BOOT': '1'})):
             path = os.path.join(tmp, key + '.npz')
             proc = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env),
                                   capture_output=True, text=True, timeout=600)
@@ -341,3 +342,58 @@ np.savez(sys.argv[1], R=R, usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=
     for i in (0, 17, 44):
         want = ref.gen_covcorr(spec, X[boots[:, i]], Y[boots[:, i]], spec.dummy)
         assert_close(out['sep']['R'][i], want, 1e-10, what='separate-moments R vs oracle')
+
+
+@pytest.mark.parametrize('shape', [(64, 3001, 50, [64], 1), (60, 2500, 10, [15, 15], 2), (90, 1300, 7, [10, 12, 8], 3),
+                                   (60, 800, 20, [60], 1), (40, 700, 8, [40], 1), (160, 900, 33, [80], 2)])
+def test_compact_blocks_equal_dense_blocks(shape):
+    """Compact cross-product blocks -- one bootstrap per block contracting over the DISTINCT rows it draws
+    (k_xprod IDX row table, multiplicities folded into A; last tile on the 4x4x4 shape when it holds <= 4
+    rows: T' = 50, 20, 33 x 2 = 66 -> not compact) -- and one split per block over its first half
+    (PLSX_SPLIT_INBLOCK = the 7-per-block fused layout) against the dense layouts: bootstrap sums, distrib,
+    split-half correlations.  Every tile count 1..4, with and without the tail, J = 1..9 cells.
+    Own processes: the switches are read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from conftest import ROOT
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from pypyls_amd import resampling as rsmp
+from pypyls_amd.engine import Engine
+S, B, T, groups, n_cond = %r
+rs = np.random.RandomState(3)
+X = rs.randn(S, B) * (0.5 + rs.rand(1, B)); Y = rs.randn(S, T) + 0.4 * X[:, :T]
+eng = Engine()
+eng.set_data(X, Y, rsmp.cell_of_row(groups, n_cond), len(groups), n_cond, 0)
+boots = rsmp.gen_bootsamp(groups, n_cond, 45, seed=4)
+xw, sv, yw = eng.decompose()
+eng.set_original(xw, sv, yw)
+usum, usq, dist = eng.boot(boots)
+cf = eng.last_timing().get('compact_row_fraction', 0.0)
+masks = rsmp.gen_splits(groups, n_cond, 11, seed=9)
+perms = rsmp.gen_permsamp(groups, n_cond, 2, seed=6)
+uc, vc = eng.split_half(masks)
+m3 = np.stack([rsmp.gen_splits(groups, n_cond, 5, seed=40 + i) for i in range(2)])
+ucp, vcp = eng.split_half(m3, perms=perms)
+np.savez(sys.argv[1], usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist, uc=uc, vc=vc, ucp=ucp, vcp=vcp,
+         compact=cf)
+""" % (ROOT, shape)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for key, env in (('compact', {'PLSX_COMPACT_BOOT_ALWAYS': '1'}),
+                         ('dense', {'PLSX_NO_COMPACT_BOOT': '1', 'PLSX_SPLIT_INBLOCK': '1'})):
+            path = os.path.join(tmp, key + '.npz')
+            proc = subprocess.run([sys.executable, '-c', code, path], env=dict(os.environ, **env),
+                                  capture_output=True, text=True, timeout=600)
+            assert proc.returncode == 0, proc.stderr[-2000:]
+            out[key] = dict(np.load(path))
+    S, B, T, groups, n_cond = shape
+    if T * len(groups) * n_cond <= 64:
+        assert 0.5 < float(out['compact']['compact']) < 0.8, 'the compact layout did not run'
+    assert float(out['dense']['compact']) == 0.0
+    for k in ('usum', 'usq', 'dist', 'uc', 'vc', 'ucp', 'vcp'):
+        assert_close(out['compact'][k], out['dense'][k], 1e-10, what='compact vs dense blocks: ' + k)

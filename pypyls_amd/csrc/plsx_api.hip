@@ -553,17 +553,16 @@ int ensure_compact_maps(plsx_ctx* ctx)
 template <int MT, int KT, bool TAIL = false>
 int launch_xprod_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st)
 {
-    constexpr int NW = 4;
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8 + (size_t)nks_c * 4 * sizeof(int);
-    const size_t epi = (size_t)se.npairs * NW * 16 * 8 + (size_t)2 * MT * 16 * 4;
+    const size_t epi = (size_t)se.npairs * 128 * 8 + (size_t)2 * MT * 16 * 4;
     const size_t lds = std::max(stage, epi);
-    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 3, true, TAIL>, lds));
-    const int ncolblk = ctx->Bpad / (NW * 16);
+    HIPCHK(set_lds(k_xprod_compact<MT, KT, 3, TAIL>, lds));
+    const int ncolblk = ceil_div(ctx->Bpad, 128);
     KTimer tm(ctx, KC_XPROD, st);
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 3, true, TAIL>), dim3(round_up(ncolblk, 8) * round_up(nres, 8)), dim3(NW * 64),
+    hipLaunchKernelGGL((k_xprod_compact<MT, KT, 3, TAIL>), dim3(round_up(ncolblk, 8) * round_up(nres, 8)), dim3(256),
                        lds, st, ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
                        ptr<double>(ctx->R), ctx->Bpad, ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
-                       (const double*)nullptr, 0, nres, ncolblk, (double*)nullptr, se, 1);
+                       (const double*)nullptr, nres, ncolblk, se);
     LAUNCHCHK();
     return 0;
 }
@@ -589,7 +588,7 @@ bool compact_boot_ok(const plsx_ctx* ctx)
 int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
                     const double* ystack, long long ystride)
 {
-    const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = 24 / (MTc == 3 ? 3 : MTc);
+    const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = 12 / MTc;      // (two column tiles per wave)
     const int nks_c = round_up(ceil_div(S, 4), KT);
     const int npairs = nres * J, groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
     const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;
@@ -644,13 +643,13 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
     se.row_cnt = row_cnt;
     const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && MTc >= 2;
     switch (MTc) {
-        case 1: return launch_xprod_cboot<1, 24>(ctx, nres, nks_c, se, st);
-        case 2: return tail ? launch_xprod_cboot<2, 12, true>(ctx, nres, nks_c, se, st)
-                            : launch_xprod_cboot<2, 12>(ctx, nres, nks_c, se, st);
-        case 3: return tail ? launch_xprod_cboot<3, 8, true>(ctx, nres, nks_c, se, st)
-                            : launch_xprod_cboot<3, 8>(ctx, nres, nks_c, se, st);
-        default: return tail ? launch_xprod_cboot<4, 6, true>(ctx, nres, nks_c, se, st)
-                             : launch_xprod_cboot<4, 6>(ctx, nres, nks_c, se, st);
+        case 1: return launch_xprod_cboot<1, 12>(ctx, nres, nks_c, se, st);
+        case 2: return tail ? launch_xprod_cboot<2, 6, true>(ctx, nres, nks_c, se, st)
+                            : launch_xprod_cboot<2, 6>(ctx, nres, nks_c, se, st);
+        case 3: return tail ? launch_xprod_cboot<3, 4, true>(ctx, nres, nks_c, se, st)
+                            : launch_xprod_cboot<3, 4>(ctx, nres, nks_c, se, st);
+        default: return tail ? launch_xprod_cboot<4, 3, true>(ctx, nres, nks_c, se, st)
+                             : launch_xprod_cboot<4, 3>(ctx, nres, nks_c, se, st);
     }
 }
 
@@ -1833,23 +1832,18 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
 template <int MT, int KT, bool TAIL = false>
 int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st)
 {
-    constexpr int NW = 4;
     const int J = ctx->J;
-    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128;          // doubles, both stages
-    const size_t tab = (size_t)(nks_c * 4 + 1) / 2;                                       // row table behind the stages
-    const size_t epi0 = (size_t)5 * J * NW * 16 + (size_t)MT * 16;                        // w5 + row maps (ints, 2 per double)
-    const size_t pre0 = round_up((int)std::max(stage + tab, epi0), 128);
-    const size_t rcpad = (size_t)((MT * 16 * 5 + 127) / 128) * 128;
-    const size_t pre_total = pre0 + (size_t)ctx->Tpp * NW * 16 + rcpad;
-    se.off_pre = (getenv("PLSX_SPLIT_PRE") && pre_total * 8 <= 80 * 1024) ? (int)pre0 : 0;
-    const size_t lds = se.off_pre ? pre_total * 8 : std::max(stage + tab, epi0 + rcpad) * 8;
-    HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 5, true, TAIL>, lds));
-    const int ncolblk = ctx->Bpad / (NW * 16);
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8 + (size_t)nks_c * 4 * sizeof(int);
+    const size_t epi = (size_t)5 * J * 128 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
+    const size_t lds = std::max(stage, epi);
+    se.off_pre = 0;
+    HIPCHK(set_lds(k_xprod_compact<MT, KT, 5, TAIL>, lds));
+    const int ncolblk = ceil_div(ctx->Bpad, 128);
     KTimer tm(ctx, KC_XPROD, st);
-    hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 5, true, TAIL>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(NW * 64), lds, st,
+    hipLaunchKernelGGL((k_xprod_compact<MT, KT, 5, TAIL>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(256), lds, st,
                        ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
                        ptr<double>(ctx->R), ctx->Bpad, 2 * ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
-                       ptr<double>(ctx->momn_m), 0, m, ncolblk, (double*)nullptr, se, 1);
+                       ptr<double>(ctx->momn_m), m, ncolblk, se);
     LAUNCHCHK();
     return 0;
 }
@@ -1857,7 +1851,7 @@ int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream
 int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
                       hipStream_t st, const double* Yarr)
 {
-    const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = 24 / (MTc == 3 ? 3 : MTc), rows = MTc * 16;
+    const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = 12 / MTc, rows = MTc * 16;
     if (!ctx->has_cellS) {
         if (int e = ensure(ctx, ctx->cellS, (size_t)2 * J * ctx->Bpad * 8, true)) return e;
         hipLaunchKernelGGL(k_cell_moments, dim3(ceil_div(ctx->B, 256)), dim3(256), 0, st, ptr<double>(ctx->Xc),
@@ -1924,13 +1918,13 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
     const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !getenv("PLSX_SPLIT_NO_TAIL4");
     switch (MTc) {
-        case 1: return launch_xprod_compact<1, 24>(ctx, m, nks_c, se, st);
-        case 2: return tail ? launch_xprod_compact<2, 12, true>(ctx, m, nks_c, se, st)
-                            : launch_xprod_compact<2, 12>(ctx, m, nks_c, se, st);
-        case 3: return tail ? launch_xprod_compact<3, 8, true>(ctx, m, nks_c, se, st)
-                            : launch_xprod_compact<3, 8>(ctx, m, nks_c, se, st);
-        default: return tail ? launch_xprod_compact<4, 6, true>(ctx, m, nks_c, se, st)
-                             : launch_xprod_compact<4, 6>(ctx, m, nks_c, se, st);
+        case 1: return launch_xprod_compact<1, 12>(ctx, m, nks_c, se, st);
+        case 2: return tail ? launch_xprod_compact<2, 6, true>(ctx, m, nks_c, se, st)
+                            : launch_xprod_compact<2, 6>(ctx, m, nks_c, se, st);
+        case 3: return tail ? launch_xprod_compact<3, 4, true>(ctx, m, nks_c, se, st)
+                            : launch_xprod_compact<3, 4>(ctx, m, nks_c, se, st);
+        default: return tail ? launch_xprod_compact<4, 3, true>(ctx, m, nks_c, se, st)
+                             : launch_xprod_compact<4, 3>(ctx, m, nks_c, se, st);
     }
 }
 

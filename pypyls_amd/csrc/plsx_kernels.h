@@ -626,15 +626,10 @@ __device__ __forceinline__ double load_x_buf(const double* rowbase, int voff)
 //     Correlation mode with in-block moments spends 2 of 24 tiles on 7 + 7 moment rows; here the
 //     moments of 192 (resample, cell) pairs fill a block and the data blocks carry data only.
 #define PLSX_ACC_PITCH 80        // LDS pitch of an l-row (64 columns + 16: rows l, l+1 of one MFMA register land in different banks)
-// 5 = fused split-half on COMPACT blocks (one split per group, contraction over the rows of its first half
-//     only: IDX row table), first-half moments from the tables the EPI 6 moment blocks write,
-// 6 = moment-only block writing the raw moments m1, m2 (se.scale, se.scale2).
-// IDX: the X row behind contraction index k comes from se.row_tab (loaded to LDS once per block).
-// TAIL (EPI 5 / 3, compact blocks): the last data tile holds <= 4 live rows and goes through the 4x4x4 shape (16 instead of 64
-// matrix-pipe cycles; A = the tile's rows 0..3 for every block, B = the X fragment as it is, the result lands
-// where register 0 of the 16x16 tile would).
-template <int MT, int NW, int KT, int NSQ, int EPI = 0, bool IDX = false, bool TAIL = false>
-__global__ __launch_bounds__(NW * 64, IDX ? 5 : 2)
+// 6 = moment-only block writing the raw moments m1, m2 (se.scale, se.scale2) -- the first-half feature moments
+//     of the compact fused split-half blocks (k_xprod_compact, EPI 5 there).
+template <int MT, int NW, int KT, int NSQ, int EPI = 0>
+__global__ __launch_bounds__(NW * 64, 2)
 void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
              const double* __restrict__ X, int ldx, int nks,
              double* __restrict__ R, int ldr, int rows_per_group,
@@ -659,21 +654,11 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // A last, partial sweep (n_groups % 8 = rem groups) would leave 8 - rem XCDs
     // idle: its rem * ncolblk tiles are dealt out as eight contiguous ranges
     // instead, one per XCD (each XCD then touches at most two groups' A).
-    // IDX (compact split-half, one split per group): every group reads its OWN half of the rows of X, so
-    // the groups of a column block share its rows only through L2 -- the 8 groups of a sweep go to ONE
-    // XCD per column block (slots s, s+1, .. of XCD x: groups 0..7 of column block (s / 8) * 8 + x), their
-    // sorted row lists advance together and each row of the column block comes from HBM once per sweep.
-    const int ncb = IDX ? ((ncolblk + 7) & ~7) : ncolblk;
-    const int sweep = blockIdx.x / (8 * ncb);
-    const int within = blockIdx.x - sweep * (8 * ncb);
+    const int sweep = blockIdx.x / (8 * ncolblk);
+    const int within = blockIdx.x - sweep * (8 * ncolblk);
     int grp = sweep * 8 + (within & 7);
     int colblk = within >> 3;
-    if constexpr (IDX) {
-        const int slot = within >> 3;
-        grp = sweep * 8 + (slot & 7);
-        colblk = (slot >> 3) * 8 + (within & 7);
-        if (grp >= n_groups || colblk >= ncolblk) return;
-    } else if (sweep * 8 + 8 > n_groups) {
+    if (sweep * 8 + 8 > n_groups) {
         const int rem = n_groups - sweep * 8;
         const int cnt = (rem * ncolblk + 7) >> 3;
         const int id = (within & 7) * cnt + colblk;
@@ -691,24 +676,9 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     d4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (d4){0.0, 0.0, 0.0, 0.0};
-    double acct = 0.0;
-    const int toff = (lane & 48) + (lane & 3) - lane;     // TAIL: lane 16 k + 4 blk + i -> fragment position 16 k + i
-    static_assert(!TAIL || ((EPI == 5 || EPI == 3) && NSQ == 0), "the 4x4x4 tail is wired for the compact blocks");
 
-    // (compact blocks contract over their own first half: any mask is legal, the table is sized for S rows)
-    const int ksteps = IDX ? max(1, (se.row_cnt[grp] + 3) >> 2) : nks;       // (the last stage of a compact block may be partial)
-    const int nkt = IDX ? (ksteps + KT - 1) / KT : nks / KT;
-    constexpr bool SPLIT = (EPI == 1 || EPI == 5);
-    int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE_LDS);       // IDX: [nks * 4] X rows of this group
-    if constexpr (IDX) {
-        for (int i = tid; i < nks * 4; i += NT) s_tab[i] = se.row_tab[(size_t)grp * nks * 4 + i];
-        __syncthreads();
-    }
-    // byte offset of this lane's X element at contraction step k (k-step granularity: 4 rows)
-    auto x_off = [&](int kstep) -> int {
-        if constexpr (IDX) return (s_tab[kstep * 4 + kq] * ldx + col) * 8;
-        else return 0;
-    };
+    const int nkt = nks / KT;
+    constexpr bool SPLIT = (EPI == 1);
     if constexpr (SPLIT) {
         // Fused split-half: the epilogue needs this block's (Tpp x 64) tile of the
         // arrangement's full-sample R and the group's row constants.  Fetched here by
@@ -737,7 +707,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     double xb[KT];
 #pragma unroll
     for (int s = 0; s < KT; ++s)
-        xb[s] = IDX ? load_x_buf(X, x_off(s)) : load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
+        xb[s] = load_x_buf(X + (size_t)(s * 4) * ldx, xvoff);
     // Force the first X fragments to be resident before the loop: a load still
     // pending at the loop header makes hipcc place a near-draining
     // s_waitcnt vmcnt(1) right after the next stage's loads are issued.
@@ -757,17 +727,15 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid, swave);
 #pragma unroll
         for (int s = 0; s < KT; ++s)
-            xn[s] = IDX ? load_x_buf(X, x_off(kn * KT + s)) : load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
+            xn[s] = load_x_buf(X + (size_t)((kn * KT + s) * 4) * ldx, xvoff);
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
-            if (IDX && kt * KT + s >= ksteps) break;
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
 #pragma unroll
-            for (int m = 0; m < (TAIL ? MT - 1 : MT); ++m)
+            for (int m = 0; m < MT; ++m)
                 acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
-            if constexpr (TAIL) acct = mfma_f64_4x4(sA[(s * MT + MT - 1) * 64 + toff], b, acct);
         }
 #pragma unroll
         for (int s = 0; s < KT; ++s) xb[s] = xn[s];
@@ -791,83 +759,6 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 if (pair >= se.npairs) continue;
                 se.scale[(size_t)pair * ldr + col] = acc[j][i];
                 se.scale2[(size_t)pair * ldr + col] = acc[NSQ + j][i];
-            }
-        return;
-    }
-    if constexpr (EPI == 5) {
-        // fused split-half of ONE split (compact block): both halves from the first half's raw sums as in
-        // EPI 1, the first half's feature moments from the tables.  LDS: w5 [5][J][64], row maps, and
-        // (prefetched by DMA at kernel start) the tile of Rfull and the row constants.
-        const int J = se.J;
-        const bool pre = se.off_pre > 0 && NW == 4;
-        double* w5 = smem;                                        // u1, v1, u2, v2, sF : [5][J][64]
-        int* s_out = reinterpret_cast<int*>(smem + 5 * J * (NW * 16));
-        int* s_mom = s_out + MT * 16;
-        const double* sRf = smem + se.off_pre;
-        double* s_rc = pre ? smem + se.off_pre + se.Tpp * (NW * 16)
-                           : reinterpret_cast<double*>(s_mom + MT * 16);
-        const int pitch2 = 2 * se.Tpp;
-        for (int i = tid; i < MT * 16; i += NT) {
-            const int orw = out_row[i];
-            s_out[i] = orw < 0 ? -1 : (orw | ((orw % pitch2) << 20));
-            s_mom[i] = mom_idx[i];
-        }
-        if (!pre)
-            for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
-        const int cb0 = colblk * (NW * 16);
-        for (int idx = tid; idx < J * (NW * 16); idx += NT) {
-            const int jc = idx / (NW * 16), c = idx - jc * (NW * 16);
-            const size_t pair = (size_t)grp * J + jc;
-            const double n1 = mom_n[pair];
-            const double m1 = se.scale[pair * ldr + cb0 + c], m2 = se.scale2[pair * ldr + cb0 + c];
-            const double nF = (double)se.cell_len[jc];
-            const double SF = se.cellS1[(size_t)jc * ldr + cb0 + c], SFF = se.cellS2[(size_t)jc * ldr + cb0 + c];
-            const double n2 = nF - n1;
-            const bool ok = n1 > 1.5 && n2 > 1.5;
-            const double var1 = ok ? (m2 - m1 * m1 / n1) / (n1 - 1.0) : 0.0;
-            const double s2x = SF - m1, s2xx = SFF - m2;
-            const double var2 = ok ? (s2xx - s2x * s2x / n2) / (n2 - 1.0) : 0.0;
-            const double varF = (SFF - SF * SF / nF) / (nF - 1.0);
-            const int o = jc * (NW * 16) + c;
-            w5[0 * J * (NW * 16) + o] = ok ? m1 / n1 : 0.0;
-            w5[1 * J * (NW * 16) + o] = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
-            w5[2 * J * (NW * 16) + o] = ok ? s2x / n2 : 0.0;
-            w5[3 * J * (NW * 16) + o] = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
-            w5[4 * J * (NW * 16) + o] = (varF > 0.0) ? sqrt(varF) : 0.0;
-        }
-        __syncthreads();
-        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
-        const int cw = wave * 16 + (lane & 15), JW = J * (NW * 16);
-        // without the LDS prefetch (more blocks per CU) the tile of Rfull comes from L2, every load
-        // issued before the first store (loads and stores share vmcnt)
-        double rfv[MT][4];
-        if (!pre) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int packed = s_out[m * 16 + kq + 4 * i];
-                    rfv[m][i] = packed < 0 ? 0.0 : se.Rfull[(size_t)(packed >> 20) * ldr + col];
-                }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m * 16 + kq + 4 * i;
-                const int packed = s_out[row];
-                if (packed < 0) continue;
-                const int orow = packed & 0xfffff, t = packed >> 20;
-                const int o = s_mom[row] * (NW * 16) + cw;
-                const double* rc = s_rc + row * 5;
-                if (TAIL && m == MT - 1 && i > 0) continue;
-                const double c1 = (TAIL && m == MT - 1) ? acct : acc[m][i];
-                const double rf = pre ? sRf[t * (NW * 16) + cw] : rfv[m][i];
-                const double cf = rf * rc[4] * w5[4 * JW + o];
-                const double r1 = (c1 - rc[0] * w5[o]) * rc[1] * w5[1 * JW + o];
-                const double r2 = ((cf - c1) - rc[2] * w5[2 * JW + o]) * rc[3] * w5[3 * JW + o];
-                __builtin_nontemporal_store(r1, &Rg[(size_t)orow * ldr]);
-                __builtin_nontemporal_store(r2, &Rg[(size_t)(orow + se.Tpp) * ldr]);
             }
         return;
     }
@@ -921,11 +812,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 sc[i] = mi >= 0 ? sS3[mi * (NW * 16) + cw] : 1.0;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (TAIL && m == MT - 1 && i > 0) break;
-                const double v = (TAIL && m == MT - 1) ? acct : acc[m][i];
-                if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = v * sc[i];
-            }
+            for (int i = 0; i < 4; ++i)
+                if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
         }
         return;
     }
@@ -1078,6 +966,231 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (orow[i] >= 0) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K_RC: compact cross-product blocks -- ONE resample per block, contraction over the rows IT uses
+// ---------------------------------------------------------------------------
+// A bootstrap draws ~63 % of the rows of X (the rest have weight zero), the first half of a split holds
+// S / 2: the dense layout of k_xprod packs ~7 resamples into a 24-tile block and contracts the block over
+// all S rows -- the union of what seven resamples use -- i.e. multiplies 37 - 50 % zeros.  Here a block is
+// one resample (group) x 128 feature columns and contracts over the resample's own rows: the X row behind
+// contraction index k comes from a row table (k_split_rank: rank of the row among the used rows; the A
+// operand is built at the rank, multiplicities folded in), padded with row 0 against zero A columns.
+// What a block of ceil(T'/16) tiles loses against 24 tiles -- X fragments, A fragments and stores per MFMA
+// all go up 6 x -- is halved again by giving every wave TWO 16-column tiles that interleave (lane c holds
+// columns 2c, 2c+1 of the wave's 32): one 16-byte X load and one LDS read of A feed two MFMAs, and the
+// epilogue stores 16 bytes per lane.
+// Block id -> (group, column block): the 8 groups of a sweep go to ONE XCD per column block (slots s, s+1,
+// .. of XCD x: groups 0..7 of column block (s / 8) * 8 + x); their sorted row lists advance together, so
+// each row of the column block comes from HBM about once per sweep and from L2 for the other groups
+// (measured: 11.9 GB fetched per 100 splits against 40 GB of row segments requested).
+// The feature moments come from moment-only blocks of k_xprod (EPI 4 / 6) over all (resample, cell) pairs.
+// EPI 3: R = (A . X) scaled by the 1 / std table (bootstraps; se.scale, se.npairs = cells, se.accB).
+// EPI 5: fused split-half (both halves from the first half's raw sums and the arrangement's full-sample R:
+//        se.Rfull, se.rowc, se.scale / scale2 = raw first-half moments, se.cellS1 / S2, se.cell_len).
+// TAIL: the last tile holds <= 4 live rows and runs on the 4x4x4 shape (16 instead of 64 pipe cycles;
+//       A = the tile's rows 0..3 for every block, B = the X fragment as it is, the result lands where
+//       register 0 of the 16x16 tile would).
+__device__ __forceinline__ d2 load_x2_buf(const double* base, int voff)
+{
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+template <int MT, int KT, int EPI, bool TAIL>
+__global__ __launch_bounds__(256, EPI == 5 ? 3 : 4)
+void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
+                     const double* __restrict__ X, int ldx, int nks,
+                     double* __restrict__ R, int ldr, int rows_per_group,
+                     const int* __restrict__ out_row, const int* __restrict__ mom_idx,
+                     const double* __restrict__ mom_n, int n_groups, int ncolblk, SplitEpi se)
+{
+    static_assert(EPI == 3 || EPI == 5, "compact blocks: bootstrap (3) or fused split-half (5) epilogue");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = 4, NT = NW * 64, BC = NW * 32;       // threads, columns of a block
+    constexpr int STAGE = KT * MT * 64;
+    constexpr int STAGE_LDS = ((STAGE + 127) / 128) * 128;
+    constexpr int PASSES = (STAGE + NT * 2 - 1) / (NT * 2);
+    constexpr bool EVEN = (STAGE % (NT * 2)) == 0;
+    constexpr int MF = TAIL ? MT - 1 : MT;                   // tiles on the 16x16x4 shape
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncb = (ncolblk + 7) & ~7;
+    const int sweep = blockIdx.x / (8 * ncb);
+    const int within = blockIdx.x - sweep * (8 * ncb);
+    const int slot = within >> 3;
+    const int grp = sweep * 8 + (slot & 7);
+    const int colblk = (slot >> 3) * 8 + (within & 7);
+    if (grp >= n_groups || colblk >= ncolblk) return;
+    const int kq = lane >> 4;
+    const int cw = wave * 32 + 2 * (lane & 15);              // this lane's (even) column inside the block
+    const int col = colblk * BC + cw;
+    const bool live = col < ldr;                             // (ldr is a multiple of 64: whole waves)
+    const int lcol = live ? col : 0;
+    const double* Ag = Afrag + (size_t)grp * group_stride;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+
+    d4 acc0[MF > 0 ? MF : 1], acc1[MF > 0 ? MF : 1];
+#pragma unroll
+    for (int m = 0; m < MF; ++m) { acc0[m] = (d4){0.0, 0.0, 0.0, 0.0}; acc1[m] = (d4){0.0, 0.0, 0.0, 0.0}; }
+    double tl0 = 0.0, tl1 = 0.0;
+    const int toff = (lane & 48) + (lane & 3) - lane;        // TAIL: lane 16 k + 4 blk + i -> fragment position 16 k + i
+
+    // any mask / index list is legal: the tables are sized for S rows, the block contracts over its own count
+    const int ksteps = max(1, (se.row_cnt[grp] + 3) >> 2);
+    const int nkt = (ksteps + KT - 1) / KT;
+    int* s_tab = reinterpret_cast<int*>(smem + 2 * STAGE_LDS);
+    for (int i = tid; i < nks * 4; i += NT) s_tab[i] = se.row_tab[(size_t)grp * nks * 4 + i];
+    __syncthreads();
+    auto x_off = [&](int kstep) -> int { return (s_tab[kstep * 4 + kq] * ldx + lcol) * 8; };
+
+    stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag, smem, tid, swave);
+    d2 xb[KT];
+#pragma unroll
+    for (int s = 0; s < KT; ++s) xb[s] = load_x2_buf(X, x_off(s));
+#pragma unroll
+    for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(xb[s]));
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const int kn = min(kt + 1, nkt - 1);
+        d2 xn[KT];
+        stage_copy_buf<NT, PASSES, EVEN, STAGE>(Ag + (size_t)kn * STAGE, smem + (cur ^ 1) * STAGE_LDS, tid, swave);
+#pragma unroll
+        for (int s = 0; s < KT; ++s) xn[s] = load_x2_buf(X, x_off(kn * KT + s));
+        const double* sA = smem + cur * STAGE_LDS + lane;
+#pragma unroll
+        for (int s = 0; s < KT; ++s) {
+            if (kt * KT + s >= ksteps) break;               // (the last stage may be partial)
+            const double b0 = xb[s].x, b1 = xb[s].y;
+#pragma unroll
+            for (int m = 0; m < MF; ++m) {
+                const double a = sA[(s * MT + m) * 64];
+                acc0[m] = mfma_f64(a, b0, acc0[m]);
+                acc1[m] = mfma_f64(a, b1, acc1[m]);
+            }
+            if constexpr (TAIL) {
+                const double a = sA[(s * MT + MT - 1) * 64 + toff];
+                tl0 = mfma_f64_4x4(a, b0, tl0);
+                tl1 = mfma_f64_4x4(a, b1, tl1);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KT; ++s) xb[s] = xn[s];
+        __syncthreads();
+    }
+
+    // value of (tile m, register i), column 0 / 1 of the lane; the tail tile has register 0 only
+    auto val0 = [&](int m, int i) -> double { return (TAIL && m == MT - 1) ? tl0 : acc0[m < MF ? m : 0][i]; };
+    auto val1 = [&](int m, int i) -> double { return (TAIL && m == MT - 1) ? tl1 : acc1[m < MF ? m : 0][i]; };
+
+    if constexpr (EPI == 3) {
+        const int nmu = se.npairs;
+        double* sS3 = smem;                                  // [nmu][BC]
+        int* s_out = reinterpret_cast<int*>(smem + (size_t)nmu * BC);
+        int* s_mom = s_out + MT * 16;
+        const double* sc0 = se.scale + (size_t)grp * nmu * ldr + colblk * BC;
+        for (int idx = tid; idx < nmu * BC; idx += NT) {
+            const int mi = idx / BC, c = idx - mi * BC;
+            sS3[idx] = (colblk * BC + c < ldr) ? sc0[(size_t)mi * ldr + c] : 0.0;
+        }
+        for (int i = tid; i < MT * 16; i += NT) { s_out[i] = out_row[i]; s_mom[i] = mom_idx[i]; }
+        __syncthreads();
+        if (!live) return;
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+        const int rows_valid = min(rows_per_group, se.accB - grp * rows_per_group);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TAIL && m == MT - 1 && i > 0) break;
+                const int row = m * 16 + kq + 4 * i;
+                const int orow = s_out[row], mi = s_mom[row];
+                if (orow < 0 || orow >= rows_valid) continue;
+                d2 sc = (d2){1.0, 1.0};
+                if (mi >= 0) sc = *reinterpret_cast<const d2*>(&sS3[mi * BC + cw]);
+                *reinterpret_cast<d2*>(&Rg[(size_t)orow * ldr]) = (d2){val0(m, i) * sc.x, val1(m, i) * sc.y};
+            }
+        return;
+    } else {
+        const int J = se.J;
+        double* w5 = smem;                                   // u1, v1, u2, v2, sF : [5][J][BC]
+        int* s_out = reinterpret_cast<int*>(smem + (size_t)5 * J * BC);
+        int* s_mom = s_out + MT * 16;
+        double* s_rc = reinterpret_cast<double*>(s_mom + MT * 16);
+        const int pitch2 = 2 * se.Tpp;
+        for (int i = tid; i < MT * 16; i += NT) {
+            const int orw = out_row[i];
+            s_out[i] = orw < 0 ? -1 : (orw | ((orw % pitch2) << 20));
+            s_mom[i] = mom_idx[i];
+        }
+        for (int i = tid; i < MT * 16 * 5; i += NT) s_rc[i] = se.rowc[(size_t)grp * MT * 16 * 5 + i];
+        const int cb0 = colblk * BC;
+        for (int idx = tid; idx < J * BC; idx += NT) {
+            const int jc = idx / BC, c = idx - jc * BC;
+            double u1 = 0, v1 = 0, u2 = 0, v2 = 0, sF = 0;
+            if (cb0 + c < ldr) {
+                const size_t pair = (size_t)grp * J + jc;
+                const double n1 = mom_n[pair];
+                const double m1 = se.scale[pair * ldr + cb0 + c], m2 = se.scale2[pair * ldr + cb0 + c];
+                const double nF = (double)se.cell_len[jc];
+                const double SF = se.cellS1[(size_t)jc * ldr + cb0 + c], SFF = se.cellS2[(size_t)jc * ldr + cb0 + c];
+                const double n2 = nF - n1;
+                const bool ok = n1 > 1.5 && n2 > 1.5;
+                const double var1 = ok ? (m2 - m1 * m1 / n1) / (n1 - 1.0) : 0.0;
+                const double s2x = SF - m1, s2xx = SFF - m2;
+                const double var2 = ok ? (s2xx - s2x * s2x / n2) / (n2 - 1.0) : 0.0;
+                const double varF = (SFF - SF * SF / nF) / (nF - 1.0);
+                u1 = ok ? m1 / n1 : 0.0;
+                v1 = (var1 > 0.0) ? 1.0 / sqrt(var1) : 0.0;
+                u2 = ok ? s2x / n2 : 0.0;
+                v2 = (var2 > 0.0) ? 1.0 / sqrt(var2) : 0.0;
+                sF = (varF > 0.0) ? sqrt(varF) : 0.0;
+            }
+            const int o = jc * BC + c;
+            w5[0 * J * BC + o] = u1; w5[1 * J * BC + o] = v1; w5[2 * J * BC + o] = u2;
+            w5[3 * J * BC + o] = v2; w5[4 * J * BC + o] = sF;
+        }
+        __syncthreads();
+        if (!live) return;
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+        const int JW = J * BC;
+        // the tile of Rfull comes from L2, every load issued before the first store (loads and stores share
+        // vmcnt: a load waited for between stores drains them)
+        d2 rfv[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TAIL && m == MT - 1 && i > 0) break;
+                const int packed = s_out[m * 16 + kq + 4 * i];
+                rfv[m][i] = packed < 0 ? (d2){0.0, 0.0}
+                                       : *reinterpret_cast<const d2*>(&se.Rfull[(size_t)(packed >> 20) * ldr + col]);
+            }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TAIL && m == MT - 1 && i > 0) break;
+                const int row = m * 16 + kq + 4 * i;
+                const int packed = s_out[row];
+                if (packed < 0) continue;
+                const int orow = packed & 0xfffff;
+                const int o = s_mom[row] * BC + cw;
+                const double* rc = s_rc + row * 5;
+                const double rc0 = rc[0], rc1 = rc[1], rc2 = rc[2], rc3 = rc[3], rc4 = rc[4];
+                const d2 u1 = *reinterpret_cast<const d2*>(&w5[o]), v1 = *reinterpret_cast<const d2*>(&w5[JW + o]);
+                const d2 u2 = *reinterpret_cast<const d2*>(&w5[2 * JW + o]), v2 = *reinterpret_cast<const d2*>(&w5[3 * JW + o]);
+                const d2 sF = *reinterpret_cast<const d2*>(&w5[4 * JW + o]);
+                const double c10 = val0(m, i), c11 = val1(m, i);
+                const double cf0 = rfv[m][i].x * rc4 * sF.x, cf1 = rfv[m][i].y * rc4 * sF.y;
+                const d2 r1 = (d2){(c10 - rc0 * u1.x) * rc1 * v1.x, (c11 - rc0 * u1.y) * rc1 * v1.y};
+                const d2 r2 = (d2){((cf0 - c10) - rc2 * u2.x) * rc3 * v2.x, ((cf1 - c11) - rc2 * u2.y) * rc3 * v2.y};
+                __builtin_nontemporal_store(r1, reinterpret_cast<d2*>(&Rg[(size_t)orow * ldr]));
+                __builtin_nontemporal_store(r2, reinterpret_cast<d2*>(&Rg[(size_t)(orow + se.Tpp) * ldr]));
+            }
     }
 }
 

@@ -150,7 +150,7 @@ class PLSC(object):
             from pypyls_amd import parallel
             _, world = parallel.rank_world()
             pmax = parallel.shard_bounds(self.perms, 0, world)[1]
-            rmax = parallel.shard_bounds(self.boots, 0, world)[1]
+            rmax = max(sum(hi - lo for lo, hi in parallel.shard_chunks(self.boots, r, world)) for r in range(world))
         self.pmax, self.rmax = pmax, rmax
         self.out_sv = torch.zeros((pmax, L), dtype=torch.float64, device=dev)
         self.dist_out = torch.zeros((rmax, Tp, L), dtype=torch.float64, device=dev)
@@ -194,8 +194,9 @@ class PLSC(object):
         """One whole analysis, the way the front-end runs it (pypyls_amd/plsc.py): ONE
         RandomState drawn on a host thread in the reference's order -- permutation arrays,
         then bootstrap arrays (every rank draws the same full arrays from the same seed) --
-        while this rank ships its contiguous shard to the device chunk by chunk as the rows
-        become final (resampling.IndexStream), permutations first, then bootstraps; the
+        while this rank ships its shard (permutations: contiguous; bootstraps: chunk-cyclic,
+        parallel.shard_chunks) to the device chunk by chunk as the rows become final
+        (resampling.IndexStream), permutations first, then bootstraps; the
         S x S kernel of the dual permutation route is formed once per analysis."""
         from pypyls_amd import parallel, resampling
         eng = self.eng
@@ -209,9 +210,12 @@ class PLSC(object):
             lo, hi = parallel.shard_bounds(self.perms, rank, world)
             for a, b in ps.chunks(lo, hi):
                 eng.perm_into(eng.rows_tensor(ps.rows[a:b]), self.out_sv[a - lo:b - lo], rotate=True)
-            lo, hi = parallel.shard_bounds(self.boots, rank, world)
-            for a, b in bs.chunks(lo, hi):
-                eng.boot_into(eng.rows_tensor(bs.rows[a:b]), self.usum, self.usq, self.dist_out[a - lo:b - lo])
+            off = 0
+            for lo, hi in parallel.shard_chunks(self.boots, rank, world):      # chunk-cyclic share
+                for a, b in bs.chunks(lo, hi):
+                    eng.boot_into(eng.rows_tensor(bs.rows[a:b]), self.usum, self.usq,
+                                  self.dist_out[off + a - lo:off + b - lo])
+                off += hi - lo
         finally:
             draws.thread.join()
         if draws.error is not None:

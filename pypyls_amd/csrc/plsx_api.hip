@@ -385,6 +385,15 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     return std::max(1, std::min(g, cap));
 }
 
+// Super-batches of a call of n resamples with at most `cap` per launch (cap a multiple of `per_group`): the same
+// number of launches, but of equal size -- 625 bootstraps run as 315 + 310, not 504 + 121 (a launch of 121 costs
+// the latency-bound stages, one wave of the small solver and the moment blocks, as much as one of 504).
+int balanced_batch(int n, int cap, int per_group)
+{
+    const int launches = ceil_div(n, std::max(cap, 1));
+    return std::min(cap, round_up(ceil_div(n, launches), std::max(per_group, 1)));
+}
+
 template <int MT, int NW, int KT, int NSQ>
 int launch_xprod_t(plsx_ctx* ctx, int groups, hipStream_t st)
 {
@@ -1610,7 +1619,7 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->dual) return perm_dual(ctx, d_perm_idx, d_ystack, n, rotate, d_out_sv, st);
     const int pg = ctx->fix ? ctx->npgf : ctx->npg;
-    const int nb = launch_groups(ctx, n, pg) * pg;
+    const int nb = balanced_batch(n, launch_groups(ctx, n, pg) * pg, pg);
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_perm_idx ? d_perm_idx + (size_t)off * ctx->S : nullptr;
@@ -1772,7 +1781,7 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
     if (!ctx->scaled && ctx->dual && ctx->gps == 0 && ctx->L == ctx->Tp && ctx->Tp <= PLSX_JACOBI_TP &&
         2 * (size_t)ctx->L * PLSX_ACC_PITCH * 8 <= 72 * 1024 && !getenv("PLSX_TWO_PASS_BOOT"))
         return boot_single_pass(ctx, d_boot_idx, n, d_usum, d_usq, d_distrib, st);
-    const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;
+    const int nb = balanced_batch(n, launch_groups(ctx, n, ctx->npg) * ctx->npg, ctx->npg);
     for (int off = 0; off < n; off += nb) {
         const int m = std::min(nb, n - off);
         const int* idx = d_boot_idx + (size_t)off * ctx->S;

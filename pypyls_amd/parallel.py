@@ -3,13 +3,13 @@ Multi-GPU sharding of the resampling loops: one process per GPU
 (``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in
 the CPU tests).  Resamples are independent given their index arrays -- the
 reference runs them in independent joblib workers (pyls/base.py:490-507,
-644-650) -- so rank r takes a contiguous slice of the permutations and of the
-bootstraps, every rank holds a full replica of X, and there is exactly ONE
+644-650) -- so rank r takes a contiguous slice of the permutations and a chunk-cyclic
+share of the bootstraps (shard_chunks), every rank holds a full replica of X, and there is exactly ONE
 collective: an all-gather of a packed per-rank buffer
 
     [ perm_singval slice | distrib slice | partial sum U | partial sum U^2 ]
 
-after which every rank concatenates the slices in rank order and adds the
+after which every rank puts the slices back into global order and adds the
 partial sums in rank order (fixed order -> deterministic).
 
 The collective deliberately lives HERE, on ``torch.distributed``, and not in
@@ -68,6 +68,49 @@ def shard_bounds(n, rank, world):
     base, rem = divmod(int(n), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+import os as _os
+
+BOOT_PARTS = int(_os.environ.get('PLSX_BOOT_PARTS', '1'))       # chunks per rank of the bootstrap shards (1 = one contiguous slice).  Chunk-cyclic shards
+                     # (2, 4) were measured on the emulated 8-rank critical path of c4 and LOSE: the last rank's
+                     # bootstraps exist 26 ms into the step instead of 28 (all 10 000 bootstrap rows are drawn in
+                     # 13 ms once the 10 000 permutations are, 17 ms), while every extra launch costs a wave of
+                     # the small solver and a partly filled moment block: 254 ms against 250 (profiles/
+                     # r03_rank_timeline.jsonl).  What the last rank waits for is the PERMUTATION draw, which the
+                     # reference's stream order puts first.
+
+
+def shard_chunks(n, rank, world, parts=None):
+    """Chunk-cyclic shard of n resamples: the rows are cut into world * parts
+    chunks (sizes differ by at most one) and rank r owns chunks r, r + world, ...
+    Returns its [(lo, hi), ...] in ascending order.
+
+    Why not one contiguous slice: every rank draws the FULL index arrays from the
+    shared seed, in the reference's order (permutations, then bootstraps), and can
+    only launch rows that exist.  With contiguous slices the last rank's rows are
+    drawn last -- its device sits idle for the whole draw and then still has its
+    whole shard to do; with cyclic chunks every rank has work after 1 / parts of
+    the draw and only its last chunk (1 / parts of its shard) waits for the end.
+    The bootstrap shards of the front-ends go through this with BOOT_PARTS chunks per
+    rank -- 1 by default (see there: at c4 the draw is too fast for the chunks to pay);
+    world 1 is the single range [0, n)."""
+    n, world = int(n), int(world)
+    if world <= 1:
+        return [(0, n)]
+    total = world * int(BOOT_PARTS if parts is None else parts)
+    out = []
+    for k in range(int(rank), total, world):
+        lo, hi = shard_bounds(n, k, total)
+        if hi > lo:
+            out.append((lo, hi))
+    return out
+
+
+def shard_rows(n, rank, world, parts=None):
+    """Global row numbers of :func:`shard_chunks`, in the rank's local order."""
+    ch = shard_chunks(n, rank, world, parts)
+    return np.concatenate([np.arange(lo, hi) for lo, hi in ch]) if ch else np.zeros(0, dtype=np.int64)
 
 
 def gather_device(slices, sums, device=None):
@@ -129,16 +172,17 @@ def _pad_rows(t, n):
     return torch.cat([t, pad])
 
 
-def collect_slices(slices, totals, sums):
+def collect_slices(slices, totals, sums, cyclic=()):
     """THE collective of a front-end call, on tensors that are already where the
     backend wants them (device tensors under RCCL: the shard results never visit the
     host before the gather).
 
-    slices: torch tensors whose leading axis is this rank's contiguous shard
-            (shard_bounds) of ``totals[i]`` resamples; sums: tensors to add over
-            ranks.  Returns (list of numpy arrays with the FULL leading axis in
-            global order, list of rank-ordered sums as tensors), identical on every
-            rank.  Without a process group nothing moves."""
+    slices: torch tensors whose leading axis is this rank's shard of ``totals[i]``
+            resamples -- contiguous (shard_bounds), or chunk-cyclic in the rank's
+            local order (shard_rows) for the positions listed in ``cyclic``;
+            sums: tensors to add over ranks.  Returns (list of numpy arrays with the
+            FULL leading axis in global order, list of rank-ordered sums as tensors),
+            identical on every rank.  Without a process group nothing moves."""
     import torch
     rank, world = rank_world()
     d = _dist()
@@ -152,13 +196,24 @@ def collect_slices(slices, totals, sums):
                 break
     else:                                   # gloo (CPU tests / single-GPU dry runs)
         device = torch.device('cpu')
-    padded = [(t, shard_bounds(n, 0, world)[1]) for t, n in zip(slices, totals)]
+    cyclic = set(cyclic)
+    counts = []
+    for i, n in enumerate(totals):
+        if i in cyclic:
+            counts.append([sum(hi - lo for lo, hi in shard_chunks(n, r, world)) for r in range(world)])
+        else:
+            counts.append([int(np.diff(shard_bounds(n, r, world))[0]) for r in range(world)])
+    padded = [(t, max(c)) for t, c in zip(slices, counts)]
     got, summed = gather_device(padded, sums, device)
     full = []
-    for blk, n in zip(got, totals):
+    for i, (blk, n) in enumerate(zip(got, totals)):
         host = blk.cpu().numpy()                                        # (world, nmax, ...)
-        full.append(np.concatenate([host[r][:np.diff(shard_bounds(n, r, world))[0]] for r in range(world)],
-                                   axis=0))
+        cat = np.concatenate([host[r][:counts[i][r]] for r in range(world)], axis=0)
+        if i in cyclic:
+            out = np.empty_like(cat)
+            out[np.concatenate([shard_rows(n, r, world) for r in range(world)])] = cat
+            cat = out
+        full.append(cat)
     return full, summed
 
 

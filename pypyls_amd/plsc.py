@@ -182,8 +182,8 @@ class _PLSCRun(object):
         rank, world = parallel.rank_world()
         rotate = bool(inp.get('rotate', True))
 
-        # ---- resampling: this rank's contiguous shard of the permutations and of the
-        # ---- bootstraps, launched chunk by chunk as the index rows arrive; results stay
+        # ---- resampling: this rank's contiguous shard of the permutations and chunk-cyclic share
+        # ---- of the bootstraps, launched chunk by chunk as the index rows arrive; results stay
         # ---- on the device until THE one collective (parallel.collect_slices) ---------
         pstream, bstream, ystack = self.perm_stream, self.boot_stream, self.ystack
         n_perm_tot = pstream.n if pstream is not None else (ystack.shape[0] if ystack is not None else 0)
@@ -198,11 +198,17 @@ class _PLSCRun(object):
             host = eng.perm_ystack(ystack[plo:phi], rotate=rotate) if phi > plo else np.zeros((L, 0))
             d_perm = torch.from_numpy(np.ascontiguousarray(host.T)).to(eng.device)
         if bstream is not None:
-            blo, bhi = parallel.shard_bounds(n_boot_tot, rank, world)
+            # chunk-cyclic share (parallel.shard_chunks): no rank waits for the END of the draw
+            # before its device has anything to do
+            bchunks = parallel.shard_chunks(n_boot_tot, rank, world)
             usum, usq = eng._zeros((eng.B, L)), eng._zeros((eng.B, L))
-            d_dist = eng._zeros((bhi - blo, eng.Tp, L))
-            for a, b in bstream.chunks(blo, bhi):
-                eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq, d_dist[a - blo:b - blo])
+            d_dist = eng._zeros((sum(hi - lo for lo, hi in bchunks), eng.Tp, L))
+            off = 0
+            for blo, bhi in bchunks:
+                for a, b in bstream.chunks(blo, bhi):
+                    eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
+                                  d_dist[off + a - blo:off + b - blo])
+                off += bhi - blo
         # host work that needs no device result runs while the device is busy: the index arrays
         # in the reference's layout and dtype ((S, n) C-contiguous int64)
         permsamp = bootsamp = None
@@ -238,7 +244,9 @@ class _PLSCRun(object):
                 d_perm = torch.cat([d_perm, torch.from_numpy(halves).to(d_perm.device)], dim=1)
             slices.append(d_perm)
             totals.append(n_perm_tot)
+        cyclic = []
         if d_dist is not None:
+            cyclic.append(len(slices))
             slices.append(d_dist)
             totals.append(n_boot_tot)
         cv_splits = self.cv_splits
@@ -253,7 +261,7 @@ class _PLSCRun(object):
             slices.append(torch.from_numpy(np.ascontiguousarray(local_cv)).to(eng.device))
             totals.append(cv_splits.shape[1])
         sums = [usum, usq] if usum is not None else []
-        full, summed = parallel.collect_slices(slices, totals, sums)
+        full, summed = parallel.collect_slices(slices, totals, sums, cyclic=cyclic)
         if usum is not None:
             usum, usq = summed
         k = 0

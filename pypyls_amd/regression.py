@@ -209,7 +209,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     res['x_scores'] = x_scores
     rank, world = parallel.rank_world()
 
-    # this rank's contiguous shards, launched chunk by chunk as the index rows arrive; the
+    # this rank's shards (permutations contiguous, bootstraps chunk-cyclic), launched chunk by chunk as the index rows arrive; the
     # results stay on the device until the one collective
     d_perm = d_yl = usum = usq = None
     n_perm_tot = pstream.n if pstream is not None else 0
@@ -220,20 +220,24 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         for a, b in pstream.chunks(lo, hi):
             eng.simpls_perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - lo:b - lo])
     if bstream is not None:
-        lo, hi = parallel.shard_bounds(n_boot_tot, rank, world)
+        bchunks = parallel.shard_chunks(n_boot_tot, rank, world)     # chunk-cyclic share of the bootstraps
         usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
-        d_yl = eng._zeros((hi - lo, T, k))
-        for a, b in bstream.chunks(lo, hi, first=256, grow=4 if third is None else 1,
-                                   limit=None if third is None else 256):
-            ystack = None
-            if third is not None:
-                # Y aggregated over the resampled third axis, NOT centred
-                # (the reference bootstraps the original Y, regression.py:308-310, 408)
-                ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a, b)])
-                if masked:
-                    ystack = np.nan_to_num(ystack)         # all-NaN rows are dropped by the row masks
-                ystack = eng._dev(ystack, np.float64)
-            eng.simpls_boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq, d_yl[a - lo:b - lo], ystack=ystack)
+        d_yl = eng._zeros((sum(hi - lo for lo, hi in bchunks), T, k))
+        off = 0
+        for lo, hi in bchunks:
+            for a, b in bstream.chunks(lo, hi, first=256, grow=4 if third is None else 1,
+                                       limit=None if third is None else 256):
+                ystack = None
+                if third is not None:
+                    # Y aggregated over the resampled third axis, NOT centred
+                    # (the reference bootstraps the original Y, regression.py:308-310, 408)
+                    ystack = np.stack([agg(Y[..., third[:, i]], axis=-1) for i in range(a, b)])
+                    if masked:
+                        ystack = np.nan_to_num(ystack)         # all-NaN rows are dropped by the row masks
+                    ystack = eng._dev(ystack, np.float64)
+                eng.simpls_boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
+                                     d_yl[off + a - lo:off + b - lo], ystack=ystack)
+            off += hi - lo
     permsamp = bootsamp = None
     if pstream is not None:
         permsamp = np.asarray(permsamples) if permsamples is not None else pstream.samples
@@ -245,7 +249,8 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
             st.warn()
     slices = [t for t in (d_perm, d_yl) if t is not None]
     totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
-    full, summed = parallel.collect_slices(slices, totals, [usum, usq] if usum is not None else [])
+    full, summed = parallel.collect_slices(slices, totals, [usum, usq] if usum is not None else [],
+                                           cyclic=[len(slices) - 1] if d_yl is not None else [])
     if usum is not None:
         usum, usq = summed
     i = 0

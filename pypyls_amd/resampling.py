@@ -396,6 +396,8 @@ class IndexStream(object):
         pos, size = int(lo), int(first)
         while pos < hi:
             want = min(hi, pos + size)
+            if hi - want < size // 2:                   # no tiny last launch: a range of 25 rows costs
+                want = hi                               # the device as much as one of 250
             have = self.wait(want)
             if limit is not None:
                 have = min(have, pos + int(limit))

@@ -103,6 +103,28 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 
 
+def test_shard_chunks_partition():
+    """Chunk-cyclic shards: every row owned once, chunks ascending, world 1 = one range,
+    counts within parts of each other."""
+    from pypyls_amd import parallel
+    assert parallel.shard_chunks(17, 0, 1) == [(0, 17)]
+    for n, w, parts in [(n, w, p) for n in (0, 1, 7, 64, 1000, 10001) for w in (2, 3, 8) for p in (1, 2, 4)]:
+        if True:
+            seen = np.concatenate([parallel.shard_rows(n, r, w, parts) for r in range(w)])
+            assert sorted(seen.tolist()) == list(range(n))
+            counts = [len(parallel.shard_rows(n, r, w, parts)) for r in range(w)]
+            assert max(counts) - min(counts) <= parts
+            for r in range(w):
+                ch = parallel.shard_chunks(n, r, w, parts)
+                assert all(ch[i][1] <= ch[i + 1][0] for i in range(len(ch) - 1))
+                if parts == 1:
+                    assert ch == ([parallel.shard_bounds(n, r, w)] if n > r else []) or n < w
+            if n >= w * parts:
+                # every rank has work within the first 1 / parts of the rows (+ a chunk)
+                first = [parallel.shard_chunks(n, r, w, parts)[0][0] for r in range(w)]
+                assert max(first) <= n // parts
+
+
 _WORKER = r'''
 import os, sys
 import numpy as np
@@ -127,6 +149,14 @@ assert np.array_equal(usum.numpy(), want)
 # permutation-only call
 perm2, d2, u2, q2 = parallel.collect(perm_all[:, lo:hi], P, None, 0, None, None)
 assert np.array_equal(perm2, perm_all) and d2 is None and u2 is None
+# chunk-cyclic shards (the lever behind the bootstraps of the front-ends): rows come back in global order
+parallel.BOOT_PARTS = 2
+for n in (5, 29, 64):
+    rows_all = rs.rand(n, 2, 3)
+    mine = parallel.shard_rows(n, rank, world)
+    full, _ = parallel.collect_slices([torch.from_numpy(perm_all.T[lo:hi].copy()), torch.from_numpy(rows_all[mine])],
+                                      [P, n], [], cyclic=[1])
+    assert np.array_equal(full[0], perm_all.T) and np.array_equal(full[1], rows_all), n
 dist.destroy_process_group()
 print('rank', rank, 'ok')
 '''

@@ -433,6 +433,43 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
     }
 }
 
+// Single-pass bootstraps: the cross-product with an accumulating epilogue (k_xprod EPI 2; A = W_r^T of the
+// group's resamples, 24 tiles, row -> LV map `out_row_w`).  Blocks of 8 waves = 128 feature columns: every block
+// streams the group's whole A operand through LDS, so twice the columns per block is half the A traffic per
+// flop -- at S = 1000 (A = 3 MB per group against the XCD's 4 MB L2, which the X stream keeps evicting) the
+// 64-column blocks re-fetched 20 % of A from HBM: c5 49.8 -> 45.8 ms.  PLSX_EPI2_NW4 keeps the 4-wave blocks.
+int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int groups, int L, hipStream_t st)
+{
+    constexpr int MT = 24, KT = 1;
+    const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
+    SplitEpi se;
+    memset(&se, 0, sizeof(se));
+    se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
+    static const bool narrow = getenv("PLSX_EPI2_NW4") != nullptr;
+    KTimer tm(ctx, KC_XPROD, st);
+    if (!narrow && 2 * (size_t)L * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
+        constexpr int NW = 8;
+        const size_t lds = std::max(stage, (size_t)2 * L * (NW * 16 + 16) * 8 + (size_t)MT * 16 * 4);
+        HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 2>, lds));
+        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
+        hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
+                           Afrag, gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks, (double*)nullptr, ctx->Bpad, 0,
+                           ptr<int>(ctx->out_row_w), (const int*)nullptr, (const double*)nullptr, 0, groups, ncolblk,
+                           (double*)nullptr, se, 1);
+    } else {
+        constexpr int NW = 4;
+        const size_t lds = std::max(stage, (size_t)2 * L * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4);
+        HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 2>, lds));
+        const int ncolblk = ctx->Bpad / (NW * 16);
+        hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
+                           Afrag, gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks, (double*)nullptr, ctx->Bpad, 0,
+                           ptr<int>(ctx->out_row_w), (const int*)nullptr, (const double*)nullptr, 0, groups, ncolblk,
+                           (double*)nullptr, se, 1);
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
 // Fixed-X fast path: A = z-scored (permuted) Y only, X pre-scaled per cell, no
 // moment tiles, 25 M-tiles = 8 resamples of T' = 50 with no padding.
 int run_xprod_fixed(plsx_ctx* ctx, const int* ysrc, int nres, hipStream_t st, const double* ystack)
@@ -1738,23 +1775,7 @@ int boot_single_pass(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_
                                ptr<double>(ctx->Mfrag), ctx->nks_t, ctx->LT, npg_w, MT, ptr<double>(ctx->Afrag), gstride);
             LAUNCHCHK();
         }
-        {
-            constexpr int NW = 4, KT = 1;
-            const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
-            const size_t epi = (size_t)2 * L * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4;
-            const size_t lds = std::max(stage, epi);
-            HIPCHK(set_lds(k_xprod<24, NW, KT, 0, 2>, lds));
-            const int ncolblk = ctx->Bpad / (NW * 16);
-            SplitEpi se;
-            memset(&se, 0, sizeof(se));
-            se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
-            KTimer tm(ctx, KC_XPROD, st);
-            hipLaunchKernelGGL((k_xprod<24, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
-                               ptr<double>(ctx->Afrag), gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
-                               (double*)nullptr, ctx->Bpad, 0, ptr<int>(ctx->out_row_w), (const int*)nullptr,
-                               (const double*)nullptr, 0, groups, ncolblk, (double*)nullptr, se, 1);
-            LAUNCHCHK();
-        }
+        if (int e = launch_xprod_acc(ctx, ptr<double>(ctx->Afrag), gstride, groups, L, st)) return e;
         {
             KTimer tm(ctx, KC_UROT, st);          // the fixed-order sum over groups (what k_urot's splits do)
             const long long count = (long long)ctx->B * L;
@@ -2420,23 +2441,9 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const doubl
                 if (int e = ensure(ctx, ctx->psum, (size_t)groups * ctx->B * k * 8)) return e;
                 if (int e = ensure(ctx, ctx->psq, (size_t)groups * ctx->B * k * 8)) return e;
                 if (ctx->timing) ctx->timed_units += std::min(ms - g0 * npg_w, groups * npg_w);
-                const size_t stage = (size_t)2 * (((size_t)MT * 64 + 127) / 128) * 128 * 8;
-                const size_t epi = (size_t)2 * k * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4;
-                const size_t lds = std::max(stage, epi);
-                HIPCHK(set_lds(k_xprod<24, 4, 1, 0, 2>, lds));
-                const int ncolblk = ctx->Bpad / (NW * 16);
-                SplitEpi se;
-                memset(&se, 0, sizeof(se));
-                se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = k; se.accB = ctx->B;
-                {
-                    KTimer tm(ctx, KC_XPROD, st);
-                    hipLaunchKernelGGL((k_xprod<24, 4, 1, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
-                                       ptr<double>(ctx->Afrag) + (size_t)g0 * ctx->group_stride, ctx->group_stride,
-                                       ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks, (double*)nullptr, ctx->Bpad, 0,
-                                       ptr<int>(ctx->out_row_w), (const int*)nullptr, (const double*)nullptr, 0, groups,
-                                       ncolblk, (double*)nullptr, se, 1);
-                    LAUNCHCHK();
-                }
+                if (int e = launch_xprod_acc(ctx, ptr<double>(ctx->Afrag) + (size_t)g0 * ctx->group_stride, ctx->group_stride,
+                                             groups, k, st))
+                    return e;
                 KTimer tm(ctx, KC_UROT, st);
                 const long long count = (long long)ctx->B * k;
                 hipLaunchKernelGGL(k_add_splits, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st,

@@ -671,7 +671,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     const double* Ag = Afrag + (size_t)grp * group_stride;
     const int swave = __builtin_amdgcn_readfirstlane(wave);
-    const int xvoff = (kq * ldx + col) * 8;            // per-lane byte offset inside a 4-row k-step
+    const int xvoff = (kq * ldx + min(col, ldx - 1)) * 8;   // per-lane byte offset inside a 4-row k-step (a block of
+                                                            // 8 waves may hang over the last 64 columns)
 
     d4 acc[MT];
 #pragma unroll
@@ -818,12 +819,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         return;
     }
     if constexpr (EPI == 2) {
-        // accumulate over the resamples of the group: LDS [2][L][PLSX_ACC_PITCH] (the A stages are dead)
+        // accumulate over the resamples of the group: LDS [2][L][ACCP] (the A stages are dead)
+        constexpr int ACCP = NW * 16 + 16;      // LDS pitch of an l-row (PLSX_ACC_PITCH for 4 waves)
         const int L = se.accL;
         double* sU = smem;
-        double* sV = smem + (size_t)L * PLSX_ACC_PITCH;
-        int* s_l = reinterpret_cast<int*>(sV + (size_t)L * PLSX_ACC_PITCH);
-        for (int i = tid; i < 2 * L * PLSX_ACC_PITCH; i += NT) smem[i] = 0.0;
+        double* sV = smem + (size_t)L * ACCP;
+        int* s_l = reinterpret_cast<int*>(sV + (size_t)L * ACCP);
+        for (int i = tid; i < 2 * L * ACCP; i += NT) smem[i] = 0.0;
         for (int i = tid; i < MT * 16; i += NT) s_l[i] = out_row[i];
         __syncthreads();
         const int cw = wave * 16 + (lane & 15);
@@ -834,8 +836,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
                 const int l = s_l[m * 16 + kq + 4 * i];
                 if (l < 0) continue;
                 const double v = acc[m][i];
-                atomicAdd(&sU[l * PLSX_ACC_PITCH + cw], v);
-                atomicAdd(&sV[l * PLSX_ACC_PITCH + cw], v * v);
+                atomicAdd(&sU[l * ACCP + cw], v);
+                atomicAdd(&sV[l * ACCP + cw], v * v);
             }
         __syncthreads();
         const int b0 = colblk * (NW * 16);
@@ -844,8 +846,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         for (int idx = tid; idx < NW * 16 * L; idx += NT) {
             const int c = idx / L, l = idx - c * L;
             if (b0 + c < se.accB) {
-                ps[(size_t)(b0 + c) * L + l] = sU[l * PLSX_ACC_PITCH + c];
-                pq[(size_t)(b0 + c) * L + l] = sV[l * PLSX_ACC_PITCH + c];
+                ps[(size_t)(b0 + c) * L + l] = sU[l * ACCP + c];
+                pq[(size_t)(b0 + c) * L + l] = sV[l * ACCP + c];
             }
         }
         return;

@@ -555,10 +555,10 @@ int run_xprod_sepmom(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, 
     se.scale = ptr<double>(ctx->scale);
     {
         // moment-only blocks: 12 weight tiles against X, the same 12 against X^2
-        constexpr int NW = 4;
+        constexpr int NW = 8;     // (moment-only blocks of 8 waves: half the A traffic per flop)
         const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
         HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 4>, lds));
-        const int ncolblk = ctx->Bpad / (NW * 16);
+        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
         se.npairs = npairs;
         KTimer tm(ctx, KC_MOM, st);
         hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 4>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
@@ -671,10 +671,10 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
     memset(&se, 0, sizeof(se));
     se.scale = ptr<double>(ctx->scale);
     {
-        constexpr int NW = 4;
+        constexpr int NW = 8;     // (moment-only blocks of 8 waves: half the A traffic per flop)
         const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
         HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 4>, lds));
-        const int ncolblk = ctx->Bpad / (NW * 16);
+        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
         se.npairs = npairs;
         KTimer tm(ctx, KC_MOM, st);
         hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 4>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
@@ -1925,10 +1925,10 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     memset(&se, 0, sizeof(se));
     se.scale = ptr<double>(ctx->m1_c); se.scale2 = ptr<double>(ctx->m2_c);
     {
-        constexpr int NW = 4;
+        constexpr int NW = 4;     // (8-wave blocks, a gain for the 1 / std table of EPI 4, are none here: two raw tables to write)
         const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
         HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 6>, lds));
-        const int ncolblk = ctx->Bpad / (NW * 16);
+        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
         se.npairs = npairs;
         KTimer tm(ctx, KC_MOM, st);
         hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 6>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,

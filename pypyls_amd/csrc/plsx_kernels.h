@@ -757,7 +757,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pair = grp * (NSQ * 16) + j * 16 + kq + 4 * i;
-                if (pair >= se.npairs) continue;
+                if (pair >= se.npairs || col >= ldr) continue;
                 se.scale[(size_t)pair * ldr + col] = acc[j][i];
                 se.scale2[(size_t)pair * ldr + col] = acc[NSQ + j][i];
             }
@@ -773,7 +773,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pair = grp * (NSQ * 16) + j * 16 + kq + 4 * i;
-                if (pair >= se.npairs) continue;
+                if (pair >= se.npairs || col >= ldr) continue;
                 const double m1 = acc[j][i], m2 = acc[NSQ + j][i];
                 const double nn = mom_n[pair];
                 const double var = (m2 - m1 * m1 / nn) / (nn - 1.0);

@@ -953,6 +953,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         }
         __syncthreads();
     }
+    if (NW > 4 && col >= ldr) return;                 // (a block of 8 waves may hang over the last 64 columns)
     double* Rg = R + (size_t)(ntab > 1 ? grp / ntab : grp) * rows_per_group * ldr + col;
 #pragma unroll
     for (int m = 0; m < W0; ++m) {

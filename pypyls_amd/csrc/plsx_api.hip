@@ -615,8 +615,9 @@ int launch_xprod_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStrea
 
 bool compact_boot_ok(const plsx_ctx* ctx)
 {
+    // (LDS of a block: the row table, 4 S bytes, behind the A stages; the scale tile of its cells, 1 KB each)
     if (!(ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 64 && !ctx->mom_out_arg &&
-          ctx->J * 64 * 8 <= 48 * 1024 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31)))
+          ctx->J <= 32 && ctx->S <= 8192 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31)))
         return false;
     static const int force = getenv("PLSX_COMPACT_BOOT_ALWAYS") ? 1 : (getenv("PLSX_NO_COMPACT_BOOT") ? -1 : 0);
     if (force) return force > 0;
@@ -1961,7 +1962,9 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
 int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
                     hipStream_t st, const double* Yarr)
 {
-    if (ctx->Tp <= 64 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) && !getenv("PLSX_SPLIT_INBLOCK"))
+    // (LDS of a compact block: the row table, 4 S bytes; the epilogue's five column tables of every cell, 5 KB each)
+    if (ctx->Tp <= 64 && ctx->J <= 10 && ctx->S <= 8192 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) &&
+        !getenv("PLSX_SPLIT_INBLOCK"))
         return run_split_compact(ctx, perm, masks, m, Rfull, st, Yarr);
     const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
     if (ctx->has_cellS != 1) {

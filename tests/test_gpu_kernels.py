@@ -345,13 +345,14 @@ np.savez(sys.argv[1], R=R, usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=
 
 
 @pytest.mark.parametrize('shape', [(64, 3001, 50, [64], 1), (60, 2500, 10, [15, 15], 2), (90, 1300, 7, [10, 12, 8], 3),
-                                   (60, 800, 20, [60], 1), (40, 700, 8, [40], 1), (160, 900, 33, [80], 2)])
+                                   (60, 800, 20, [60], 1), (40, 700, 8, [40], 1), (160, 900, 33, [80], 2), (96, 700, 3, [6, 6, 6, 6], 4)])
 def test_compact_blocks_equal_dense_blocks(shape):
     """Compact cross-product blocks -- one bootstrap per block contracting over the DISTINCT rows it draws
     (k_xprod IDX row table, multiplicities folded into A; last tile on the 4x4x4 shape when it holds <= 4
     rows: T' = 50, 20, 33 x 2 = 66 -> not compact) -- and one split per block over its first half
     (PLSX_SPLIT_INBLOCK = the 7-per-block fused layout) against the dense layouts: bootstrap sums, distrib,
-    split-half correlations.  Every tile count 1..4, with and without the tail, J = 1..9 cells.
+    split-half correlations.  Every tile count 1..4, with and without the tail, J = 1..16 cells (16 cells:
+    compact bootstraps, but the split-half epilogue's column tables no longer fit: dense fused layout).
     Own processes: the switches are read once."""
     import json
     import os

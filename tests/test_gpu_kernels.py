@@ -380,8 +380,27 @@ perms = rsmp.gen_permsamp(groups, n_cond, 2, seed=6)
 uc, vc = eng.split_half(masks)
 m3 = np.stack([rsmp.gen_splits(groups, n_cond, 5, seed=40 + i) for i in range(2)])
 ucp, vcp = eng.split_half(m3, perms=perms)
+# lopsided masks (any mask is legal through the C ABI): a first half of nearly all rows, one of three rows
+# per cell, one that misses a cell entirely (NaN, as the dense layout gives)
+cells = rsmp.cell_of_row(groups, n_cond)
+odd = np.array(masks[:, :3], dtype=bool)
+odd[:, 0] = True
+odd[:, 1] = False
+for j in np.unique(cells):
+    rows = np.flatnonzero(cells == j)
+    odd[rows[:2], 0] = False
+    odd[rows[:3], 1] = True
+    if j == 0:
+        odd[rows, 2] = False
+uco, vco = eng.split_half(odd)
+# bootstraps that draw very few distinct rows (every cell: two subjects, over and over)
+few = np.array(boots[:, :6])
+for j in np.unique(cells):
+    rows = np.flatnonzero(cells == j)
+    few[rows, :] = rows[:2][np.arange(len(rows))[:, None] %% 2 * np.ones((1, 6), dtype=int)]
+usum2, usq2, dist2 = eng.boot(few)
 np.savez(sys.argv[1], usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist, uc=uc, vc=vc, ucp=ucp, vcp=vcp,
-         compact=cf)
+         compact=cf, uco=uco, vco=vco, usum2=usum2.cpu().numpy(), usq2=usq2.cpu().numpy(), dist2=dist2)
 """ % (ROOT, shape)
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -398,3 +417,10 @@ np.savez(sys.argv[1], usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist,
     assert float(out['dense']['compact']) == 0.0
     for k in ('usum', 'usq', 'dist', 'uc', 'vc', 'ucp', 'vcp'):
         assert_close(out['compact'][k], out['dense'][k], 1e-10, what='compact vs dense blocks: ' + k)
+    for k in ('uco', 'vco', 'usum2', 'usq2', 'dist2'):
+        a, b = out['compact'][k], out['dense'][k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), 'NaN pattern of ' + k
+        ok = ~np.isnan(b)
+        if ok.any():
+            scale = np.max(np.abs(b[ok]))
+            assert np.max(np.abs(a[ok] - b[ok])) <= 1e-8 * scale, 'lopsided resamples, compact vs dense: ' + k

@@ -1003,7 +1003,7 @@ __device__ __forceinline__ d2 load_x2_buf(const double* base, int voff)
 }
 
 template <int MT, int KT, int EPI, bool TAIL>
-__global__ __launch_bounds__(256, EPI == 5 ? 3 : 4)
+__global__ __launch_bounds__(256, EPI == 5 ? 3 : (MT > 6 ? 2 : (MT > 4 ? 3 : 4)))
 void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
                      const double* __restrict__ X, int ldx, int nks,
                      double* __restrict__ R, int ldr, int rows_per_group,

@@ -10,7 +10,10 @@
 // index so HBM accesses are row-contiguous.
 //
 //   k_xprod      R = scale o (A . X)          (n*T' x S) . (S x B)     "K_R"
-//                (+ split-half epilogue: both halves from one pass)
+//                (+ split-half epilogue: both halves from one pass; accumulating
+//                epilogue of the single-pass bootstraps; moment-only blocks)
+//   k_xprod_compact   the same product for ONE bootstrap / split per block,
+//                contracted over the rows it uses (row table)          "K_RC"
 //   k_gram4      bootstrap Gram G = R R^T (upper blocks) and P = R U0 on
 //                v_mfma_f64_4x4x4_4b_f64 (4-row granularity)           "K_G"
 //   k_gram / k_nt_gemm   the same products on 16x16x4 tiles (T' > 52, G only,

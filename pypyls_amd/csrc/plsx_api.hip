@@ -591,7 +591,7 @@ int ensure_compact_maps(plsx_ctx* ctx)
     return 0;
 }
 
-// Compact bootstraps (correlation mode, T' <= 192): a bootstrap draws ~63 % of the rows of X; the 7-per-block
+// Compact bootstraps (correlation mode, T' <= 208): a bootstrap draws ~63 % of the rows of X; the 7-per-block
 // layout contracts every block over all S rows (the union of seven draws), i.e. multiplies 37 % zeros.
 // Here every bootstrap has a block of its own that contracts over the rows it draws (k_xprod IDX: row table,
 // multiplicities folded into A), scaled by the 1 / std table of the moment-only blocks as in the
@@ -616,7 +616,7 @@ int launch_xprod_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStrea
 bool compact_boot_ok(const plsx_ctx* ctx)
 {
     // (LDS of a block: the row table, 4 S bytes, behind the A stages; the scale tile of its cells, 1 KB each)
-    if (!(ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 192 && !ctx->mom_out_arg &&
+    if (!(ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 208 && !ctx->mom_out_arg &&
           ctx->J <= 32 && ctx->S <= 8192 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31)))
         return false;
     static const int force = getenv("PLSX_COMPACT_BOOT_ALWAYS") ? 1 : (getenv("PLSX_NO_COMPACT_BOOT") ? -1 : 0);
@@ -697,12 +697,12 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
                             : launch_xprod_cboot<3, 4>(ctx, nres, nks_c, se, st);
         case 4: return tail ? launch_xprod_cboot<4, 3, true>(ctx, nres, nks_c, se, st)
                             : launch_xprod_cboot<4, 3>(ctx, nres, nks_c, se, st);
-        // 64 < T' <= 192: 5 .. 12 tiles, 3 or 2 waves per SIMD (the accumulators of two column tiles)
+        // 64 < T' <= 208: 5 .. 13 tiles, 3 or 2 waves per SIMD (the accumulators of two column tiles)
 #define PLSX_CB(M, K) case M: return tail ? launch_xprod_cboot<M, K, true>(ctx, nres, nks_c, se, st) \
                                           : launch_xprod_cboot<M, K>(ctx, nres, nks_c, se, st);
-        PLSX_CB(5, 2) PLSX_CB(6, 2) PLSX_CB(7, 1) PLSX_CB(8, 1) PLSX_CB(9, 1) PLSX_CB(10, 1) PLSX_CB(11, 1) PLSX_CB(12, 1)
+        PLSX_CB(5, 2) PLSX_CB(6, 2) PLSX_CB(7, 1) PLSX_CB(8, 1) PLSX_CB(9, 1) PLSX_CB(10, 1) PLSX_CB(11, 1) PLSX_CB(12, 1) PLSX_CB(13, 1)
 #undef PLSX_CB
-        default: return fail(ctx, PLSX_ERR_STATE, "compact bootstrap blocks: T' > 192");
+        default: return fail(ctx, PLSX_ERR_STATE, "compact bootstrap blocks: T' > 208");
     }
 }
 

@@ -346,11 +346,11 @@ np.savez(sys.argv[1], R=R, usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=
 
 @pytest.mark.parametrize('shape', [(64, 3001, 50, [64], 1), (60, 2500, 10, [15, 15], 2), (90, 1300, 7, [10, 12, 8], 3),
                                    (60, 800, 20, [60], 1), (40, 700, 8, [40], 1), (160, 900, 33, [80], 2), (96, 700, 3, [6, 6, 6, 6], 4),
-                                   (130, 900, 100, [130], 1), (150, 800, 60, [75], 2), (200, 600, 180, [200], 1)])
+                                   (130, 900, 100, [130], 1), (150, 800, 60, [75], 2), (200, 600, 180, [200], 1), (240, 500, 200, [240], 1)])
 def test_compact_blocks_equal_dense_blocks(shape):
     """Compact cross-product blocks -- one bootstrap per block contracting over the DISTINCT rows it draws
     (k_xprod IDX row table, multiplicities folded into A; last tile on the 4x4x4 shape when it holds <= 4
-    rows: T' = 50, 20, 100; bootstraps up to T' = 192 = 12 tiles, split-half up to 64) -- and one split per block over its first half
+    rows: T' = 50, 20, 100; bootstraps up to T' = 208 = 13 tiles, split-half up to 64) -- and one split per block over its first half
     (PLSX_SPLIT_INBLOCK = the 7-per-block fused layout) against the dense layouts: bootstrap sums, distrib,
     split-half correlations.  Every tile count 1..4, with and without the tail, J = 1..16 cells (16 cells:
     compact bootstraps, but the split-half epilogue's column tables no longer fit: dense fused layout).
@@ -413,7 +413,7 @@ np.savez(sys.argv[1], usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist,
             assert proc.returncode == 0, proc.stderr[-2000:]
             out[key] = dict(np.load(path))
     S, B, T, groups, n_cond = shape
-    if T * len(groups) * n_cond <= 192:
+    if T * len(groups) * n_cond <= 208:
         assert 0.5 < float(out['compact']['compact']) < 0.8, 'the compact layout did not run'
     assert float(out['dense']['compact']) == 0.0
     for k in ('usum', 'usq', 'dist', 'uc', 'vc', 'ucp', 'vcp'):

@@ -576,6 +576,46 @@ int run_xprod_sepmom(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, 
     }
 }
 
+// Moment-only blocks of a launch of `npairs` (resample, cell) pairs: 192 pairs per block (12 + 12 tiles) or 128
+// (8 + 8), whichever issues fewer tiles -- 100 pairs (a split-half pass): 16 instead of 24, 504: 64 instead of 72.
+struct MomLayout { int pairs, mt, groups; size_t stride; };
+MomLayout moment_layout(const plsx_ctx* ctx, int npairs)
+{
+    const int t192 = ceil_div(npairs, 192) * 24, t128 = ceil_div(npairs, 128) * 16;
+    MomLayout m;
+    m.pairs = (t128 * 6 < t192 * 5) ? 128 : 192;        // (a 16-tile block is ~10 % slower per tile: 504 pairs, 64 vs 72 tiles, measured no gain)
+    m.mt = m.pairs / 8;
+    m.groups = ceil_div(npairs, m.pairs);
+    m.stride = (size_t)ctx->nks * m.mt * 64;
+    return m;
+}
+
+// EPI 4 (1 / std table) or EPI 6 (raw m1, m2) over the layout above; 8-wave blocks for the single table.
+template <int EPI>
+int launch_moment_blocks(plsx_ctx* ctx, const MomLayout& ml, SplitEpi se, hipStream_t st)
+{
+    constexpr int NW = (EPI == 4) ? 8 : 4;
+    const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
+    KTimer tm(ctx, KC_MOM, st);
+    if (ml.mt == 24) {
+        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
+        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, EPI>, lds));
+        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, EPI>), dim3(ncolblk * round_up(ml.groups, 8)), dim3(NW * 64), lds, st,
+                           ptr<double>(ctx->Afrag_m), ml.stride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                           ptr<double>(ctx->momn_m), 0, ml.groups, ncolblk, (double*)nullptr, se, 1);
+    } else {
+        const size_t lds = (size_t)2 * (((size_t)16 * 64 + 127) / 128) * 128 * 8;
+        HIPCHK(set_lds(k_xprod<16, NW, 1, 8, EPI>, lds));
+        hipLaunchKernelGGL((k_xprod<16, NW, 1, 8, EPI>), dim3(ncolblk * round_up(ml.groups, 8)), dim3(NW * 64), lds, st,
+                           ptr<double>(ctx->Afrag_m), ml.stride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                           ptr<double>(ctx->momn_m), 0, ml.groups, ncolblk, (double*)nullptr, se, 1);
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
 // Row maps of a compact block (one resample / split per group): data row t -> R row t, moment index = its cell.
 int ensure_compact_maps(plsx_ctx* ctx)
 {
@@ -637,15 +677,17 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
 {
     const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = std::max(1, 12 / MTc);      // (two column tiles per wave)
     const int nks_c = round_up(ceil_div(S, 4), KT);
-    const int npairs = nres * J, groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
-    const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;
+    const int npairs = nres * J;
+    const MomLayout ml = moment_layout(ctx, npairs);
+    const int groups_m = ml.groups;
+    const size_t astride = (size_t)nks_c * MTc * 64, mstride = ml.stride;
     if (int e = ensure_compact_maps(ctx)) return e;
     if (int e = ensure(ctx, ctx->Afrag_c, (size_t)nres * astride * 8 + 4096)) return e;
     if (int e = ensure(ctx, ctx->mask_c, (size_t)nres * S)) return e;
     if (int e = ensure(ctx, ctx->rank_c, (size_t)nres * S * sizeof(int))) return e;
     if (int e = ensure(ctx, ctx->rowtab_c, ((size_t)nres * nks_c * 4 + nres) * sizeof(int))) return e;
     if (int e = ensure(ctx, ctx->Afrag_m, (size_t)groups_m * mstride * 8 + 4096)) return e;
-    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, PLSX_MOM_PAIRS) * 8)) return e;
+    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, 192) * 8)) return e;
     if (int e = ensure(ctx, ctx->scale, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
     HIPCHK(hipMemsetAsync(ctx->Afrag_c.p, 0, (size_t)nres * astride * 8, st));
     HIPCHK(hipMemsetAsync(ctx->Afrag_m.p, 0, (size_t)groups_m * mstride * 8, st));
@@ -665,25 +707,14 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
                            ystack ? ystack : ptr<double>(ctx->Y), ystack ? ystride : 0LL, ctx->T, S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay, ctx->cov, 1,
                            ptr<double>(ctx->Afrag_c), astride, ptr<double>(ctx->momn_m), 0, 0,
-                           ptr<double>(ctx->Afrag_m), mstride, ptr<int>(ctx->rank_c));
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<int>(ctx->rank_c), ml.pairs);
         LAUNCHCHK();
     }
     SplitEpi se;
     memset(&se, 0, sizeof(se));
     se.scale = ptr<double>(ctx->scale);
-    {
-        constexpr int NW = 8;     // (moment-only blocks of 8 waves: half the A traffic per flop)
-        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
-        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 4>, lds));
-        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
-        se.npairs = npairs;
-        KTimer tm(ctx, KC_MOM, st);
-        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 4>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
-                           ptr<double>(ctx->Afrag_m), mstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
-                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
-                           ptr<double>(ctx->momn_m), 0, groups_m, ncolblk, (double*)nullptr, se, 1);
-        LAUNCHCHK();
-    }
+    se.npairs = npairs;
+    if (int e = launch_moment_blocks<4>(ctx, ml, se, st)) return e;
     se.npairs = J;
     se.accB = nres * ctx->Tpp;
     se.row_tab = ptr<int>(ctx->rowtab_c);
@@ -1901,15 +1932,18 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     if (int e = ensure_compact_maps(ctx)) return e;
     // the tables are sized for a first half of all S rows; a block contracts over its own count
     const int nks_c = round_up(ceil_div(S, 4), KT);
-    const size_t astride = (size_t)nks_c * MTc * 64, mstride = (size_t)ctx->nks * 24 * 64;
-    const int npairs = m * J, groups_m = ceil_div(npairs, PLSX_MOM_PAIRS);
+    const size_t astride = (size_t)nks_c * MTc * 64;
+    const int npairs = m * J;
+    const MomLayout ml = moment_layout(ctx, npairs);
+    const int groups_m = ml.groups;
+    const size_t mstride = ml.stride;
     if (int e = ensure_scratch(ctx, std::min(ctx->Gcap, ceil_div(2 * m, ctx->npg)))) return e;
     if ((size_t)2 * m * ctx->strideR * 8 > ctx->R.bytes) return fail(ctx, PLSX_ERR_STATE, "compact split: R scratch too small");
     if (int e = ensure(ctx, ctx->Afrag_c, (size_t)m * astride * 8 + 4096)) return e;
     if (int e = ensure(ctx, ctx->rank_c, (size_t)m * S * sizeof(int))) return e;
     if (int e = ensure(ctx, ctx->rowtab_c, ((size_t)m * nks_c * 4 + m) * sizeof(int))) return e;
     if (int e = ensure(ctx, ctx->Afrag_m, (size_t)groups_m * mstride * 8 + 4096)) return e;
-    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, PLSX_MOM_PAIRS) * 8)) return e;
+    if (int e = ensure(ctx, ctx->momn_m, (size_t)round_up(npairs, 192) * 8)) return e;
     if (int e = ensure(ctx, ctx->m1_c, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
     if (int e = ensure(ctx, ctx->m2_c, (size_t)round_up(npairs, 8) * ctx->Bpad * 8)) return e;
     if (int e = ensure(ctx, ctx->rowc, ((size_t)m * rows * 5 + 256) * 8)) return e;
@@ -1926,25 +1960,14 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
         hipLaunchKernelGGL(k_build_A_split, dim3(m, J), dim3(256), 0, st, Yarr ? Yarr : ptr<double>(ctx->Y), ctx->T, S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), perm, masks, lay,
                            ptr<double>(ctx->Afrag_c), astride, ptr<double>(ctx->momn_m), 0, ptr<double>(ctx->rowc),
-                           ptr<int>(ctx->rank_c), ptr<double>(ctx->Afrag_m), mstride);
+                           ptr<int>(ctx->rank_c), ptr<double>(ctx->Afrag_m), mstride, ml.pairs);
         LAUNCHCHK();
     }
     SplitEpi se;
     memset(&se, 0, sizeof(se));
     se.scale = ptr<double>(ctx->m1_c); se.scale2 = ptr<double>(ctx->m2_c);
-    {
-        constexpr int NW = 4;     // (8-wave blocks, a gain for the 1 / std table of EPI 4, are none here: two raw tables to write)
-        const size_t lds = (size_t)2 * (((size_t)24 * 64 + 127) / 128) * 128 * 8;
-        HIPCHK(set_lds(k_xprod<24, NW, 1, 12, 6>, lds));
-        const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
-        se.npairs = npairs;
-        KTimer tm(ctx, KC_MOM, st);
-        hipLaunchKernelGGL((k_xprod<24, NW, 1, 12, 6>), dim3(ncolblk * round_up(groups_m, 8)), dim3(NW * 64), lds, st,
-                           ptr<double>(ctx->Afrag_m), mstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
-                           (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
-                           (const double*)nullptr, 0, groups_m, ncolblk, (double*)nullptr, se, 1);
-        LAUNCHCHK();
-    }
+    se.npairs = npairs;
+    if (int e = launch_moment_blocks<6>(ctx, ml, se, st)) return e;     // (4-wave blocks: two raw tables to write)
     se.Rfull = Rfull;
     se.cellS1 = ptr<double>(ctx->cellS);
     se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;

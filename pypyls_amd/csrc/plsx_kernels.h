@@ -169,8 +169,9 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
                                 double* __restrict__ Afrag, size_t group_stride,
                                 double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0,
                                 double* __restrict__ Amom = nullptr, size_t mom_stride = 0,
-                                const int* __restrict__ rank = nullptr)
+                                const int* __restrict__ rank = nullptr, int mom_pairs = PLSX_MOM_PAIRS)
 {
+    // mom_pairs: pairs per moment-only block (192 = 12 + 12 tiles, or 128 = 8 + 8 when that issues fewer tiles)
     // rank != nullptr (compact layout, one resample per group, with Amom): the contraction index of source
     // row xi is its rank among the rows the resample draws (k_split_rank over k_drawn_mask); the weight
     // rows keep the subject index (moment-only blocks contract over all of X).
@@ -260,14 +261,14 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
         }
     } else if (scaled && Amom) {
         const int pair = r * lay.J + j;
-        double* Am = Amom + (size_t)(pair / PLSX_MOM_PAIRS) * mom_stride;
-        const int mrow = pair % PLSX_MOM_PAIRS;
+        double* Am = Amom + (size_t)(pair / mom_pairs) * mom_stride;
+        const int mrow = pair % mom_pairs, mmt = mom_pairs / 8;
         for (int pl = tid; pl < len; pl += blockDim.x) {
             int p = start + pl;
             int xi = xs ? xs[p] : p;
             if (xi < 0) continue;
-            atomicAdd(Am + afrag_off(mrow, xi, 24), 1.0);
-            atomicAdd(Am + afrag_off(PLSX_MOM_PAIRS + mrow, xi, 24), 1.0);
+            atomicAdd(Am + afrag_off(mrow, xi, mmt), 1.0);
+            atomicAdd(Am + afrag_off(mom_pairs + mrow, xi, mmt), 1.0);
         }
         if (tid == 0) mom_n[pair] = (double)cnt;
     } else if (scaled) {
@@ -433,7 +434,7 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
                      GroupLayout lay, double* __restrict__ Afrag, size_t group_stride,
                      double* __restrict__ mom_n, int nmom_pad, double* __restrict__ rowc,
                      const int* __restrict__ rank = nullptr, double* __restrict__ Amom = nullptr,
-                     size_t mom_stride = 0)
+                     size_t mom_stride = 0, int mom_pairs = PLSX_MOM_PAIRS)
 {
     // rank != nullptr (compact layout, one split per group): the contraction index of position p is
     // its rank among the split's first-half rows (k_split_rank), and the weight rows of pair
@@ -509,13 +510,13 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
     }
     if (rank) {
         const int pair = i * lay.J + j;
-        double* Am = Amom + (size_t)(pair / PLSX_MOM_PAIRS) * mom_stride;
-        const int mrow = pair % PLSX_MOM_PAIRS;
+        double* Am = Amom + (size_t)(pair / mom_pairs) * mom_stride;
+        const int mrow = pair % mom_pairs, mmt = mom_pairs / 8;
         for (int pl = tid; pl < len; pl += blockDim.x) {
             const int p = start + pl;
             if (!mk[p]) continue;
-            Am[afrag_off(mrow, p, 24)] = 1.0;
-            Am[afrag_off(PLSX_MOM_PAIRS + mrow, p, 24)] = 1.0;
+            Am[afrag_off(mrow, p, mmt)] = 1.0;
+            Am[afrag_off(mom_pairs + mrow, p, mmt)] = 1.0;
         }
         if (tid == 0) mom_n[pair] = (double)s_n1;
         return;

@@ -2123,6 +2123,12 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
                 // feature-axis sums of E_h = D_h^T . vd
                 const int ntile = ceil_div(ctx->B, 16);
                 int nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
+                {
+                    // whole rounds of resident blocks: 100 splits x 21 chunks = 4.1 rounds of 512 left the chip
+                    // nearly empty for a fifth of the kernel
+                    static const int slots = chip_slots(reinterpret_cast<const void*>(k_ucorr_partial<4, 13, true>));
+                    nchunk = pick_parts(m, slots, std::max(1, (nchunk * 2) / 3), std::min(std::max(1, ntile / 8), 2 * nchunk));
+                }
                 const int tpc = ceil_div(ntile, nchunk);
                 nchunk = ceil_div(ntile, tpc);
                 const int lpad = ctx->LT * 16;

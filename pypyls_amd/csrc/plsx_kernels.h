@@ -1007,7 +1007,7 @@ __device__ __forceinline__ d2 load_x2_buf(const double* base, int voff)
 }
 
 template <int MT, int KT, int EPI, bool TAIL>
-__global__ __launch_bounds__(256, EPI == 5 ? 3 : (MT > 6 ? 2 : (MT > 4 ? 3 : 4)))
+__global__ __launch_bounds__(256, MT > 6 ? 2 : ((MT > 4 || (EPI == 5 && MT == 4 && !TAIL)) ? 3 : 4))
 void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
                      const double* __restrict__ X, int ldx, int nks,
                      double* __restrict__ R, int ldr, int rows_per_group,
@@ -1164,18 +1164,11 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
         if (!live) return;
         double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
         const int JW = J * BC;
-        // the tile of Rfull comes from L2, every load issued before the first store (loads and stores share
-        // vmcnt: a load waited for between stores drains them)
-        d2 rfv[MT][4];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (TAIL && m == MT - 1 && i > 0) break;
-                const int packed = s_out[m * 16 + kq + 4 * i];
-                rfv[m][i] = packed < 0 ? (d2){0.0, 0.0}
-                                       : *reinterpret_cast<const d2*>(&se.Rfull[(size_t)(packed >> 20) * ldr + col]);
-            }
+        // Phase A: the first halves -- they need no Rfull -- go out first, 13 stores with nothing to wait for.
+        // Phase B: the second halves in batches of two tiles; a batch's eight Rfull loads (L2) are issued
+        // together and waited for once (loads and stores share vmcnt, so that wait also drains the stores before
+        // it: one round trip per batch, covered by the other waves of the SIMD).  Holding the whole Rfull tile
+        // in registers next to the accumulators (one wait per block) cost 168 VGPRs = 3 waves per SIMD.
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -1184,20 +1177,45 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
                 const int row = m * 16 + kq + 4 * i;
                 const int packed = s_out[row];
                 if (packed < 0) continue;
-                const int orow = packed & 0xfffff;
                 const int o = s_mom[row] * BC + cw;
-                const double* rc = s_rc + row * 5;
-                const double rc0 = rc[0], rc1 = rc[1], rc2 = rc[2], rc3 = rc[3], rc4 = rc[4];
+                const double rc0 = s_rc[row * 5], rc1 = s_rc[row * 5 + 1];
                 const d2 u1 = *reinterpret_cast<const d2*>(&w5[o]), v1 = *reinterpret_cast<const d2*>(&w5[JW + o]);
-                const d2 u2 = *reinterpret_cast<const d2*>(&w5[2 * JW + o]), v2 = *reinterpret_cast<const d2*>(&w5[3 * JW + o]);
-                const d2 sF = *reinterpret_cast<const d2*>(&w5[4 * JW + o]);
-                const double c10 = val0(m, i), c11 = val1(m, i);
-                const double cf0 = rfv[m][i].x * rc4 * sF.x, cf1 = rfv[m][i].y * rc4 * sF.y;
-                const d2 r1 = (d2){(c10 - rc0 * u1.x) * rc1 * v1.x, (c11 - rc0 * u1.y) * rc1 * v1.y};
-                const d2 r2 = (d2){((cf0 - c10) - rc2 * u2.x) * rc3 * v2.x, ((cf1 - c11) - rc2 * u2.y) * rc3 * v2.y};
-                __builtin_nontemporal_store(r1, reinterpret_cast<d2*>(&Rg[(size_t)orow * ldr]));
-                __builtin_nontemporal_store(r2, reinterpret_cast<d2*>(&Rg[(size_t)(orow + se.Tpp) * ldr]));
+                const d2 r1 = (d2){(val0(m, i) - rc0 * u1.x) * rc1 * v1.x, (val1(m, i) - rc0 * u1.y) * rc1 * v1.y};
+                __builtin_nontemporal_store(r1, reinterpret_cast<d2*>(&Rg[(size_t)(packed & 0xfffff) * ldr]));
             }
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+            asm volatile("" ::: "memory");          // (keeps hipcc from hoisting this batch's loads over the stores above:
+            d2 rfv[2][4];                           //  that is the all-in-registers form again)
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + mm;
+                    if (m >= MT || (TAIL && m == MT - 1 && i > 0)) break;
+                    const int packed = s_out[m * 16 + kq + 4 * i];
+                    rfv[mm][i] = packed < 0 ? (d2){0.0, 0.0}
+                                            : *reinterpret_cast<const d2*>(&se.Rfull[(size_t)(packed >> 20) * ldr + col]);
+                }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + mm;
+                    if (m >= MT || (TAIL && m == MT - 1 && i > 0)) break;
+                    const int row = m * 16 + kq + 4 * i;
+                    const int packed = s_out[row];
+                    if (packed < 0) continue;
+                    const int o = s_mom[row] * BC + cw;
+                    const double rc2 = s_rc[row * 5 + 2], rc3 = s_rc[row * 5 + 3], rc4 = s_rc[row * 5 + 4];
+                    const d2 u2 = *reinterpret_cast<const d2*>(&w5[2 * JW + o]), v2 = *reinterpret_cast<const d2*>(&w5[3 * JW + o]);
+                    const d2 sF = *reinterpret_cast<const d2*>(&w5[4 * JW + o]);
+                    const double c10 = val0(m, i), c11 = val1(m, i);
+                    const double cf0 = rfv[mm][i].x * rc4 * sF.x, cf1 = rfv[mm][i].y * rc4 * sF.y;
+                    const d2 r2 = (d2){((cf0 - c10) - rc2 * u2.x) * rc3 * v2.x, ((cf1 - c11) - rc2 * u2.y) * rc3 * v2.y};
+                    __builtin_nontemporal_store(r2, reinterpret_cast<d2*>(&Rg[(size_t)((packed & 0xfffff) + se.Tpp) * ldr]));
+                }
+        }
     }
 }
 

@@ -279,6 +279,8 @@ class PLSC(object):
                'avg_launch_ms': avg_ms, 'launches': launches, 'resamples_per_launch': units}
         crow = tm.get('compact_row_fraction', 0.0)
         if crow > 0:
+            out['kernel'] = out['kernel'].replace('k_xprod<', 'k_xprod_compact<', 1).replace(
+                'data-only blocks', 'one bootstrap per block, contraction over the rows it draws')
             # compact blocks: one bootstrap per block, contraction over the DISTINCT rows it draws (k-steps of
             # 4 rows), T' rows on ceil(T'/16) tiles whose last one runs on the 4x4x4 shape when it holds <= 4
             mt = -(-Tp // 16)

@@ -994,7 +994,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 // each row of the column block comes from HBM about once per sweep and from L2 for the other groups
 // (measured: 11.9 GB fetched per 100 splits against 40 GB of row segments requested).
 // The feature moments come from moment-only blocks of k_xprod (EPI 4 / 6) over all (resample, cell) pairs.
-// EPI 3: R = (A . X) scaled by the 1 / std table (bootstraps; se.scale, se.npairs = cells, se.accB).
+// EPI 3: R = (A . X) scaled by the 1 / std table (bootstraps; se.scale, se.npairs = cells, se.accB); MT up to 13
+//        tiles (T' <= 208) at 3 or 2 waves per SIMD.
 // EPI 5: fused split-half (both halves from the first half's raw sums and the arrangement's full-sample R:
 //        se.Rfull, se.rowc, se.scale / scale2 = raw first-half moments, se.cellS1 / S2, se.cell_len).
 // TAIL: the last tile holds <= 4 live rows and runs on the 4x4x4 shape (16 instead of 64 pipe cycles;

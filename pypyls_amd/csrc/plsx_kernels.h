@@ -2660,7 +2660,7 @@ __global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restr
 // large for LDS).
 // TAIL (NKS > 0): the last tile of L holds <= 4 live columns and goes through the 4x4x4 shape, as in k_urot.
 template <int LT, int NKS, bool TAIL = false>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, (NKS > 13) ? 1 : 2)       // (T' <= 52: two waves per SIMD fit without spilling)
 void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
                      const double* __restrict__ Mfrag, int B, int tiles_per_chunk,
                      double* __restrict__ part /* [nchunk][npairs][5][lpad] */, int npairs, int k0, int lpad)

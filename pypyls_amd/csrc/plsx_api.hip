@@ -1120,17 +1120,28 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     return 0;
 }
 
+// Waves per block of the rotation kernel: every block copies the M operand of every resample to LDS, so 8
+// waves (128 features) per block halve that L2 -> LDS stream (as large as the HBM stream of R at 4 waves) for
+// the compiled-in k-step counts at large B (c4: 23.3 -> 22.1 ms per 1008 bootstraps); the generic variants and
+// small B (c2: 0.97 vs 1.03 ms) keep 4.
+inline int urot_waves(int nks_template, int B)
+{
+    static const bool four = getenv("PLSX_UROT_NW4") != nullptr;
+    return (nks_template > 0 && !four && B >= 65536) ? 8 : 4;      // (few feature tiles: more, smaller blocks fill the chip)
+}
+
 // One launch of the rotation kernel for the chunk of L tiles [lt0, lt0 + LT).
 template <int LT, int NKS, bool TAIL = false>
 int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
                 double* ps, double* pq, hipStream_t st)
 {
-    const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
+    const int nw = urot_waves(NKS, ctx->B);
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), nw);
     // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
     const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
     HIPCHK(set_lds(k_urot<LT, NKS, TAIL>, lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
-    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL>), dim3(nblk, nsplit), dim3(256), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL>), dim3(nblk, nsplit), dim3(64 * nw), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
                        ctx->L, lt0 * 16, usum, usq, out, rps, ps, pq);
     LAUNCHCHK();
@@ -1155,10 +1166,11 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
 {
     const int nks = ctx->nks_t, LT = ctx->LT;
     KTimer tm(ctx, KC_UROT, st);
-    const int nblk = ceil_div(ceil_div(ctx->B, 16), 4);
+    const bool square = !getenv("PLSX_UROT_GENERIC") && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4) && nks <= 16;
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), urot_waves(square ? 1 : 0, ctx->B));
     int nsplit = 1;
     if (!out && nres >= 64) {
-        const int slots = chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>));
+        const int slots = std::max(1, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)) * 4 / urot_waves(square ? 1 : 0, ctx->B));
         // many feature blocks: cut the resamples so that the grid ends in a full round;
         // few (small B): cut them so that the grid fills the chip at all -- every block
         // walks its resamples one after the other

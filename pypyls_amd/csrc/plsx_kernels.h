@@ -2337,7 +2337,7 @@ void k_small(SmallArgs a)
 // of four features, B is the M fragment of that tile read with the column index folded to 0..3:
 // 16 matrix cycles instead of 32 per k-step, and a quarter of the sum / square updates.
 template <int LT, int NKS, bool TAIL = false>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(512)
 void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             const double* __restrict__ Mfrag, size_t mstride, int nres, int B, int L, int k0,
             double* __restrict__ usum, double* __restrict__ usq, double* __restrict__ out,
@@ -2354,7 +2354,8 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     // then conflict-free ds_read_b64 instead of one L2 fetch per MFMA.
     extern __shared__ __attribute__((aligned(16))) double sm_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b_real = (blockIdx.x * 4 + wave) * 16;
+    const int nwav = blockDim.x >> 6;            // 4 or 8 waves share the M operand of a resample
+    const int b_real = (blockIdx.x * nwav + wave) * 16;
     const bool live = b_real < B;
     const int b0 = live ? b_real : 0;            // idle waves keep pace for the barriers
     const int r_beg = blockIdx.y * res_per_split;
@@ -2374,7 +2375,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
         if (NKS < 0) return;
         __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(Mfrag + (size_t)r * mstride), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
-        for (int p = swave; p < pieces; p += 4)
+        for (int p = swave; p < pieces; p += nwav)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
                 rsM, (__attribute__((address_space(3))) void*)(buf + p * 128), 16, lane * 16, p * 1024, 0, 0);
     };
@@ -2438,7 +2439,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             const int pcs = (min(KC, nks_t - ks0) * LT + 1) / 2;
             __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(Mfrag + (size_t)r * mstride + (size_t)ks0 * LT * 64), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
-            for (int p = swave; p < pcs; p += 4)
+            for (int p = swave; p < pcs; p += nwav)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     rsM, (__attribute__((address_space(3))) void*)(buf + p * 128), 16, lane * 16, p * 1024, 0, 0);
         };

@@ -58,6 +58,16 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (vendor; = FP32 matri
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md
 
 
+
+def _engine_kwargs():
+    """Engine arguments of a bench run: a fixed 48 GB super-batch scratch (PLSX_SCRATCH_GB overrides) and the
+    PLSX_<KEY> route switches of an A/B command line -- translated HERE; the library reads no environment."""
+    from pypyls_amd.engine import options_from_env
+    kw = options_from_env()
+    kw.setdefault('scratch_gb', 48.0)
+    return kw
+
+
 def synth(S, B, T, seed=0):
     rs = np.random.RandomState(seed)
     X = rs.randn(S, B)
@@ -125,7 +135,7 @@ class PLSC(object):
                 resampling.cell_of_row(self.groups, self.n_cond)]
             self.Y = None
         # long-lived engine: fixed super-batch scratch, mapped during warm-up
-        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng = self.eng = Engine(**_engine_kwargs())
         eng.set_data(self.X, self.Y, resampling.cell_of_row(self.groups, self.n_cond), len(self.groups),
                      self.n_cond, 0 if self.method == 'behavioral' else 1)
         xw, sv, yw = eng.decompose()
@@ -348,7 +358,7 @@ class Simpls(object):
         X, Y = synth(S, B, T)
         self.Xc = X - X.mean(axis=0, keepdims=True)
         self.Yc = Y - Y.mean(axis=0, keepdims=True)
-        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng = self.eng = Engine(**_engine_kwargs())
         eng.set_data_regression(self.Xc, self.Yc, k)
         W, pct, cvec, _ = eng.simpls_decompose()
         idx = np.argmax(np.abs(W), axis=0)
@@ -452,7 +462,7 @@ class SplitHalf(object):
         from pypyls_amd.engine import Engine
         S, B, T = self.S, self.B, self.T
         self.X, self.Y = synth(S, B, T)
-        eng = self.eng = Engine(scratch_gb=float(os.environ.get('PLSX_SCRATCH_GB', 48)))
+        eng = self.eng = Engine(**_engine_kwargs())
         eng.set_data(self.X, self.Y, resampling.cell_of_row([S], 1), 1, 1, 0)
         self.L = eng.L
         self.perm_idx, self.masks = [], []

@@ -35,8 +35,8 @@ enum plsx_status {
     PLSX_OK = 0,
     PLSX_ERR_ARG = -1,       /* bad shape / flag / null pointer            */
     PLSX_ERR_UNSUPPORTED = -2, /* shape outside what the device path covers */
-    PLSX_ERR_HIP = -3,       /* HIP runtime failure (incl. out of memory)   */
-    PLSX_ERR_STATE = -4,     /* call order violated (e.g. no data set)      */
+    PLSX_ERR_HIP = -3,       /* HIP runtime failure (incl. out of device or host memory) */
+    PLSX_ERR_STATE = -4,     /* call order violated (e.g. no data set); a C++ exception caught at the boundary */
     PLSX_ERR_NUMERIC = -5    /* an eigen-solve of a finished batch did not converge (reported by plsx_sync) */
 };
 
@@ -257,8 +257,7 @@ int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
  * by a cost model that weighs mapping fresh device memory (the driver clears
  * recycled VRAM, 30-70 ms per GB) against the per-launch overhead, so a
  * one-shot run of a few thousand resamples maps a few GB instead of 48.
- * Must precede plsx_set_data.  The environment variable PLSX_SCRATCH_GB=<gb>
- * is equivalent to plsx_set_scratch(ctx, gb, 1).  No reference counterpart
+ * Must precede plsx_set_data.  No reference counterpart
  * (joblib workers size themselves, pyls/base.py:490-507). */
 int plsx_set_scratch(plsx_ctx* ctx, double max_gb, int fixed);
 
@@ -284,9 +283,37 @@ const char* plsx_kernel_class_name(int kernel_class);
  * dual call after plsx_set_data or after this call forms it, later calls
  * (chunks of one analysis) reuse it; dual < 0 keeps the route and only drops
  * that kernel (bench.py: every timed analysis forms its own).  Returns the
- * route now in effect (0 / 1) or a negative status.
- * Equivalent environment switch at bind time: PLSX_NO_DUAL_PERM=1. */
+ * route now in effect (0 / 1; 0 whatever was asked when the original spectrum is graded, see
+ * plsx_numeric_report) or a negative status.  At bind time: plsx_set_option(ctx, "no_dual_perm", 1). */
 int plsx_set_perm_path(plsx_ctx* ctx, int dual);
+
+/*
+ * Route / layout switch `key` := value (0 / 1 unless stated).  Every route computes the same statistics to
+ * rounding; the switches exist for A/B measurements and so that tests can pin each kernel variant against the
+ * others and the oracle.  The library reads NO environment variable: a host that wants PLSX_<KEY>=1 to mean
+ * something passes it on itself (bench.py and the tests do, pypyls_amd.engine.options_from_env).
+ *   layout-time (before plsx_set_data): "xprod_mt24", "min_batch" (resamples per super-batch aimed for, default
+ *     4096), "inblock_moments", "no_fixed_x", "no_dual_perm"
+ *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
+ *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
+ *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "epi2_nw4", "trace_alloc"
+ * plsx_option_name(i) enumerates the keys (NULL past the last).  No reference counterpart.
+ */
+int plsx_set_option(plsx_ctx* ctx, const char* key, int value);
+const char* plsx_option_name(int index);
+
+/*
+ * Graded spectra.  The device takes singular values / vectors from the Gram side (G = R R^T), which loses
+ * eps (d_max / d_k)^2 where the reference's SVD of R (pyls/compute.py:10-52) loses eps d_max / d_k.  A resample
+ * with a live LV below 1e-3 d_max therefore re-solves the subspace of its small LVs on R itself (its Gram matrix
+ * in the rotated basis V_s^T R, whose rounding errors are relative to the SMALL scale) wherever R exists: every
+ * feature-pass route with T' <= 64.  A data set whose ORIGINAL spectrum is graded (plsx_decompose /
+ * plsx_set_original) is taken off the dual-space routes for that reason.  This call synchronises the device and
+ * returns -- and clears -- two counters since the last call: resamples whose small LVs were refined, and resamples
+ * with such LVs that could NOT be (T' > 64, or a dual-space route on data whose original spectrum was not
+ * graded): their LVs below ~ 6e-6 d_max may miss the 1e-5 relative tolerance; the host warns.
+ */
+int plsx_numeric_report(plsx_ctx* ctx, long long* refined, long long* unrefined);
 
 /*
  * Host-side index generators -- gen_permsamp / gen_bootsamp / gen_splits

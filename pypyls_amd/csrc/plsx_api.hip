@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -24,9 +26,26 @@ struct Buf {
 
 }  // namespace
 
+// Route / layout switches (plsx_set_option).  Every route computes the same statistics -- they exist for A/B
+// measurements and so that the tests can pin each kernel variant against the others and the oracle.  None is
+// read from the environment: a host that wants PLSX_<NAME>=1 to mean something translates it itself
+// (pypyls_amd.engine.options_from_env, used by bench.py and the tests only).
+enum {
+    OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
+    OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
+    OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_COUNT
+};
+static const char* const kOptionNames[OPT_COUNT] = {
+    "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
+    "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
+    "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
+    "split_no_tail4", "split_inblock", "no_split_fuse"};
+
 struct plsx_ctx {
     int device = 0;
     std::string err;
+    int opt[OPT_COUNT] = {};
     bool has_data = false, has_orig = false;
     // problem
     int method = 0, S = 0, B = 0, T = 0, J = 0, n_groups = 0, n_cond = 1, mc = 0, cov = 0;
@@ -66,7 +85,10 @@ struct plsx_ctx {
     Buf ScT, out_row_w;                                 // single-pass bootstrap (unscaled modes): scores^T (L x S), row -> l map
     int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
-    Buf status;                                         // device word: numerical status bits of the small solvers
+    Buf status;                                         // device words: [0] numerical status bits of the small solvers, [1] refined, [2] graded but unrefined resamples
+    Buf refV, refLam, refK0, refPart;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
+    int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
+    long long n_refined = 0, n_unrefined = 0;           // host copies of status[1], status[2] since the last plsx_numeric_report
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
     int has_cellS = 0;
     int dual = 0, dual_ok = 0, has_Kd = 0;              // has_Kd: the S x S kernel of the bound data is current
@@ -96,6 +118,21 @@ int fail(plsx_ctx* c, int code, const std::string& msg)
     return code;
 }
 
+// Nothing may unwind through the C ABI (include/plsx.h): every extern "C" entry with a body worth guarding is a
+// function-try-block closed by PLSX_CATCH -- std::vector / std::string / std::thread inside the library can throw
+// (host memory, thread limits), and so could anything added later.  The handlers themselves do not throw.
+int fail_nothrow(plsx_ctx* c, int code, const char* what) noexcept
+{
+    if (c) {
+        try { c->err = what ? what : "exception"; } catch (...) { }
+    }
+    return code;
+}
+#define PLSX_CATCH(ctxexpr)                                                                            \
+    catch (const std::bad_alloc&) { return fail_nothrow(ctxexpr, PLSX_ERR_HIP, "out of host memory"); } \
+    catch (const std::exception& ex_) { return fail_nothrow(ctxexpr, PLSX_ERR_STATE, ex_.what()); }      \
+    catch (...) { return fail_nothrow(ctxexpr, PLSX_ERR_STATE, "unknown C++ exception inside libplsx"); }
+
 #define HIPCHK(call)                                                                      \
     do {                                                                                  \
         hipError_t e_ = (call);                                                           \
@@ -113,7 +150,7 @@ int fail(plsx_ctx* c, int code, const std::string& msg)
 int ensure(plsx_ctx* ctx, Buf& b, size_t bytes, bool zero = false)
 {
     if (b.bytes < bytes) {
-        static const bool trace = getenv("PLSX_TRACE_ALLOC") != nullptr;
+        const bool trace = ctx->opt[OPT_TRACE_ALLOC] != 0;
         auto t0 = std::chrono::steady_clock::now();
         if (b.p) HIPCHK(hipFree(b.p));
         auto t1 = std::chrono::steady_clock::now();
@@ -180,7 +217,6 @@ struct KTimer {
 };
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
-int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && atoi(e) > 0) ? atoi(e) : dflt; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Physical cross-product groups of `rgroups` resample groups.
@@ -209,7 +245,7 @@ int plan_groups(plsx_ctx* c)
     int best = fit(24);
     // a block of 16 tiles when it wastes clearly fewer rows (one resample of 177 <= T' <= 224 rows
     // fills 15 of 24 tiles but 15 of 16); behavioural correlation PLS only (instantiations of k_xprod)
-    if (c->method == PLSX_BEHAVIORAL && !getenv("PLSX_XPROD_MT24")) {
+    if (c->method == PLSX_BEHAVIORAL && !c->opt[OPT_XPROD_MT24]) {
         const int b16 = fit(16);
         if (b16 >= 1 && (double)b16 / 16.0 > 1.15 * (double)best / 24.0) { c->MT = 16; best = b16; }
     }
@@ -252,7 +288,7 @@ int plan_groups(plsx_ctx* c)
     int g = round_up(std::max(1, ceil_div(2048, ncolblk)), 8);
     // ... and (c) small shapes amortise their launches: 4096 resamples per super-batch where the budget
     // allows (c2: 512 -> 4096 per batch, 1.72 M -> 1.91 M resamples/s; the headline shape is budget bound)
-    g = std::max(g, round_up(ceil_div(env_int("PLSX_MIN_BATCH", 4096), std::max(best, 1)), 8));
+    g = std::max(g, round_up(ceil_div(c->opt[OPT_MIN_BATCH] > 0 ? c->opt[OPT_MIN_BATCH] : 4096, std::max(best, 1)), 8));
     g = std::min(std::max(g, 8), 128);
     const double budget = c->scratch_gb * 1073741824.0;
     while (g > 1 && (double)g * best * c->Tpp * (double)c->Bpad * 8.0 > budget) g -= (g > 8 ? 8 : 1);
@@ -308,7 +344,7 @@ int upload_rowmaps(plsx_ctx* ctx)
 int plan_sepmom(plsx_ctx* ctx)
 {
     ctx->sepmom = 0;
-    if (!ctx->scaled || ctx->gps > 0 || getenv("PLSX_INBLOCK_MOMENTS")) return 0;
+    if (!ctx->scaled || ctx->gps > 0 || ctx->opt[OPT_INBLOCK_MOMENTS]) return 0;
     int best_mt = 0, best_n = 0;
     double best_fill = 0.0;
     for (int mt : {24, 22, 16}) {
@@ -445,7 +481,7 @@ int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int gro
     SplitEpi se;
     memset(&se, 0, sizeof(se));
     se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
-    static const bool narrow = getenv("PLSX_EPI2_NW4") != nullptr;
+    const bool narrow = ctx->opt[OPT_EPI2_NW4] != 0;
     KTimer tm(ctx, KC_XPROD, st);
     if (!narrow && 2 * (size_t)L * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
         constexpr int NW = 8;
@@ -659,7 +695,7 @@ bool compact_boot_ok(const plsx_ctx* ctx)
     if (!(ctx->scaled && ctx->method == PLSX_BEHAVIORAL && ctx->gps == 0 && ctx->Tp <= 208 && !ctx->mom_out_arg &&
           ctx->J <= 32 && ctx->S <= 8192 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31)))
         return false;
-    static const int force = getenv("PLSX_COMPACT_BOOT_ALWAYS") ? 1 : (getenv("PLSX_NO_COMPACT_BOOT") ? -1 : 0);
+    const int force = ctx->opt[OPT_COMPACT_BOOT_ALWAYS] ? 1 : (ctx->opt[OPT_NO_COMPACT_BOOT] ? -1 : 0);
     if (force) return force > 0;
     // matrix-pipe cycles per bootstrap in units of (S / 4 k-steps x one 16-row tile): a compact block contracts
     // ~0.66 S rows (distinct draws, rounded to k-steps) on its own tiles at ~0.8 of the dense blocks' pipe
@@ -762,7 +798,7 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
         const long long cost_a = (long long)groups * ctx->MT;
         const long long cost_b = (long long)ceil_div(nres, ctx->npg_d) * ctx->MTd +
                                  (long long)ceil_div(nres * ctx->J, PLSX_MOM_PAIRS) * 24;
-        static const bool force_b = getenv("PLSX_SEPMOM_ALWAYS") != nullptr;     // tests: the layout at any launch size
+        const bool force_b = ctx->opt[OPT_SEPMOM_ALWAYS] != 0;     // tests: the layout at any launch size
         ctx->sepmom_used = force_b || cost_b * 102 < cost_a * 100;
         if (ctx->sepmom_used)
             return run_xprod_sepmom(ctx, xsrc, ysrc, nres, st, ystack, ystride);
@@ -936,7 +972,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     const double* R = ptr<double>(ctx->R);
     double* Gm = ptr<double>(ctx->Gm);
     const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
-    if ((ctx->Tp > 64 || Erows > 64) && !getenv("PLSX_GRAM_NT")) {
+    if ((ctx->Tp > 64 || Erows > 64) && !ctx->opt[OPT_GRAM_NT]) {
         // 64 x 64 output blocks on the register-streamed k_gram (4 x the rate of the generic
         // LDS-tiled k_nt_gemm): G upper block triangle, then P, into one partial buffer
         const int nt_t = ceil_div(ctx->Tp, 64), nt_l = mode != 0 ? ceil_div(Erows, 64) : 0;
@@ -951,7 +987,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
         double* part = ptr<double>(ctx->part);
         KTimer tm(ctx, KC_GRAM, st);
         const dim3 gG(ceil_div(ctx->Tp * ctx->Tp, 256), nres), gP(ceil_div(ctx->Tp * std::max(Erows, 1), 256), nres);
-        const bool reg_streamed = getenv("PLSX_GRAM_REG") != nullptr;     // the A side from global memory in every wave
+        const bool reg_streamed = ctx->opt[OPT_GRAM_REG] != 0;     // the A side from global memory in every wave
         if (!reg_streamed) {
             if (mode == 1 && nt_l == nt_t) {
                 // square: G and P of the blocks tm <= tn share their A fragments in one pass,
@@ -1028,7 +1064,7 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     // square P (bootstrap G + P, or the cross product alone): the 4x4x4-MFMA kernel
     // (no 16-row padding, symmetric G)
     {
-        const bool no4 = getenv("PLSX_NO_GRAM4") != nullptr;
+        const bool no4 = ctx->opt[OPT_NO_GRAM4] != 0;
         const int nb4 = ceil_div(ctx->Tp, 4);
         // (14+ row blocks would spill at two waves per SIMD: T' > 52 keeps the 16x16x4 kernel)
         if (!no4 && nb4 <= 13 && (mode == 0 || ceil_div(Erows, 4) == nb4) && 4 * ctx->strideR * 8 < (1LL << 31) &&
@@ -1076,7 +1112,10 @@ int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st)
                        ptr<double>(ctx->Pm), st);
 }
 
-int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
+// Rref: the cross-covariance matrices the Gram matrices a.G were formed from (slot r at r * strideR, pitch Bpad,
+// B live columns), or nullptr on the dual-space routes that never form them.  With them a graded spectrum is
+// refined on R itself (SmallArgs::phase, k_refine_gram); without, such resamples are only counted.
+int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double* Rref = nullptr)
 {
     const int n = a.n;
     const int ld = n | 1;
@@ -1084,6 +1123,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     a.nres = nres;
     a.ld = ld;
     a.jtol = 1e-15;
+    a.phase = 0;
     if (n > PLSX_JACOBI_TP) {
         // Householder + implicit QL (plsx_symeig.h): persistent blocks, a global workspace of 4 n ld
         // doubles per block, and whatever LDS is left behind the bookkeeping vectors for the leading
@@ -1111,12 +1151,39 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
 #define SMALL_LDS_LAUNCH(ITL, THREADS) { HIPCHK(set_lds(k_small<ITL>, lds)); \
         hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), lds, st, a); }
-    if (n <= 16) SMALL_LDS_LAUNCH(2, 64)          // one wave per resample: the step barriers cost nothing
-    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128)
-    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256)
+#define SMALL_LDS_DISPATCH() \
+    if (n <= 16) SMALL_LDS_LAUNCH(2, 64)          /* one wave per resample: the step barriers cost nothing */ \
+    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128) \
+    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256) \
     else SMALL_LDS_LAUNCH(8, 256)
-#undef SMALL_LDS_LAUNCH
+    int nchunk = 0;
+    if (Rref && n > 1 && !ctx->opt[OPT_NO_REFINE]) {
+        // partial refined Grams: one (n x n) tile per (resample, column chunk), 256 MB at most
+        nchunk = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(32, ceil_div(ctx->B, 1024)),
+                                                                  (256LL << 20) / ((long long)nres * n * n * 8)));
+        if (int e = ensure(ctx, ctx->refV, (size_t)nres * n * n * 8)) return e;
+        if (int e = ensure(ctx, ctx->refLam, (size_t)nres * n * 8)) return e;
+        if (int e = ensure(ctx, ctx->refK0, (size_t)nres * sizeof(int))) return e;
+        if (int e = ensure(ctx, ctx->refPart, (size_t)nres * nchunk * n * n * 8)) return e;
+        a.phase = 1;
+        a.refV = ptr<double>(ctx->refV); a.refLam = ptr<double>(ctx->refLam); a.refK0 = ptr<int>(ctx->refK0);
+        a.refPart = ptr<double>(ctx->refPart); a.ref_nchunk = nchunk;
+    }
+    SMALL_LDS_DISPATCH()
     LAUNCHCHK();
+    if (a.phase == 1) {
+        // blocks of resamples that are not parked return at once: two short launches when nothing is graded
+        const size_t rlds = ((size_t)n * 64 + 64 * 66) * 8;
+        HIPCHK(set_lds(k_refine_gram, rlds));
+        hipLaunchKernelGGL(k_refine_gram, dim3(nchunk, nres), dim3(256), rlds, st, Rref, ctx->strideR, ctx->Bpad,
+                           ctx->B, n, ptr<double>(ctx->refV), ptr<int>(ctx->refK0), ptr<double>(ctx->refPart), nchunk);
+        LAUNCHCHK();
+        a.phase = 2;
+        SMALL_LDS_DISPATCH()
+        LAUNCHCHK();
+    }
+#undef SMALL_LDS_DISPATCH
+#undef SMALL_LDS_LAUNCH
     return 0;
 }
 
@@ -1124,9 +1191,9 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st)
 // waves (128 features) per block halve that L2 -> LDS stream (as large as the HBM stream of R at 4 waves) for
 // the compiled-in k-step counts at large B (c4: 23.3 -> 22.1 ms per 1008 bootstraps); the generic variants and
 // small B (c2: 0.97 vs 1.03 ms) keep 4.
-inline int urot_waves(int nks_template, int B)
+inline int urot_waves(const plsx_ctx* ctx, int nks_template, int B)
 {
-    static const bool four = getenv("PLSX_UROT_NW4") != nullptr;
+    const bool four = ctx->opt[OPT_UROT_NW4] != 0;
     return (nks_template > 0 && !four && B >= 65536) ? 8 : 4;      // (few feature tiles: more, smaller blocks fill the chip)
 }
 
@@ -1135,7 +1202,7 @@ template <int LT, int NKS, bool TAIL = false>
 int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
                 double* ps, double* pq, hipStream_t st)
 {
-    const int nw = urot_waves(NKS, ctx->B);
+    const int nw = urot_waves(ctx, NKS, ctx->B);
     const int nblk = ceil_div(ceil_div(ctx->B, 16), nw);
     // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
     const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
@@ -1166,11 +1233,11 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
 {
     const int nks = ctx->nks_t, LT = ctx->LT;
     KTimer tm(ctx, KC_UROT, st);
-    const bool square = !getenv("PLSX_UROT_GENERIC") && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4) && nks <= 16;
-    const int nblk = ceil_div(ceil_div(ctx->B, 16), urot_waves(square ? 1 : 0, ctx->B));
+    const bool square = !ctx->opt[OPT_UROT_GENERIC] && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4) && nks <= 16;
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), urot_waves(ctx, square ? 1 : 0, ctx->B));
     int nsplit = 1;
     if (!out && nres >= 64) {
-        const int slots = std::max(1, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)) * 4 / urot_waves(square ? 1 : 0, ctx->B));
+        const int slots = std::max(1, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)) * 4 / urot_waves(ctx, square ? 1 : 0, ctx->B));
         // many feature blocks: cut the resamples so that the grid ends in a full round;
         // few (small B): cut them so that the grid fills the chip at all -- every block
         // walks its resamples one after the other
@@ -1187,12 +1254,12 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
         ps = ptr<double>(ctx->psum);
         pq = ptr<double>(ctx->psq);
     }
-    const bool generic = getenv("PLSX_UROT_GENERIC") != nullptr;   // A/B and race check
+    const bool generic = ctx->opt[OPT_UROT_GENERIC] != 0;   // A/B and race check
     int rc = -1;
     // square case (L tiles follow from T'): k-step count compiled in, fragments of the
     // next resample prefetched
     // the last tile of L on the 4x4x4 shape when it holds at most 4 live columns (see k_urot)
-    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !getenv("PLSX_UROT_NO_TAIL4");
+    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !ctx->opt[OPT_UROT_NO_TAIL4];
     if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: rc = tail4 ? launch_urot<(N + 3) / 4, N, true>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
@@ -1254,7 +1321,7 @@ int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, const dou
     const int nks = ctx->nks_t, LT = ctx->LT, lpad = LT * 16;
     const double* R = ptr<double>(ctx->R);
     KTimer tm(ctx, KC_UCORR, st);
-    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !getenv("PLSX_UROT_NO_TAIL4");
+    const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !ctx->opt[OPT_UROT_NO_TAIL4];
     if (LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: return tail4 ? launch_ucorr_t<(N + 3) / 4, N, true>(ctx, grid, block, st, R, ctx->strideR, ctx->Bpad, \
@@ -1292,6 +1359,25 @@ SmallArgs small_args(plsx_ctx* ctx, int mode)
     return a;
 }
 
+// Dual-space routes (S x S kernel: permutations, single-pass bootstraps of the unscaled modes) never form R and
+// so cannot refine a graded spectrum (run_small); a data set whose ORIGINAL spectrum is graded takes the feature pass.
+inline int use_dual(const plsx_ctx* ctx) { return (ctx->dual && !ctx->graded) ? 1 : 0; }
+
+// d (L values on the device, descending): set ctx->graded when a live singular value lies below PLSX_REFINE_TAU d_max.
+int note_spectrum(plsx_ctx* ctx, const double* d_sv, hipStream_t st)
+{
+    std::vector<double> d(ctx->L);
+    HIPCHK(hipMemcpyAsync(d.data(), d_sv, (size_t)ctx->L * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double dmax = 0.0;
+    for (double v : d) if (v > dmax) dmax = v;
+    int graded = 0;
+    for (double v : d) if (v > PLSX_RANK_RTOL * dmax && v < PLSX_REFINE_TAU * dmax) graded = 1;
+    if (graded != ctx->graded) ctx->has_Kd = ctx->has_Kd && !graded;
+    ctx->graded = graded && !ctx->opt[OPT_NO_REFINE];
+    return 0;
+}
+
 #define NEED_DATA()                                                             \
     if (!ctx) return PLSX_ERR_ARG;                                              \
     if (!ctx->has_data) return fail(ctx, PLSX_ERR_STATE, "plsx_set_data has not been called")
@@ -1307,7 +1393,7 @@ int plsx_version(void) { return 1000; }
 int plsx_max_tprime(void) { return PLSX_MAX_TP; }
 
 int plsx_ctx_create(int device, plsx_ctx** out)
-{
+try {
     if (!out) return PLSX_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -1316,20 +1402,17 @@ int plsx_ctx_create(int device, plsx_ctx** out)
     plsx_ctx* c = new (std::nothrow) plsx_ctx();
     if (!c) return PLSX_ERR_HIP;
     c->device = device;
-    if (hipMalloc(&c->status.p, sizeof(int)) != hipSuccess || hipMemset(c->status.p, 0, sizeof(int)) != hipSuccess) {
+    if (hipMalloc(&c->status.p, 4 * sizeof(int)) != hipSuccess || hipMemset(c->status.p, 0, 4 * sizeof(int)) != hipSuccess) {
         delete c;
         return PLSX_ERR_HIP;
     }
-    c->status.bytes = sizeof(int);
-    if (const char* env = getenv("PLSX_SCRATCH_GB")) {
-        if (atof(env) > 0.0) { c->scratch_gb = atof(env); c->scratch_fixed = 1; }
-    }
+    c->status.bytes = 4 * sizeof(int);
     *out = c;
     return PLSX_OK;
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_ctx_destroy(plsx_ctx* ctx)
-{
+try {
     if (!ctx) return PLSX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -1340,31 +1423,38 @@ int plsx_ctx_destroy(plsx_ctx* ctx)
                    &ctx->Kmat, &ctx->swork, &ctx->spct, &ctx->sc,
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
-                   &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c})
+                   &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
+                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 const char* plsx_last_error(const plsx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int plsx_sync(plsx_ctx* ctx)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     // numerical status of everything that ran since the last call: an eigen-solve that gave up is an
     // error of the results already written, reported here instead of flowing on silently
-    int st = 0;
-    HIPCHK(hipMemcpy(&st, ctx->status.p, sizeof(int), hipMemcpyDeviceToHost));
+    int stw[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(stw, ctx->status.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (stw[1] || stw[2]) {
+        ctx->n_refined += stw[1];
+        ctx->n_unrefined += stw[2];
+        HIPCHK(hipMemset(static_cast<int*>(ctx->status.p) + 1, 0, 2 * sizeof(int)));
+    }
+    const int st = stw[0];
     if (st) {
         HIPCHK(hipMemset(ctx->status.p, 0, sizeof(int)));
         return fail(ctx, PLSX_ERR_NUMERIC, "small solver: implicit QL did not converge within 60 iterations for at least "
                                            "one resample (non-finite or pathological Gram matrix); results of the batch are invalid");
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_num_lv(const plsx_ctx* ctx) { return (ctx && ctx->has_data) ? ctx->L : PLSX_ERR_STATE; }
 int plsx_tprime(const plsx_ctx* ctx) { return (ctx && ctx->has_data) ? ctx->Tp : PLSX_ERR_STATE; }
@@ -1372,7 +1462,7 @@ int plsx_tprime(const plsx_ctx* ctx) { return (ctx && ctx->has_data) ? ctx->Tp :
 int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_Y,
                   const int32_t* d_cell_of_row, int S, int B, int T, int n_groups, int n_cond,
                   int mean_centering, unsigned flags, void* stream)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
@@ -1467,8 +1557,7 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     if (int e = plan_sepmom(ctx)) return e;
     ctx->fix = 0; ctx->has_Xn = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
     {
-        const char* nf = getenv("PLSX_NO_FIXED_X");
-        if (method == PLSX_BEHAVIORAL && !ctx->cov && !(nf && atoi(nf))) {
+        if (method == PLSX_BEHAVIORAL && !ctx->cov && !ctx->opt[OPT_NO_FIXED_X]) {
             // fixed-X fast path for permutations
             ctx->npgf = ctx->gps > 0 ? 0 : (ctx->MTf * 16) / ctx->Tp;
             {
@@ -1495,9 +1584,9 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     }
     {
         // dual permutation path: needs a resample-independent feature matrix
-        const char* nd = getenv("PLSX_NO_DUAL_PERM");
         ctx->dual_ok = (method == PLSX_MEANCENTERED || (method == PLSX_BEHAVIORAL && (ctx->has_Xn || ctx->cov))) ? 1 : 0;
-        ctx->dual = (ctx->dual_ok && !(nd && atoi(nd))) ? 1 : 0;
+        ctx->dual = (ctx->dual_ok && !ctx->opt[OPT_NO_DUAL_PERM]) ? 1 : 0;
+        ctx->graded = 0;
     }
     if (int e = ensure(ctx, ctx->U0T, (size_t)ctx->L * ctx->Bpad * 8, true)) return e;
     if (int e = ensure(ctx, ctx->V0, (size_t)ctx->Tp * ctx->L * 8)) return e;
@@ -1512,20 +1601,20 @@ int plsx_set_data(plsx_ctx* ctx, int method, const double* d_X, const double* d_
     HIPCHK(hipStreamSynchronize(st));
     ctx->has_data = true;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_colmean(plsx_ctx* ctx, double* d_mean, void* stream)
-{
+try {
     NEED_DATA();
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(d_mean, ctx->xmean.p, (size_t)ctx->B * 8, hipMemcpyDeviceToDevice,
                           static_cast<hipStream_t>(stream)));
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_crosscov_batch(plsx_ctx* ctx, const int32_t* d_xsrc, const int32_t* d_ysrc, int n,
                         double* d_R, void* stream)
-{
+try {
     NEED_DATA();
     if (n < 1 || !d_R) return fail(ctx, PLSX_ERR_ARG, "plsx_crosscov_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1542,10 +1631,10 @@ int plsx_crosscov_batch(plsx_ctx* ctx, const int32_t* d_xsrc, const int32_t* d_y
         LAUNCHCHK();
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void* stream)
-{
+try {
     NEED_DATA();
     if (!d_xw || !d_sv || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_decompose: null output");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1554,12 +1643,13 @@ int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void
     if (int e = run_gram(ctx, 1, false, st)) return e;
     SmallArgs a = small_args(ctx, SMALL_DECOMP);
     a.out_V = d_yw; a.out_d = d_sv;
-    if (int e = run_small(ctx, a, 1, st)) return e;
-    return run_urot(ctx, 1, nullptr, nullptr, d_xw, st);
-}
+    if (int e = run_small(ctx, a, 1, st, ptr<double>(ctx->R))) return e;
+    if (int e = run_urot(ctx, 1, nullptr, nullptr, d_xw, st)) return e;
+    return note_spectrum(ctx, d_sv, st);
+} PLSX_CATCH(ctx)
 
 int plsx_project(plsx_ctx* ctx, const double* d_W, int L, double* d_out, void* stream)
-{
+try {
     NEED_DATA();
     if (!d_W || !d_out || L < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_project: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1571,17 +1661,18 @@ int plsx_project(plsx_ctx* ctx, const double* d_W, int L, double* d_out, void* s
     LAUNCHCHK();
     return run_nt(ctx, ptr<double>(ctx->Xc), 0, ctx->Bpad, ctx->S, ptr<double>(ctx->tmpW), 0, ctx->Bpad, L,
                   nullptr, 0, 0, 0, ctx->B, 1, d_out, 0, L, nullptr, 0, 0, st);
-}
+} PLSX_CATCH(ctx)
 
 int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv, const double* d_yw,
                       void* stream)
-{
+try {
     NEED_DATA();
     if (!d_xw || !d_sv || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_set_original: null input");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(ctx->V0.p, d_yw, (size_t)ctx->Tp * ctx->L * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->d0.p, d_sv, (size_t)ctx->L * 8, hipMemcpyDeviceToDevice, st));
+    if (int e = note_spectrum(ctx, d_sv, st)) return e;
     hipLaunchKernelGGL(k_transpose, dim3(ceil_div(ctx->L, 32), ceil_div(ctx->B, 32)), dim3(32, 8), 0, st,
                        d_xw, ctx->B, ctx->L, ctx->L, ptr<double>(ctx->U0T), ctx->Bpad);
     LAUNCHCHK();
@@ -1605,7 +1696,7 @@ int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv, con
     }
     ctx->has_orig = true;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 namespace {
 int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int n, int rotate,
@@ -1614,21 +1705,21 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
 
 int plsx_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, int rotate, double* d_out_sv,
                     void* stream)
-{
+try {
     NEED_ORIG();
     if (!d_perm_idx || !d_out_sv || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch: bad arguments");
     return perm_batch_impl(ctx, d_perm_idx, nullptr, n, rotate, d_out_sv, stream);
-}
+} PLSX_CATCH(ctx)
 
 int plsx_perm_batch_y(plsx_ctx* ctx, const double* d_ystack, int n, int rotate, double* d_out_sv,
                       void* stream)
-{
+try {
     NEED_ORIG();
     if (ctx->method != PLSX_BEHAVIORAL)
         return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch_y: pre-permuted Y stacks need behavioral PLS");
     if (!d_ystack || !d_out_sv || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_perm_batch_y: bad arguments");
     return perm_batch_impl(ctx, nullptr, d_ystack, n, rotate, d_out_sv, stream);
-}
+} PLSX_CATCH(ctx)
 
 namespace {
 // Dual permutation path.  A permutation leaves the feature side untouched
@@ -1704,7 +1795,7 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->dual) return perm_dual(ctx, d_perm_idx, d_ystack, n, rotate, d_out_sv, st);
+    if (use_dual(ctx)) return perm_dual(ctx, d_perm_idx, d_ystack, n, rotate, d_out_sv, st);
     const int pg = ctx->fix ? ctx->npgf : ctx->npg;
     const int nb = balanced_batch(n, launch_groups(ctx, n, pg) * pg, pg);
     for (int off = 0; off < n; off += nb) {
@@ -1721,7 +1812,7 @@ int perm_batch_impl(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ys
         SmallArgs a = small_args(ctx, SMALL_PERM);
         a.rotate = rotate ? 1 : 0;
         a.out_sv = d_out_sv + (size_t)off * ctx->L;
-        if (int e = run_small(ctx, a, m, st)) return e;
+        if (int e = run_small(ctx, a, m, st, ptr<double>(ctx->R))) return e;
     }
     return PLSX_OK;
 }
@@ -1842,15 +1933,15 @@ extern "C" {
 
 int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_usum, double* d_usq,
                     double* d_distrib, void* stream)
-{
+try {
     NEED_ORIG();
     if (!d_boot_idx || !d_usum || !d_usq || !d_distrib || n < 1)
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_batch: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
     // unscaled modes: one pass over the features per bootstrap (see boot_single_pass)
-    if (!ctx->scaled && ctx->dual && ctx->gps == 0 && ctx->L == ctx->Tp && ctx->Tp <= PLSX_JACOBI_TP &&
-        2 * (size_t)ctx->L * PLSX_ACC_PITCH * 8 <= 72 * 1024 && !getenv("PLSX_TWO_PASS_BOOT"))
+    if (!ctx->scaled && use_dual(ctx) && ctx->gps == 0 && ctx->L == ctx->Tp && ctx->Tp <= PLSX_JACOBI_TP &&
+        2 * (size_t)ctx->L * PLSX_ACC_PITCH * 8 <= 72 * 1024 && !ctx->opt[OPT_TWO_PASS_BOOT])
         return boot_single_pass(ctx, d_boot_idx, n, d_usum, d_usq, d_distrib, st);
     const int nb = balanced_batch(n, launch_groups(ctx, n, ctx->npg) * ctx->npg, ctx->npg);
     for (int off = 0; off < n; off += nb) {
@@ -1860,7 +1951,7 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
         if (int e = run_gram(ctx, m, true, st)) return e;
         const double* R = ptr<double>(ctx->R);
         SmallArgs a = small_args(ctx, SMALL_BOOT);
-        if (int e = run_small(ctx, a, m, st)) return e;
+        if (int e = run_small(ctx, a, m, st, R)) return e;
         if (int e = run_urot(ctx, m, d_usum, d_usq, nullptr, st)) return e;
         dim3 g(ceil_div(ctx->Tp * ctx->L, 256), m);
         hipLaunchKernelGGL(k_gather_cols, g, dim3(256), 0, st, R, ctx->strideR, ctx->Bpad, ctx->B, ctx->Tp,
@@ -1868,7 +1959,7 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_u
         LAUNCHCHK();
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 }  // extern "C"
 
@@ -1989,7 +2080,7 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     se.row_tab = ptr<int>(ctx->rowtab_c);
     se.row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)m * nks_c * 4;
     // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
-    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !getenv("PLSX_SPLIT_NO_TAIL4");
+    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !ctx->opt[OPT_SPLIT_NO_TAIL4];
     switch (MTc) {
         case 1: return launch_xprod_compact<1, 12>(ctx, m, nks_c, se, st);
         case 2: return tail ? launch_xprod_compact<2, 6, true>(ctx, m, nks_c, se, st)
@@ -2006,7 +2097,7 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
 {
     // (LDS of a compact block: the row table, 4 S bytes; the epilogue's five column tables of every cell, 5 KB each)
     if (ctx->Tp <= 64 && ctx->J <= 10 && ctx->S <= 8192 && (long long)ctx->Kpad * ctx->Bpad * 8 < (1LL << 31) &&
-        !getenv("PLSX_SPLIT_INBLOCK"))
+        !ctx->opt[OPT_SPLIT_INBLOCK])
         return run_split_compact(ctx, perm, masks, m, Rfull, st, Yarr);
     const int J = ctx->J, S = ctx->S, rows = ctx->MT * 16;
     if (ctx->has_cellS != 1) {
@@ -2055,13 +2146,13 @@ extern "C" {
 
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, const uint8_t* d_masks,
                           int ns, double* d_ucorr, double* d_vcorr, void* stream)
-{
+try {
     return plsx_split_half_batch_y(ctx, d_perm_idx, nullptr, np, d_masks, ns, d_ucorr, d_vcorr, stream);
-}
+} PLSX_CATCH(ctx)
 
 int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int np,
                             const uint8_t* d_masks, int ns, double* d_ucorr, double* d_vcorr, void* stream)
-{
+try {
     NEED_DATA();
     if (!d_masks || !d_ucorr || !d_vcorr || np < 1 || ns < 1 || (d_ystack && d_perm_idx))
         return fail(ctx, PLSX_ERR_ARG, "plsx_split_half_batch: bad arguments");
@@ -2089,7 +2180,7 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
     const int permute_x = (ctx->method == PLSX_MEANCENTERED) ? 1 : 0;
     // behavioral correlation mode: only the first half of a split takes the MFMA pass
     const bool fused = ctx->scaled && !permute_x && ctx->gps == 0 && ctx->Gcap >= 2 && ctx->MT == 24 &&
-                       !getenv("PLSX_NO_SPLIT_FUSE");       // (the fused epilogue is instantiated for 24-tile blocks)
+                       !ctx->opt[OPT_NO_SPLIT_FUSE];       // (the fused epilogue is instantiated for 24-tile blocks)
     // splits per pass (the fused path writes two R slots per split from groups of npg splits)
     const int spp = fused ? std::max(1, std::min(nb / 2, (ctx->Gcap / 2) * ctx->npg)) : nb / 2;
     for (int p0 = 0; p0 < np; p0 += pcmax) {
@@ -2104,7 +2195,7 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
         if (int e = run_gram(ctx, pc, false, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_DECOMP);
         a.out_V = ptr<double>(ctx->Vp); a.out_d = ptr<double>(ctx->dp); a.Mfrag = ptr<double>(ctx->Mvd);
-        if (int e = run_small(ctx, a, pc, st)) return e;
+        if (int e = run_small(ctx, a, pc, st, ptr<double>(ctx->R))) return e;
         for (int pi = 0; pi < pc; ++pi) {
             const int p = p0 + pi;
             const int* perm = d_perm_idx ? d_perm_idx + (size_t)p * S : nullptr;
@@ -2157,7 +2248,7 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
         }
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 }  // extern "C"
 
@@ -2178,7 +2269,7 @@ int replan_moments(plsx_ctx* ctx, int want)
 extern "C" {
 
 int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, double* d_r2, void* stream)
-{
+try {
     NEED_DATA();
     if (ctx->method != PLSX_BEHAVIORAL)
         return fail(ctx, PLSX_ERR_ARG, "plsx_crossval_batch: cross-validation is defined for behavioral PLS");
@@ -2192,7 +2283,7 @@ int plsx_crossval_batch(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_
     HIPCHK(hipStreamSynchronize(st));
     if (int e = replan_moments(ctx, 0)) return e;
     return rc;
-}
+} PLSX_CATCH(ctx)
 
 }  // extern "C"
 
@@ -2222,7 +2313,7 @@ int crossval_impl(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, dou
         if (int e2 = ensure(ctx, ctx->ds, (size_t)mm * L * 8)) return e2;
         SmallArgs a = small_args(ctx, SMALL_DECOMP);
         a.out_V = ptr<double>(ctx->Vs); a.out_d = ptr<double>(ctx->ds);
-        if (int e2 = run_small(ctx, a, mm, st)) return e2;
+        if (int e2 = run_small(ctx, a, mm, st, ptr<double>(ctx->R))) return e2;
         // rescaled copies and offsets, then Q = Rs . Xc^T
         if (int e2 = ensure(ctx, ctx->R2, (size_t)mm * J * ctx->strideR * 8)) return e2;
         if (int e2 = ensure(ctx, ctx->cvc, (size_t)mm * J * Tp * 8)) return e2;
@@ -2363,13 +2454,13 @@ namespace {
 // pass accumulates the aligned weights and their squares (k_xprod EPI = 2)
 bool simpls_single_pass(const plsx_ctx* ctx)
 {
-    return (size_t)2 * ctx->ncomp * PLSX_ACC_PITCH * 8 <= 72 * 1024 && ctx->Qs.p && !getenv("PLSX_TWO_PASS_BOOT");
+    return (size_t)2 * ctx->ncomp * PLSX_ACC_PITCH * 8 <= 72 * 1024 && ctx->Qs.p && !ctx->opt[OPT_TWO_PASS_BOOT];
 }
 }  // namespace
 
 int plsx_simpls_decompose(plsx_ctx* ctx, double* d_xwT, double* d_pctvar, double* d_cvec, double* d_yload,
                           void* stream)
-{
+try {
     NEED_DATA();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
     if (!d_xwT || !d_pctvar || !d_cvec || !d_yload) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_decompose: null output");
@@ -2381,10 +2472,10 @@ int plsx_simpls_decompose(plsx_ctx* ctx, double* d_xwT, double* d_pctvar, double
                        ptr<double>(ctx->R), ctx->strideR, ctx->Bpad, 0, ctx->Tp, ctx->B, d_xwT);
     LAUNCHCHK();
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream)
-{
+try {
     NEED_DATA();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
     if (!d_w0cT) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_set_original: null input");
@@ -2400,10 +2491,10 @@ int plsx_simpls_set_original(plsx_ctx* ctx, const double* d_w0cT, void* stream)
         return e;
     ctx->has_orig = true;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, double* d_out, void* stream)
-{
+try {
     NEED_DATA();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
     if (!d_perm_idx || !d_out || n < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_simpls_perm_batch: bad arguments");
@@ -2423,10 +2514,10 @@ int plsx_simpls_perm_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int n, doub
             return e;
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_simpls_set_row_masks(plsx_ctx* ctx, const uint8_t* d_okx, const uint8_t* d_oky, void* stream)
-{
+try {
     NEED_DATA();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2444,11 +2535,11 @@ int plsx_simpls_set_row_masks(plsx_ctx* ctx, const uint8_t* d_okx, const uint8_t
     }
     HIPCHK(hipStreamSynchronize(st));
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const double* d_ystack, int n,
                            double* d_usum, double* d_usq, double* d_yload, void* stream)
-{
+try {
     NEED_ORIG();
     if (ctx->method != PLSX_REGRESSION) return fail(ctx, PLSX_ERR_STATE, "data not bound for regression");
     if (!d_boot_idx || !d_usum || !d_usq || !d_yload || n < 1)
@@ -2518,11 +2609,11 @@ int plsx_simpls_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, const doubl
         }
     }
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, const double* d_usq,
                   int n_boot, int add_orig, long long count, double* d_bsr, double* d_se, void* stream)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     if (!d_orig || !d_usum || !d_usq || !d_bsr || !d_se || count < 1 || n_boot < 1)
         return fail(ctx, PLSX_ERR_ARG, "plsx_boot_rel: bad arguments");
@@ -2532,10 +2623,10 @@ int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum, con
                        d_bsr, d_se);
     LAUNCHCHK();
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops)
-{
+try {
     if (!ctx || !tflops) return PLSX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     const int blocks = 256 * 8, iters = 1 << 16;   // ~0.1 s: long enough for the clock to settle
@@ -2557,11 +2648,11 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops)
     const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
     *tflops = flops / (ms * 1e-3) / 1e12;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, int n, int i_lo, double g_lo,
                        int i_hi, double g_hi, double* d_lo, double* d_hi, void* stream)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     if (!d_data || !d_lo || !d_hi || nseries < 1 || n < 1 || i_lo < 0 || i_hi < 0 || i_lo >= n || i_hi >= n)
         return fail(ctx, PLSX_ERR_ARG, "plsx_percentile_ci: bad arguments");
@@ -2575,30 +2666,30 @@ int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, i
                        d_data, n, p2, i_lo, g_lo, i_hi, g_hi, d_lo, d_hi);
     LAUNCHCHK();
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_set_scratch(plsx_ctx* ctx, double max_gb, int fixed)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     if (!(max_gb > 0.0)) return fail(ctx, PLSX_ERR_ARG, "plsx_set_scratch: budget must be positive");
     if (ctx->has_data) return fail(ctx, PLSX_ERR_STATE, "plsx_set_scratch must precede plsx_set_data");
     ctx->scratch_gb = max_gb;
     ctx->scratch_fixed = fixed ? 1 : 0;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_set_timing(plsx_ctx* ctx, int enable)
-{
+try {
     if (!ctx) return PLSX_ERR_ARG;
     ctx->timing = enable ? 1 : 0;
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     ctx->events.clear();
     ctx->timed_units = 0;
     return PLSX_OK;
-}
+} PLSX_CATCH(ctx)
 
 int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
-{
+try {
     plsx_ctx* ctx = const_cast<plsx_ctx*>(cctx);
     if (!ctx || !out || cap < 1) return PLSX_ERR_ARG;
     double ms = 0.0;
@@ -2624,14 +2715,14 @@ int plsx_last_timing(const plsx_ctx* cctx, double* out, int cap)
     const bool cmp = ctx->last_compact_n > 0;
     double vals[8] = {ms, (double)launches, (double)(cmp ? 1 : (ctx->sepmom_used ? ctx->npg_d : ctx->npg)),
                       (double)(cmp ? ceil_div(ctx->Tp, 16) : (ctx->sepmom_used ? ctx->MTd : ctx->MT)),
-                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)ctx->dual, crows};
+                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)use_dual(ctx), crows};
     int n = std::min(cap, 8);
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
-}
+} PLSX_CATCH(const_cast<plsx_ctx*>(cctx))
 
 int plsx_kernel_timing(const plsx_ctx* cctx, int kernel_class, double* ms_out, int* launches_out)
-{
+try {
     plsx_ctx* ctx = const_cast<plsx_ctx*>(cctx);
     if (!ctx || kernel_class < 0 || kernel_class >= KC_COUNT) return PLSX_ERR_ARG;
     double ms = 0.0;
@@ -2646,7 +2737,7 @@ int plsx_kernel_timing(const plsx_ctx* cctx, int kernel_class, double* ms_out, i
     if (ms_out) *ms_out = ms;
     if (launches_out) *launches_out = launches;
     return PLSX_OK;
-}
+} PLSX_CATCH(const_cast<plsx_ctx*>(cctx))
 
 const char* plsx_kernel_class_name(int kernel_class)
 {
@@ -2654,12 +2745,47 @@ const char* plsx_kernel_class_name(int kernel_class)
 }
 
 int plsx_set_perm_path(plsx_ctx* ctx, int dual)
-{
+try {
     NEED_DATA();
     if (dual >= 0) ctx->dual = (dual && ctx->dual_ok) ? 1 : 0;      // dual < 0: keep the route
     ctx->has_Kd = 0;            // the next dual call forms K again (bench.py: once per timed analysis)
-    return ctx->dual;
+    return use_dual(ctx);
+} PLSX_CATCH(ctx)
+
+int plsx_set_option(plsx_ctx* ctx, const char* key, int value)
+try {
+    if (!ctx || !key) return PLSX_ERR_ARG;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(key, kOptionNames[i])) {
+            // layout-time switches are read by plsx_set_data
+            const bool plan_time = (i == OPT_XPROD_MT24 || i == OPT_MIN_BATCH || i == OPT_INBLOCK_MOMENTS ||
+                                    i == OPT_NO_FIXED_X || i == OPT_NO_DUAL_PERM);
+            if (plan_time && ctx->has_data && ctx->opt[i] != value)
+                return fail(ctx, PLSX_ERR_STATE, std::string("plsx_set_option: '") + key + "' must precede plsx_set_data");
+            ctx->opt[i] = value;
+            return PLSX_OK;
+        }
+    return fail(ctx, PLSX_ERR_ARG, std::string("plsx_set_option: unknown option '") + key + "'");
+} PLSX_CATCH(ctx)
+
+const char* plsx_option_name(int index)
+{
+    return (index >= 0 && index < OPT_COUNT) ? kOptionNames[index] : nullptr;
 }
+
+int plsx_numeric_report(plsx_ctx* ctx, long long* refined, long long* unrefined)
+try {
+    if (!ctx) return PLSX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    int stw[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(stw, ctx->status.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (stw[1] || stw[2]) HIPCHK(hipMemset(static_cast<int*>(ctx->status.p) + 1, 0, 2 * sizeof(int)));
+    if (refined) *refined = ctx->n_refined + stw[1];
+    if (unrefined) *unrefined = ctx->n_unrefined + stw[2];
+    ctx->n_refined = ctx->n_unrefined = 0;
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
 
 // ---- host-side index generators (no device, no context) ------------------------
 namespace {
@@ -2680,7 +2806,7 @@ bool bad_design(const int* groups, int n_groups, int n_cond)
 
 int plsx_gen_permsamp_stream(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
                              int32_t* out, int* rows_done)
-{
+try {
     plsx_rs::MT rs;
     if (bad_design(groups, n_groups, n_cond) || n_perm < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
         return PLSX_ERR_ARG;
@@ -2688,17 +2814,17 @@ int plsx_gen_permsamp_stream(const int* groups, int n_groups, int n_cond, int n_
     memcpy(mt_key, rs.key, sizeof(rs.key));
     *mt_pos = rs.pos;
     return w;
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_gen_permsamp(const int* groups, int n_groups, int n_cond, int n_perm, uint32_t* mt_key, int* mt_pos,
                       int32_t* out)
-{
+try {
     return plsx_gen_permsamp_stream(groups, n_groups, n_cond, n_perm, mt_key, mt_pos, out, nullptr);
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_gen_bootsamp_stream(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
                              int32_t* out, int* rows_done)
-{
+try {
     plsx_rs::MT rs;
     if (bad_design(groups, n_groups, n_cond) || n_boot < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
         return PLSX_ERR_ARG;
@@ -2706,17 +2832,17 @@ int plsx_gen_bootsamp_stream(const int* groups, int n_groups, int n_cond, int n_
     memcpy(mt_key, rs.key, sizeof(rs.key));
     *mt_pos = rs.pos;
     return w;
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_gen_bootsamp(const int* groups, int n_groups, int n_cond, int n_boot, uint32_t* mt_key, int* mt_pos,
                       int32_t* out)
-{
+try {
     return plsx_gen_bootsamp_stream(groups, n_groups, n_cond, n_boot, mt_key, mt_pos, out, nullptr);
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, double test_size, uint32_t* mt_key,
                     int* mt_pos, uint8_t* out)
-{
+try {
     plsx_rs::MT rs;
     if (bad_design(groups, n_groups, n_cond) || n_split < 0 || !out || !mt_pos || load_mt(rs, mt_key, *mt_pos))
         return PLSX_ERR_ARG;
@@ -2724,11 +2850,11 @@ int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, do
     memcpy(mt_key, rs.key, sizeof(rs.key));
     *mt_pos = rs.pos;
     return w;
-}
+} PLSX_CATCH(nullptr)
 
 int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
                            const uint32_t* seeds, int n_seeds, uint8_t* out)
-{
+try {
     if (bad_design(groups, n_groups, n_cond) || n_split < 0 || n_seeds < 0 || !out || (n_seeds && !seeds))
         return PLSX_ERR_ARG;
     const plsx_rs::Design d(groups, n_groups, n_cond);
@@ -2759,6 +2885,6 @@ int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_sp
     int w = 0;
     for (int v : warn) w |= v;
     return w;
-}
+} PLSX_CATCH(nullptr)
 
 }  // extern "C"

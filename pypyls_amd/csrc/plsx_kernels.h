@@ -42,6 +42,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_UROT_KC 20         // k-steps (of 4 rows of T') per LDS stage of the rotation operand when it is staged in pieces
 #define PLSX_LT_CHUNK 6         // 16-column tiles of L per rotation / correlation launch
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
+#define PLSX_REFINE_TAU 1e-3    // live LVs with d < REFINE_TAU * d_max are re-solved on R itself (k_refine_gram):
+                                // the Gram side loses eps (d_max / d)^2, 3.5e-10 at the threshold
 #define PLSX_MOM_PAIRS 192       // (resample, cell) pairs per moment-only cross-product block (12 + 12 tiles)
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
@@ -1991,7 +1993,19 @@ struct SmallArgs {
     int ld;            // column pitch of the work matrices (n | 1)
     int lds_cap;       // QL: doubles of LDS behind the bookkeeping vectors
     double jtol;       // Jacobi stopping threshold on |a_p.a_q| / (|a_p| |a_q|)
-    int* status;       // device word: bit 0 set when an eigen-solve did not converge
+    int* status;       // device words: [0] bit 0 set when an eigen-solve did not converge, [1] resamples whose
+                       // small LVs were refined on R, [2] resamples with graded LVs that could not be (no R on
+                       // the route, or T' > PLSX_JACOBI_TP)
+    // Refinement of graded spectra (T' <= PLSX_JACOBI_TP, routes that keep R in HBM).  phase 0: one launch,
+    // nothing parked; phase 1: a resample with a live LV below PLSX_REFINE_TAU d_max parks its rank-ordered
+    // eigenvectors / eigenvalues and the first small rank k0 and returns; k_refine_gram then forms
+    // G_s = (V_s^T R)(V_s^T R)^T for the parked ones; phase 2: they re-solve G_s, rotate V_s and finish.
+    int phase;
+    double* refV;      // [nres][n][n] column k = eigenvector of rank k
+    double* refLam;    // [nres][n]
+    int* refK0;        // [nres] first refined rank (0: not parked)
+    const double* refPart;   // [nres][ref_nchunk][n][n] partial G_s (top-left (n - k0)^2 entries)
+    int ref_nchunk;
 };
 
 // LDS Jacobi variant (T' <= PLSX_JACOBI_TP): both n x (n|1) work matrices in LDS, one block per
@@ -2009,23 +2023,52 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     int* order = rank + n;                         // [n] physical column of rank k
     __shared__ int s_flag;
     __shared__ double s_dmax;
+    __shared__ int s_k0;
     const int tid = threadIdx.x;
     const double* G = a.G + (size_t)r * n * n;
 
-    for (int idx = tid; idx < n * n; idx += blockDim.x) {
-        int c = idx / n, i = idx % n;
-        bufA[c * ld + i] = G[(size_t)i * n + c];
-        bufV[c * ld + i] = (i == c) ? 1.0 : 0.0;
+    if (a.phase == 2) {
+        // A parked resample: eigenvectors of rank >= k0 span the subspace of its small singular values to
+        // eps (d_max / d_k0)^2, but inside it the Gram-side solve is only good to eps (d_max / d_k)^2.
+        // G_s = (V_s^T R)(V_s^T R)^T was formed from R itself (k_refine_gram: its entries carry errors
+        // relative to the SMALL scale); its eigenvectors W rotate V_s, its eigenvalues replace lam.
+        const int k0 = a.refK0[r];
+        if (!k0) return;
+        const int m = n - k0;
+        const double* rv = a.refV + (size_t)r * n * n;
+        for (int idx = tid; idx < n * n; idx += blockDim.x) bufV[(idx / n) * ld + (idx % n)] = rv[idx];
+        for (int k = tid; k < n; k += blockDim.x) lam[k] = a.refLam[(size_t)r * n + k];
+        const double* pp = a.refPart + (size_t)r * a.ref_nchunk * n * n;
+        for (int idx = tid; idx < m * m; idx += blockDim.x) {
+            const int c = idx / m, i = idx % m;
+            double s = 0.0;
+            for (int ch = 0; ch < a.ref_nchunk; ++ch) s += pp[((size_t)ch * n + i) * n + c];
+            bufA[c * ld + i] = s;
+        }
+        __syncthreads();
+        jacobi_cols_reg<ITL, 8>(bufA, m, bufV + (size_t)k0 * ld, n, m, ld, &s_flag, a.jtol);
+        for (int c = tid; c < m; c += blockDim.x) {
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) { double x = bufA[c * ld + i]; s += x * x; }
+            lam[k0 + c] = sqrt(s);
+        }
+        __syncthreads();
+    } else {
+        for (int idx = tid; idx < n * n; idx += blockDim.x) {
+            int c = idx / n, i = idx % n;
+            bufA[c * ld + i] = G[(size_t)i * n + c];
+            bufV[c * ld + i] = (i == c) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        jacobi_cols_reg<ITL, 8>(bufA, n, bufV, n, n, ld, &s_flag, a.jtol);
+        // eigenvalues = column norms of G.V (G is PSD)
+        for (int c = tid; c < n; c += blockDim.x) {
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) { double x = bufA[c * ld + i]; s += x * x; }
+            lam[c] = sqrt(s);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    jacobi_cols_reg<ITL, 8>(bufA, n, bufV, n, n, ld, &s_flag, a.jtol);
-    // eigenvalues = column norms of G.V (G is PSD)
-    for (int c = tid; c < n; c += blockDim.x) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) { double x = bufA[c * ld + i]; s += x * x; }
-        lam[c] = sqrt(s);
-    }
-    __syncthreads();
     for (int c = tid; c < n; c += blockDim.x) {
         int rk = 0;
         const double lc = lam[c];
@@ -2040,6 +2083,26 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     if (tid == 0) s_dmax = sqrt(lam[order[0]]);
     __syncthreads();
     const double dmax = s_dmax;
+
+    if (a.phase != 2) {
+        // graded spectrum?  first rank below PLSX_REFINE_TAU d_max that is still live
+        if (tid == 0) {
+            int k0 = 0;
+            for (int k = 1; k < L; ++k)
+                if (sqrt(lam[order[k]]) < PLSX_REFINE_TAU * dmax) { k0 = k; break; }
+            if (k0 && !(sqrt(lam[order[k0]]) > PLSX_RANK_RTOL * dmax)) k0 = 0;
+            s_k0 = k0;
+            if (a.phase == 1) a.refK0[r] = k0;
+            if (k0) atomicAdd(a.status + (a.phase == 1 ? 1 : 2), 1);
+        }
+        __syncthreads();
+        if (a.phase == 1 && s_k0) {
+            double* rv = a.refV + (size_t)r * n * n;
+            for (int idx = tid; idx < n * n; idx += blockDim.x) rv[idx] = bufV[order[idx / n] * ld + (idx % n)];
+            for (int k = tid; k < n; k += blockDim.x) a.refLam[(size_t)r * n + k] = lam[order[k]];
+            return;
+        }
+    }
 
     if (a.mode == SMALL_DECOMP) {
         for (int idx = tid; idx < n * L; idx += blockDim.x) {
@@ -2214,7 +2277,17 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
         order[rk] = c;
     }
     __syncthreads();
-    if (tid == 0) s_dmax = sqrt(lam[order[0]]);
+    if (tid == 0) {
+        s_dmax = sqrt(lam[order[0]]);
+        // graded spectra are not refined on this path (see small_solve): counted, reported by plsx_numeric_report
+        for (int k = 1; k < L; ++k) {
+            const double dk = sqrt(lam[order[k]]);
+            if (dk < PLSX_REFINE_TAU * s_dmax) {
+                if (dk > PLSX_RANK_RTOL * s_dmax) atomicAdd(a.status + 2, 1);
+                break;
+            }
+        }
+    }
     __syncthreads();
     const double dmax = s_dmax;
 
@@ -2314,6 +2387,82 @@ void k_small(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];
     small_solve<ITL>(a, blockIdx.x, sm_s);
+}
+
+// Refined Gram matrix of the small-singular-value subspace of parked resamples (SmallArgs::phase):
+//   Y = V_s^T R   (m x B, m = n - k0 trailing eigenvectors of the first solve),  G_s = Y Y^T,
+// summed over the block's chunk of feature columns into part[r][chunk][n][n] (top-left m x m).  R is read
+// once; the entries of Y are O(d_small) sums of O(d_max) terms, so G_s carries eps d_max d_small -- the
+// accuracy LAPACK's SVD of R has for these singular values -- instead of the eps d_max^2 of R R^T.
+// Only graded data ever gets here (blocks of resamples that are not parked return at once): plain fp64
+// VALU code, 64 columns per step -- stage 1: wave w forms rows [16 w, 16 w + 16) of Y for one column per
+// lane (V_s broadcast from LDS); stage 2: 4 x 4 register tiles of G_s over the 64 columns in LDS.
+__global__ __launch_bounds__(256)
+void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int B, int n,
+                   const double* __restrict__ refV, const int* __restrict__ refK0,
+                   double* __restrict__ part, int nchunk)
+{
+    const int r = blockIdx.y, ch = blockIdx.x;
+    const int k0 = refK0[r];
+    if (!k0) return;
+    const int m = n - k0;
+    extern __shared__ __attribute__((aligned(16))) double sm_r[];
+    double* Vs = sm_r;                    // [n][64]: Vs[t][j] = eigenvector k0 + j, entry t (zero for j >= m)
+    double* Yl = Vs + (size_t)n * 64;     // [64 columns][66]
+    const int tid = threadIdx.x;
+    const double* rv = refV + (size_t)r * n * n;
+    for (int idx = tid; idx < n * 64; idx += 256) {
+        const int t = idx >> 6, j = idx & 63;
+        Vs[idx] = j < m ? rv[(size_t)(k0 + j) * n + t] : 0.0;
+    }
+    const int cpc = ((B + nchunk - 1) / nchunk + 63) / 64 * 64;
+    const int b_lo = ch * cpc, b_hi = min(B, b_lo + cpc);
+    const int kg = tid >> 6, c = tid & 63;          // stage 1: rows [16 kg, 16 kg + 16) of Y, column c
+    const int ti = tid >> 4, tj = tid & 15;         // stage 2: G_s[4 ti ..][4 tj ..]
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    const double* Rr = R + (size_t)r * strideR;
+    __syncthreads();
+    for (int b0 = b_lo; b0 < b_hi; b0 += 64) {
+        double y[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) y[j] = 0.0;
+        if (16 * kg < m) {
+            const int col = b0 + c;
+            const bool ok = col < b_hi;
+            const double* rp = Rr + (ok ? col : b_lo);
+            for (int t = 0; t < n; ++t) {
+                const double x = ok ? rp[(size_t)t * ldr] : 0.0;
+                const double* vr = Vs + t * 64 + 16 * kg;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) y[j] = __builtin_fma(vr[j], x, y[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Yl[c * 66 + 16 * kg + j] = y[j];
+        __syncthreads();
+        if (4 * ti < m && 4 * tj < m) {
+            for (int cc = 0; cc < 64; ++cc) {
+                double ya[4], yb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ya[i] = Yl[cc * 66 + 4 * ti + i]; yb[i] = Yl[cc * 66 + 4 * tj + i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(ya[i], yb[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    double* po = part + ((size_t)r * nchunk + ch) * n * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * ti + i < m && 4 * tj + j < m) po[(size_t)(4 * ti + i) * n + 4 * tj + j] = acc[i][j];
 }
 
 // ---------------------------------------------------------------------------

@@ -67,6 +67,9 @@ def _load():
         'plsx_kernel_timing': ([vp, i32, ctypes.POINTER(c_d), ctypes.POINTER(i32)], i32),
         'plsx_kernel_class_name': ([i32], ctypes.c_char_p),
         'plsx_set_perm_path': ([vp, i32], i32),
+        'plsx_set_option': ([vp, ctypes.c_char_p, i32], i32),
+        'plsx_option_name': ([i32], ctypes.c_char_p),
+        'plsx_numeric_report': ([vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)], i32),
         'plsx_set_scratch': ([vp, c_d, i32], i32),
         'plsx_mfma_f64_peak': ([vp, ctypes.POINTER(c_d)], i32),
         'plsx_percentile_ci': ([vp, vp, ctypes.c_longlong, i32, i32, c_d, i32, c_d, vp, vp, vp], i32),
@@ -102,13 +105,52 @@ def exported_symbols():
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
              'plsx_gen_splits', 'plsx_gen_splits_seeded', 'plsx_gen_permsamp_stream',
-             'plsx_gen_bootsamp_stream']
+             'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report']
     return [n for n in names if hasattr(lib, n)]
 
 
 def _torch():
     import torch
     return torch
+
+
+def option_names():
+    """Keys of plsx_set_option (include/plsx.h)."""
+    lib = _load()
+    out, i = [], 0
+    while True:
+        name = lib.plsx_option_name(i)
+        if not name:
+            return out
+        out.append(name.decode())
+        i += 1
+
+
+def options_from_env(environ=None):
+    """``{'options': {...}, 'scratch_gb': ...}`` keyword arguments for :class:`Engine` from
+    ``PLSX_<KEY>=<int>`` variables.  libplsx.so itself reads no environment variable and
+    neither does the product path (``Engine()``, the front-ends): only bench.py, tools/ and
+    the tests translate the environment -- so that one A/B command line or one monkeypatched
+    test can select a kernel route -- through this helper."""
+    environ = os.environ if environ is None else environ
+    opts = {}
+    for key in option_names():
+        val = environ.get('PLSX_' + key.upper())
+        if val is not None and val != '':
+            try:
+                opts[key] = int(val)
+            except ValueError:
+                opts[key] = 1
+    kw = {'options': opts}
+    if environ.get('PLSX_SCRATCH_GB'):
+        kw['scratch_gb'] = float(environ['PLSX_SCRATCH_GB'])
+    return kw
+
+
+class GradedSpectrumWarning(UserWarning):
+    """Resamples had live latent variables below 1e-3 of the largest singular value that the
+    device could not refine on R (T' > 64, or a dual-space route): their smallest LVs may miss
+    the 1e-5 relative tolerance against an SVD of R (include/plsx.h, plsx_numeric_report)."""
 
 
 def check_index_array(samples, S):
@@ -134,10 +176,12 @@ class Engine(object):
     """One device context.  All ndarray arguments / results are host numpy
     arrays unless a method says it returns a device tensor."""
 
-    def __init__(self, device=None, scratch_gb=None):
+    def __init__(self, device=None, scratch_gb=None, options=None):
         """``scratch_gb``: fixed super-batch scratch budget for a long-lived
         engine (steady-state throughput); None sizes the scratch per call
-        (include/plsx.h, plsx_set_scratch)."""
+        (include/plsx.h, plsx_set_scratch).  ``options``: {key: int} route / layout
+        switches for plsx_set_option (A/B measurements and tests; every route
+        computes the same statistics)."""
         torch = _torch()
         if not torch.cuda.is_available():
             raise PlsxError('no AMD GPU visible to PyTorch-ROCm: the PLS resampling engine has '
@@ -153,8 +197,11 @@ class Engine(object):
             raise PlsxError('plsx_ctx_create failed with status {}'.format(rc))
         self.ctx = ctx
         self.S = self.B = self.L = self.Tp = 0
+        self.refined = self.unrefined = 0
         if scratch_gb is not None:
             self._check(self.lib.plsx_set_scratch(self.ctx, float(scratch_gb), 1))
+        for key, val in (options or {}).items():
+            self.set_option(key, val)
 
     # -- plumbing ---------------------------------------------------------
     def close(self):
@@ -190,8 +237,27 @@ class Engine(object):
         torch = _torch()
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
+    def set_option(self, key, value=1):
+        self._check(self.lib.plsx_set_option(self.ctx, str(key).encode(), int(value)))
+
     def sync(self):
         self._check(self.lib.plsx_sync(self.ctx))
+
+    def numeric_report(self, warn=True):
+        """(refined, unrefined) resample counts of graded spectra since the last call
+        (plsx_numeric_report); warns when some could not be refined."""
+        a, b = ctypes.c_longlong(), ctypes.c_longlong()
+        self._check(self.lib.plsx_numeric_report(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        self.refined += a.value
+        self.unrefined += b.value
+        if warn and b.value:
+            import warnings
+            warnings.warn('{} decomposition(s) had live latent variables below 1e-3 of the largest singular '
+                          'value that could not be refined on the cross-covariance matrix (T\' > 64 or a '
+                          'dual-space route): singular values below ~6e-6 of the largest may differ from an '
+                          'SVD of R by more than 1e-5 relative'.format(b.value), GradedSpectrumWarning,
+                          stacklevel=2)
+        return a.value, b.value
 
     # -- data -------------------------------------------------------------
     def set_data(self, X, Y, cell_of_row, n_groups, n_cond, method, mean_centering=0,

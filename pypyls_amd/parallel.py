@@ -70,9 +70,9 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-import os as _os
-
-BOOT_PARTS = int(_os.environ.get('PLSX_BOOT_PARTS', '1'))       # chunks per rank of the bootstrap shards (1 = one contiguous slice).  Chunk-cyclic shards
+BOOT_PARTS = 1       # chunks per rank of the bootstrap shards (1 = one contiguous slice); a module constant, NOT read
+                     # from the environment: every rank derives every rank's row order from it (collect_slices), so
+                     # it must be identical everywhere.  Chunk-cyclic shards
                      # (2, 4) were measured on the emulated 8-rank critical path of c4 and LOSE: the last rank's
                      # bootstraps exist 26 ms into the step instead of 28 (all 10 000 bootstrap rows are drawn in
                      # 13 ms once the 10 000 permutations are, 17 ms), while every extra launch costs a wave of

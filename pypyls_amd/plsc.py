@@ -220,6 +220,7 @@ class _PLSCRun(object):
         for st in (pstream, bstream):
             if st is not None:
                 st.warn()
+        eng.sync()                 # numerical status of the launches above is raised HERE, for the batch that set it
         orig_splits = self.orig_splits
         n_split = inp.get('n_split')
         slices, totals = [], []
@@ -337,6 +338,7 @@ class _PLSCRun(object):
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv
+        eng.numeric_report()       # warns when graded decompositions could not be refined (T' > 64)
         self.engine_used = eng
         return res
 

@@ -247,6 +247,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     for st in (pstream, bstream):
         if st is not None:
             st.warn()
+    eng.sync()                     # numerical status of the launches above is raised here
     slices = [t for t in (d_perm, d_yl) if t is not None]
     totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
     full, summed = parallel.collect_slices(slices, totals, [usum, usq] if usum is not None else [],

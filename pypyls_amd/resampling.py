@@ -21,8 +21,8 @@ the readable restatement, also the checker of the native one) and the native
 generators of libplsx.so (csrc/plsx_resample.h: MT19937 + numpy's legacy
 sampling algorithms in C++), used by default because the Python loops would
 cap multi-GPU scaling (1 s for 10 000 + 10 000 index vectors, 30 s for the
-10 000 x 100 split masks of a split-half run).  ``PLSX_PY_RESAMPLE=1`` forces
-the Python loops.  The RandomState is handed over and back through
+10 000 x 100 split masks of a split-half run).  ``resampling.FORCE_PYTHON = True``
+(tests) forces the Python loops.  The RandomState is handed over and back through
 ``get_state`` / ``set_state``, so a stream shared with other draws stays in
 step with the reference's.
 """
@@ -34,9 +34,12 @@ import warnings
 import numpy as np
 
 
+FORCE_PYTHON = False          # tests: take the Python loops instead of the native generators
+
+
 def _native():
     """libplsx.so for the native generators, or None (forced off / not built)."""
-    if os.environ.get('PLSX_PY_RESAMPLE'):
+    if FORCE_PYTHON:
         return None
     try:
         from . import engine
@@ -154,7 +157,9 @@ def gen_permsamp(groups, n_cond, n_perm, seed=None, verbose=True):
     return _py_gen_permsamp(groups, n_cond, n_perm, rs)
 
 
-def _py_gen_permsamp(groups, n_cond, n_perm, seed=None, verbose=True):
+def _py_gen_permsamp(groups, n_cond, n_perm, seed=None, verbose=True, dup_flag=None):
+    # dup_flag: a list that receives True instead of the warning (IndexStream.draw runs on a thread, where
+    # warnings.catch_warnings -- process-global filter state -- must not be used)
     des = _Design(groups, n_cond)
     rs = check_random_state(seed)
     out = np.zeros((des.n_rows, n_perm), dtype=int)
@@ -179,7 +184,10 @@ def _py_gen_permsamp(groups, n_cond, n_perm, seed=None, verbose=True):
             if key in seen:
                 duplicated = True
         if count == 500 and not warned:
-            warnings.warn('WARNING: Duplicate permutations used.')
+            if dup_flag is not None:
+                dup_flag.append(True)
+            else:
+                warnings.warn('WARNING: Duplicate permutations used.')
             warned = True
         seen.add(key)
         out[:, i] = perminds
@@ -199,7 +207,9 @@ def gen_bootsamp(groups, n_cond, n_boot, seed=None, verbose=True):
     return _py_gen_bootsamp(groups, n_cond, n_boot, rs)
 
 
-def _py_gen_bootsamp(groups, n_cond, n_boot, seed=None, verbose=True):
+def _py_gen_bootsamp(groups, n_cond, n_boot, seed=None, verbose=True, dup_flag=None):
+    # dup_flag: a list that receives True instead of the warning (IndexStream.draw runs on a thread, where
+    # warnings.catch_warnings -- process-global filter state -- must not be used)
     des = _Design(groups, n_cond)
     rs = check_random_state(seed)
     out = np.zeros((des.n_rows, n_boot), dtype=int)
@@ -224,7 +234,10 @@ def _py_gen_bootsamp(groups, n_cond, n_boot, seed=None, verbose=True):
             if any(k in s for k, s in zip(keys, seen)):
                 duplicated = True
         if count == 500 and not warned:
-            warnings.warn('WARNING: Duplicate bootstraps used.')
+            if dup_flag is not None:
+                dup_flag.append(True)
+            else:
+                warnings.warn('WARNING: Duplicate bootstraps used.')
             warned = True
         for k, s in zip(keys, seen):
             s.add(k)
@@ -329,6 +342,7 @@ class IndexStream(object):
         self.finished = threading.Event()
         self.error = None
         self.duplicates = False
+        self.owner = None                               # the DrawThread whose job list holds draw()
 
     @classmethod
     def of_array(cls, samples):
@@ -342,7 +356,7 @@ class IndexStream(object):
         import threading
         st.finished = threading.Event()
         st.finished.set()
-        st.error, st.duplicates = None, False
+        st.error, st.duplicates, st.owner = None, False, None
         return st
 
     def draw(self, rs):
@@ -352,11 +366,10 @@ class IndexStream(object):
             done = _native_call(fn, rs, self.groups, self.n_cond, self.n, self.rows,
                                 tail=(ctypes.byref(self._done),))
             if not done:
-                with warnings.catch_warnings(record=True) as caught:
-                    warnings.simplefilter('always')
-                    py = _py_gen_permsamp if self.kind == 'perm' else _py_gen_bootsamp
-                    self.rows[:] = py(self.groups, self.n_cond, self.n, rs).T
-                self.duplicates = any('Duplicate' in str(w.message) for w in caught)
+                dup = []
+                py = _py_gen_permsamp if self.kind == 'perm' else _py_gen_bootsamp
+                self.rows[:] = py(self.groups, self.n_cond, self.n, rs, dup_flag=dup).T
+                self.duplicates = bool(dup)
             else:
                 self.duplicates = done == 2
             self._done.value = self.n
@@ -373,6 +386,9 @@ class IndexStream(object):
         import time
         upto = min(int(upto), self.n)
         while self._done.value < upto and not self.finished.is_set():
+            # an EARLIER job of the generator thread failed: this stream will never be drawn
+            if self.owner is not None and self.owner.error is not None:
+                raise self.owner.error
             time.sleep(2e-5)
         if self.error is not None:
             raise self.error
@@ -390,20 +406,24 @@ class IndexStream(object):
         return np.ascontiguousarray(self.rows.T, dtype=np.int64)
 
     def chunks(self, lo, hi, first=256, grow=4, limit=None):
-        """Row ranges [a, b) covering [lo, hi) as they become final: a first small
-        one so that the device starts early, then everything that has arrived
-        (at most ``limit`` rows per range)."""
+        """Row ranges [a, b) covering [lo, hi), yielded as they become final: a first small
+        one so that the device starts early, then ranges ``grow`` times longer (at most
+        ``limit`` rows each).  The boundaries are a function of (lo, hi, first, grow, limit)
+        ONLY -- not of how far the generator thread has got -- so the launch sizes, and with
+        them the kernel layouts and the floating-point summation order of the accumulated
+        bootstrap sums, are the same on every run of a seed (bit-reproducible results).  A
+        caller-supplied array (``of_array``) is one range."""
         pos, size = int(lo), int(first)
+        if self.kind == 'given' and limit is None:
+            size = max(size, int(hi) - pos)
         while pos < hi:
-            want = min(hi, pos + size)
-            if hi - want < size // 2:                   # no tiny last launch: a range of 25 rows costs
-                want = hi                               # the device as much as one of 250
-            have = self.wait(want)
-            if limit is not None:
-                have = min(have, pos + int(limit))
-            end = min(hi, max(want, have))
-            yield pos, end
-            pos, size = end, size * grow
+            step = size if limit is None else min(size, int(limit))
+            want = min(hi, pos + step)
+            if hi - want < step // 2 and (limit is None or hi - pos <= int(limit)):
+                want = hi                               # no tiny last launch: a range of 25 rows costs
+            self.wait(want)                             # the device as much as one of 250
+            yield pos, want
+            pos, size = want, size * grow
 
 
 class DrawThread(object):
@@ -416,6 +436,10 @@ class DrawThread(object):
     def __init__(self, rs, jobs):
         import threading
         self.rs, self.jobs, self.error = rs, list(jobs), None
+        for job in self.jobs:                           # streams learn who draws them: a failure of an
+            st = getattr(job, '__self__', None)         # earlier job must not leave their consumers waiting
+            if isinstance(st, IndexStream):
+                st.owner = self
         self.thread = threading.Thread(target=self._run, name='plsx-draws', daemon=True)
 
     def start(self):
@@ -423,11 +447,19 @@ class DrawThread(object):
         return self
 
     def _run(self):
+        k = 0
         try:
-            for job in self.jobs:
+            for k, job in enumerate(self.jobs):
                 job(self.rs)
         except BaseException as exc:
             self.error = exc
+            # the jobs behind the failed one never run: fail their streams so that a consumer blocked in
+            # IndexStream.wait() (and, under torch.distributed, every rank behind it) raises instead of spinning
+            for job in self.jobs[k + 1:]:
+                st = getattr(job, '__self__', None)
+                if isinstance(st, IndexStream) and not st.finished.is_set():
+                    st.error = exc
+                    st.finished.set()
 
     def join(self):
         self.thread.join()

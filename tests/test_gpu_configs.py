@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine():
-    from pypyls_amd.engine import Engine
-    return Engine()
+    from pypyls_amd.engine import Engine, options_from_env
+    return Engine(**options_from_env())          # PLSX_<KEY>=1 (monkeypatched per test) -> plsx_set_option
 
 
 def _synth(S, B, T, seed=0):

@@ -6,7 +6,8 @@ squares the condition number of R; the reference decomposes R itself
 data, where d_1 / d_L stays below ~10.  Here the behaviours are nearly
 collinear (graded mixtures, near-duplicate columns, one EXACTLY collinear
 column) or the cell effects of a mean-centred design are graded, so that
-d_1 / d_L = 1e1 ... 1e4, and every comparison is PER LATENT VARIABLE:
+d_1 / d_L = 1e1 ... 7e5 (the engine's rank threshold is 1e6), and every comparison is
+PER LATENT VARIABLE:
 
     |a_k - b_k| <= rtol * |b_k|            singular values, rows of perm_singval
     max|a[:, k] - b[:, k]| <= rtol * max|b[:, k]|   weights, sum U, sum U^2,
@@ -16,6 +17,13 @@ with rtol = 1e-5, the north-star tolerance (BASELINE.json), against the oracle
 (exact LAPACK SVD of R).  Only LVs the reference's own comparator would mask
 (pyls/tests/matlab.py:160: ``isclose(singvals, 0)``; here d_k <= 1e-6 d_1,
 oracle.live_lvs) are excluded, and only in the exactly-collinear cases.
+
+Round 4: above d_1 / d_L ~ 1.7e5 the plain Gram-side solve (eps (d_1/d_k)^2) leaves the
+tolerance; resamples with a live LV below 1e-3 d_1 are re-solved on R itself
+(plsx_kernels.h: SmallArgs::phase, k_refine_gram), and data whose original spectrum is
+graded leaves the dual-space routes.  The cases above 1e3 assert that the refinement ran
+(Engine.numeric_report) and that nothing graded stayed unrefined; ``no_refine`` shows the
+law it removes.
 """
 import numpy as np
 import pytest
@@ -28,8 +36,8 @@ RTOL = 1e-5
 
 
 def _engine():
-    from pypyls_amd.engine import Engine
-    return Engine()
+    from pypyls_amd.engine import Engine, options_from_env
+    return Engine(**options_from_env())          # PLSX_<KEY>=1 (monkeypatched per test) -> plsx_set_option
 
 
 def per_lv_close(got, want, axis, rtol=RTOL, what='', mask=None):
@@ -121,6 +129,10 @@ def run_case(X, Y, groups, n_cond, method, mean_centering=0, n=8, min_ratio=None
     bsr_g, _ = ref.boot_rel(U @ d, usum, usq, n)
     bsr_w, _ = ref.boot_rel(U @ d, ws, wq, n)
     worst = max(worst, bsr_close(bsr_g, bsr_w, ws, wq, n, live))
+    refined, unrefined = eng.numeric_report(warn=False)
+    assert unrefined == 0, 'graded decompositions left unrefined: {}'.format(unrefined)
+    if ratio > 3e3:
+        assert refined > 0, 'd_1/d_L = {:.3g} but no decomposition was refined'.format(ratio)
     return ratio, worst
 
 
@@ -149,7 +161,7 @@ def bsr_close(got, want, u_sum, u_square, n, live, rtol=RTOL):
 
 
 @pytest.mark.parametrize('kind', ['mix', 'dup'])
-@pytest.mark.parametrize('ratio', [1e1, 1e2, 1e3, 1e4])
+@pytest.mark.parametrize('ratio', [1e1, 1e2, 1e3, 1e4, 1e5, 3e5, 6e5])
 @pytest.mark.parametrize('S,groups,n_cond', [(80, [80], 1), (200, [50, 50], 2), (500, [500], 1)])
 def test_behavioral_graded_spectrum(S, groups, n_cond, ratio, kind):
     rs = np.random.RandomState(int(S + np.log10(ratio) * 7 + (kind == 'dup')))
@@ -175,12 +187,17 @@ def test_behavioral_exactly_collinear_column(S, groups, n_cond):
     print('collinear S={}: live d1/dL = {:.3g}, worst {:.2e}'.format(S, ratio, worst))
 
 
-@pytest.mark.parametrize('ratio', [1e1, 1e2, 1e3, 1e4])
+@pytest.mark.parametrize('two_pass', [False, True])
+@pytest.mark.parametrize('ratio', [1e1, 1e2, 1e3, 1e4, 1e5, 3e5, 6e5])
 @pytest.mark.parametrize('groups,n_cond,mc', [([30, 30, 30], 2, 0), ([40, 40], 3, 1), ([25, 25, 25, 25], 2, 2)])
-def test_meancentered_graded_spectrum(groups, n_cond, mc, ratio):
+def test_meancentered_graded_spectrum(groups, n_cond, mc, ratio, two_pass, monkeypatch):
     """Cell effects of graded size on top of small noise: the live singular values of the
-    mean-centred cell-mean matrix span ``ratio``."""
+    mean-centred cell-mean matrix span ``ratio``.  Default route (single-pass bootstrap in the
+    dual space while the original spectrum is not graded, the feature pass with refinement
+    once it is) and the two-pass route forced (PLSX_TWO_PASS_BOOT -> plsx_set_option)."""
     from pypyls_amd import resampling as rsmp
+    if two_pass:
+        monkeypatch.setenv('PLSX_TWO_PASS_BOOT', '1')
     rs = np.random.RandomState(int(sum(groups) + mc + np.log10(ratio)))
     S, B = sum(groups) * n_cond, 4000
     cells = rsmp.cell_of_row(groups, n_cond)
@@ -203,3 +220,37 @@ def test_meancentered_graded_spectrum(groups, n_cond, mc, ratio):
                                 min_ratio=ratio / 30, max_ratio=ratio * 30, null_lvs=nnull)
     print('meancentered {} x {} mc {} target {:g}: d1/dL = {:.3g}, worst {:.2e}'.format(
         groups, n_cond, mc, ratio, got_ratio, worst))
+
+
+def test_unrefined_graded_spectrum_is_counted_and_warned(monkeypatch):
+    """``no_refine`` (the round-3 behaviour): a spectrum of d_1/d_L ~ 2e5 is solved on the Gram side
+    only and misses 1e-5 on its smallest LV -- and the engine SAYS so: every graded decomposition
+    is counted (plsx_numeric_report) and Engine.numeric_report warns."""
+    from pypyls_amd import resampling as rsmp
+    from pypyls_amd.engine import GradedSpectrumWarning
+    monkeypatch.setenv('PLSX_NO_REFINE', '1')
+    S, B, T = 80, 3000, 8
+    rs = np.random.RandomState(101)
+    X = rs.randn(S, B)
+    Y = graded_behaviours(rs, S, T, 3e5, 'mix')
+    eng = _engine()
+    eng.set_data(X, Y, rsmp.cell_of_row([S], 1), 1, 1, 0)
+    spec = ref.Spec('behavioral', [S], 1, False, 0)
+    U, d, V = ref.decompose(spec, X, Y)
+    dv = np.diag(d)
+    xw, sv, yw = eng.decompose()
+    rel = np.abs(sv - dv) / dv
+    print('no_refine: d1/dL = {:.3g}, per-LV rel err {}'.format(dv[0] / dv[-1], np.array2string(rel, precision=1)))
+    assert rel[:3].max() < 1e-9
+    assert rel[-1] > 1e-8            # the eps (d_1/d_L)^2 law; with the refinement the same LV is < 1e-9
+    with pytest.warns(GradedSpectrumWarning):
+        refined, unrefined = eng.numeric_report()
+    assert refined == 0 and unrefined >= 1
+    monkeypatch.delenv('PLSX_NO_REFINE')
+    eng2 = _engine()
+    eng2.set_data(X, Y, rsmp.cell_of_row([S], 1), 1, 1, 0)
+    xw2, sv2, yw2 = eng2.decompose()
+    rel2 = np.abs(sv2 - dv) / dv
+    print('refined:   per-LV rel err {}'.format(np.array2string(rel2, precision=1)))
+    assert rel2.max() < 1e-8
+    assert eng2.numeric_report() == (1, 0)

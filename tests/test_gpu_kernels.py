@@ -9,8 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine():
-    from pypyls_amd.engine import Engine
-    return Engine()
+    from pypyls_amd.engine import Engine, options_from_env
+    return Engine(**options_from_env())          # PLSX_<KEY>=1 (monkeypatched per test) -> plsx_set_option
 
 
 def _data(S, B, T, seed=0, signal=0.5):
@@ -293,7 +293,7 @@ def test_separate_moments_layout_equals_in_block(shape):
     """Correlation mode: data-only cross-product blocks scaled from the table that moment-only blocks
     write (k_xprod EPI 3 / 4; chosen per launch by tile passes, here forced: PLSX_SEPMOM_ALWAYS) against
     in-block moment rows (PLSX_INBLOCK_MOMENTS) and the oracle -- R itself, bootstraps, and the two-pass
-    split-half route (masked resamples: rows with xsrc = -1).  Own processes: the switches are read once."""
+    split-half route (masked resamples: rows with xsrc = -1).  Own processes (historical: the switches used to be read once per process)."""
     import subprocess
     import sys
     import json
@@ -302,11 +302,11 @@ def test_separate_moments_layout_equals_in_block(shape):
 import sys, json, numpy as np
 sys.path.insert(0, %r)
 from pypyls_amd import resampling as rsmp
-from pypyls_amd.engine import Engine
+from pypyls_amd.engine import Engine, options_from_env
 S, B, T, groups, n_cond = %r
 rs = np.random.RandomState(3)
 X = rs.randn(S, B) * (0.5 + rs.rand(1, B)); Y = rs.randn(S, T) + 0.4 * X[:, :T]
-eng = Engine()
+eng = Engine(**options_from_env())
 eng.set_data(X, Y, rsmp.cell_of_row(groups, n_cond), len(groups), n_cond, 0)
 boots = rsmp.gen_bootsamp(groups, n_cond, 45, seed=4)
 R = eng.crosscov(xsrc=boots, ysrc=boots)
@@ -354,7 +354,7 @@ def test_compact_blocks_equal_dense_blocks(shape):
     (PLSX_SPLIT_INBLOCK = the 7-per-block fused layout) against the dense layouts: bootstrap sums, distrib,
     split-half correlations.  Every tile count 1..4, with and without the tail, J = 1..16 cells (16 cells:
     compact bootstraps, but the split-half epilogue's column tables no longer fit: dense fused layout).
-    Own processes: the switches are read once."""
+    Own processes (historical: the switches used to be read once per process)."""
     import json
     import os
     import subprocess
@@ -365,11 +365,11 @@ def test_compact_blocks_equal_dense_blocks(shape):
 import sys, json, numpy as np
 sys.path.insert(0, %r)
 from pypyls_amd import resampling as rsmp
-from pypyls_amd.engine import Engine
+from pypyls_amd.engine import Engine, options_from_env
 S, B, T, groups, n_cond = %r
 rs = np.random.RandomState(3)
 X = rs.randn(S, B) * (0.5 + rs.rand(1, B)); Y = rs.randn(S, T) + 0.4 * X[:, :T]
-eng = Engine()
+eng = Engine(**options_from_env())
 eng.set_data(X, Y, rsmp.cell_of_row(groups, n_cond), len(groups), n_cond, 0)
 boots = rsmp.gen_bootsamp(groups, n_cond, 45, seed=4)
 xw, sv, yw = eng.decompose()

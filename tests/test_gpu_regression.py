@@ -160,7 +160,9 @@ def test_single_pass_bootstrap_equals_two_pass(monkeypatch):
     for route in ('single', 'two'):
         if route == 'two':
             monkeypatch.setenv('PLSX_TWO_PASS_BOOT', '1')
-        out[route] = pls.pls_regression(X, Y, n_components=k, n_perm=10, n_boot=700, seed=99, verbose=False)
+        from pypyls_amd.engine import Engine, options_from_env
+        out[route] = pls.pls_regression(X, Y, n_components=k, n_perm=10, n_boot=700, seed=99, verbose=False,
+                                        _engine=Engine(**options_from_env()))
     monkeypatch.delenv('PLSX_TWO_PASS_BOOT')
     a, b = out['single'], out['two']
     np.testing.assert_array_equal(a.bootres.bootsamples, b.bootres.bootsamples)

@@ -234,3 +234,56 @@ def test_shared_seed_multiprocess_gloo(tmp_path):
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok') == 2
+
+
+def test_every_c_abi_entry_is_guarded_and_reads_no_environment():
+    """no C++ exception crosses the ABI, and the route switches are an interface
+    (plsx_set_option), not ambient environment.  Every ``extern "C"`` definition in plsx_api.hip is either
+    a function-try-block closed by PLSX_CATCH or a one-line accessor that cannot throw; nothing under
+    csrc/ calls getenv."""
+    import re
+    src = open(os.path.join(ROOT, 'pypyls_amd', 'csrc', 'plsx_api.hip')).read()
+    lines = src.split('\n')
+    header = open(os.path.join(ROOT, 'include', 'plsx.h')).read()
+    declared = set(re.findall(r'\b(plsx_\w+)\s*\(', header))
+    trivial = {'plsx_version', 'plsx_max_tprime', 'plsx_last_error', 'plsx_num_lv', 'plsx_tprime',
+               'plsx_kernel_class_name', 'plsx_option_name'}
+    defined, unguarded = set(), []
+    for i, ln in enumerate(lines):
+        m = re.match(r'^(?:int|const char\*) (plsx_\w+)\(', ln)
+        if not m or ln.rstrip().endswith(';'):
+            continue
+        name = m.group(1)
+        j = i
+        while not (lines[j].startswith('{') or lines[j].startswith('try {') or lines[j].rstrip().endswith('}')
+                   or lines[j].rstrip().endswith(';')):
+            j += 1
+        if lines[j].rstrip().endswith(';') and '{' not in lines[j]:
+            continue                                   # forward declaration
+        defined.add(name)
+        if name in trivial:
+            continue
+        if not lines[j].startswith('try {'):
+            unguarded.append(name)
+            continue
+        k = j
+        while not lines[k].startswith('}'):
+            k += 1
+        assert lines[k].startswith('} PLSX_CATCH('), (name, lines[k])
+    assert not unguarded, unguarded
+    assert declared <= defined, declared - defined
+    for f in os.listdir(os.path.join(ROOT, 'pypyls_amd', 'csrc')):
+        assert 'getenv' not in open(os.path.join(ROOT, 'pypyls_amd', 'csrc', f)).read(), f
+    # ... and the product's Python does not select routes from the environment either
+    for f in ('engine.py', 'plsc.py', 'regression.py', 'parallel.py', 'resampling.py'):
+        text = open(os.path.join(ROOT, 'pypyls_amd', f)).read()
+        uses = re.findall(r"environ(?:\.get)?\(?\[?['\"]PLSX_", text)
+        assert not uses or f == 'engine.py', (f, uses)     # engine.options_from_env: bench / tests helper only
+
+
+def test_options_from_env_translates_known_keys_only():
+    from pypyls_amd import engine
+    kw = engine.options_from_env({'PLSX_NO_DUAL_PERM': '1', 'PLSX_MIN_BATCH': '512', 'PLSX_SCRATCH_GB': '6',
+                                  'PLSX_UNKNOWN': '1', 'HOME': '/root'})
+    assert kw == {'options': {'no_dual_perm': 1, 'min_batch': 512}, 'scratch_gb': 6.0}
+    assert engine.options_from_env({}) == {'options': {}}

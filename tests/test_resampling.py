@@ -203,9 +203,53 @@ def test_stream_of_given_array_and_errors():
 
 
 def test_python_fallback_stream(monkeypatch):
-    """PLSX_PY_RESAMPLE=1: the stream falls back to the Python loops, same arrays."""
-    monkeypatch.setenv('PLSX_PY_RESAMPLE', '1')
+    """resampling.FORCE_PYTHON: the stream falls back to the Python loops, same arrays."""
+    monkeypatch.setattr(rsmp, 'FORCE_PYTHON', True)
     st = rsmp.IndexStream('boot', [7, 8], 2, 20)
     rsmp.DrawThread(np.random.RandomState(5), [st.draw]).start().join()
-    monkeypatch.delenv('PLSX_PY_RESAMPLE')
+    monkeypatch.setattr(rsmp, 'FORCE_PYTHON', False)
     np.testing.assert_array_equal(st.samples, rsmp.gen_bootsamp([7, 8], 2, 20, seed=5, verbose=False))
+
+
+def test_failing_job_in_the_middle_fails_the_streams_behind_it():
+    """a job of the generator thread that raises (native gen_splits status, bad n_split,
+    MemoryError) used to leave the streams queued behind it un-drawn and their consumers spinning in
+    wait() forever.  Now they raise, promptly."""
+    import threading
+    import time
+
+    def boom(rs):
+        raise RuntimeError('split masks failed')
+
+    first = rsmp.IndexStream('perm', [12], 1, 6)
+    late = rsmp.IndexStream('boot', [12], 1, 50)
+    th = rsmp.DrawThread(np.random.RandomState(1), [first.draw, boom, late.draw])
+    got = {}
+
+    def consume():
+        try:
+            for a, b in late.chunks(0, 50):
+                pass
+            got['done'] = True
+        except RuntimeError as exc:
+            got['exc'] = str(exc)
+
+    c = threading.Thread(target=consume, daemon=True)
+    th.start()
+    c.start()
+    c.join(timeout=5.0)
+    assert not c.is_alive(), 'consumer still waiting for a stream that will never be drawn'
+    assert got.get('exc') == 'split masks failed'
+    assert first.available() == 6                        # the job before the failure completed
+    with pytest.raises(RuntimeError):
+        th.join()
+
+
+def test_chunk_boundaries_do_not_depend_on_arrival():
+    """Launch sizes are a function of the shard bounds only (bit-reproducible accumulation order)."""
+    st = rsmp.IndexStream.of_array(np.zeros((5, 10000), dtype=int))
+    st.kind = 'boot'                                      # pretend it is a drawn stream that has fully arrived
+    assert list(st.chunks(0, 10000)) == [(0, 256), (256, 1280), (1280, 5376), (5376, 10000)]
+    assert list(st.chunks(1250, 2500)) == [(1250, 1506), (1506, 2500)]
+    assert list(st.chunks(0, 700, limit=256)) == [(0, 256), (256, 512), (512, 700)]
+    assert list(st.chunks(0, 300)) == [(0, 300)]

@@ -91,7 +91,8 @@ def _c4_engine():
     from pypyls_amd import resampling, hostmath
     from pypyls_amd.engine import Engine
     X, Y = synth(500, 200000, 50)
-    eng = Engine()
+    from pypyls_amd.engine import options_from_env
+    eng = Engine(**options_from_env())
     eng.set_data(X, Y, resampling.cell_of_row([500], 1), 1, 1, 0)
     xw, sv, yw = eng.decompose()
     xw, yw = hostmath.sign_convention(xw, yw)

@@ -22,7 +22,8 @@ def main():
     X = rs.randn(S, B)
     Y = rs.randn(S, T) + 0.3 * X[:, :T]
     groups = [S // G // C] * G
-    eng = Engine(scratch_gb=24)
+    from pypyls_amd.engine import options_from_env
+    eng = Engine(**dict(options_from_env(), scratch_gb=24))
     eng.set_data(X, Y, resampling.cell_of_row(groups, C), G, C, 0)
     xw, sv, yw = eng.decompose()
     xw, yw = hostmath.sign_convention(xw, yw)

@@ -26,7 +26,8 @@ def main():
     rs = np.random.RandomState(0)
     X = rs.randn(S, B)
     Y = rs.randn(S, T) + 0.3 * X[:, :T]
-    eng = Engine()
+    from pypyls_amd.engine import options_from_env
+    eng = Engine(**options_from_env())
     eng.set_data(X, Y, resampling.cell_of_row([S], 1), 1, 1, 0)
     spec = ref.Spec('behavioral', [S], 1)
     xw, sv, yw = eng.decompose()

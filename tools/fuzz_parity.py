@@ -55,7 +55,8 @@ def one_case(rs, idx):
     LAST = desc = dict(i=idx, method=method, groups=groups, n_cond=n_cond, S=S, B=B, T=T, cov=cov, mc=mc, rotate=rotate)
     if method == 'behavioral' and n_groups * n_cond * T > 1280:
         return desc, 'skipped'
-    eng = Engine()
+    from pypyls_amd.engine import options_from_env
+    eng = Engine(**options_from_env())
     eng.set_data(X, Y if method == 'behavioral' else None, rsmp.cell_of_row(groups, n_cond), n_groups, n_cond,
                  0 if method == 'behavioral' else 1, mean_centering=mc, covariance=cov)
     spec = ref.Spec(method, groups, n_cond, cov, mc, rotate)

@@ -86,7 +86,7 @@ struct plsx_ctx {
     int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf status;                                         // device words: [0] numerical status bits of the small solvers, [1] refined, [2] graded but unrefined resamples
-    Buf refV, refLam, refK0, refPart;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
+    Buf refV, refLam, refK0, refPart, refPartP, refH;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
     int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
     long long n_refined = 0, n_unrefined = 0;           // host copies of status[1], status[2] since the last plsx_numeric_report
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
@@ -1149,37 +1149,45 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double
     }
     // one-sided Jacobi out of LDS, one block per resample, 8 lanes per column pair
     const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
-#define SMALL_LDS_LAUNCH(ITL, THREADS) { HIPCHK(set_lds(k_small<ITL>, lds)); \
-        hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), lds, st, a); }
-#define SMALL_LDS_DISPATCH() \
-    if (n <= 16) SMALL_LDS_LAUNCH(2, 64)          /* one wave per resample: the step barriers cost nothing */ \
-    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128) \
-    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256) \
-    else SMALL_LDS_LAUNCH(8, 256)
+#define SMALL_LDS_LAUNCH(ITL, THREADS, BYTES) { HIPCHK(set_lds(k_small<ITL>, BYTES)); \
+        hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), BYTES, st, a); }
+#define SMALL_LDS_DISPATCH(BYTES) \
+    if (n <= 16) SMALL_LDS_LAUNCH(2, 64, BYTES)          /* one wave per resample: the step barriers cost nothing */ \
+    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128, BYTES) \
+    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256, BYTES) \
+    else SMALL_LDS_LAUNCH(8, 256, BYTES)
     int nchunk = 0;
+    const bool boot = a.mode == SMALL_BOOT;
     if (Rref && n > 1 && !ctx->opt[OPT_NO_REFINE]) {
-        // partial refined Grams: one (n x n) tile per (resample, column chunk), 256 MB at most
+        // partial G' (and Y U0): one (n x n) (+ (n x L)) tile per (resample, column chunk), 256 MB at most
+        const long long per = (long long)n * (n + (boot ? a.L : 0)) * 8;
         nchunk = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(32, ceil_div(ctx->B, 1024)),
-                                                                  (256LL << 20) / ((long long)nres * n * n * 8)));
+                                                                  (256LL << 20) / ((long long)nres * per)));
         if (int e = ensure(ctx, ctx->refV, (size_t)nres * n * n * 8)) return e;
         if (int e = ensure(ctx, ctx->refLam, (size_t)nres * n * 8)) return e;
         if (int e = ensure(ctx, ctx->refK0, (size_t)nres * sizeof(int))) return e;
         if (int e = ensure(ctx, ctx->refPart, (size_t)nres * nchunk * n * n * 8)) return e;
+        if (boot) if (int e = ensure(ctx, ctx->refPartP, (size_t)nres * nchunk * n * a.L * 8)) return e;
         a.phase = 1;
         a.refV = ptr<double>(ctx->refV); a.refLam = ptr<double>(ctx->refLam); a.refK0 = ptr<int>(ctx->refK0);
-        a.refPart = ptr<double>(ctx->refPart); a.ref_nchunk = nchunk;
+        a.refPart = ptr<double>(ctx->refPart); a.refPartP = boot ? ptr<double>(ctx->refPartP) : nullptr;
+        a.ref_nchunk = nchunk;
     }
-    SMALL_LDS_DISPATCH()
+    SMALL_LDS_DISPATCH(lds)
     LAUNCHCHK();
     if (a.phase == 1) {
         // blocks of resamples that are not parked return at once: two short launches when nothing is graded
-        const size_t rlds = ((size_t)n * 64 + 64 * 66) * 8;
+        const size_t rlds = ((size_t)n * 64 + 2 * 64 * 66) * 8;
         HIPCHK(set_lds(k_refine_gram, rlds));
         hipLaunchKernelGGL(k_refine_gram, dim3(nchunk, nres), dim3(256), rlds, st, Rref, ctx->strideR, ctx->Bpad,
-                           ctx->B, n, ptr<double>(ctx->refV), ptr<int>(ctx->refK0), ptr<double>(ctx->refPart), nchunk);
+                           ctx->B, n, ptr<double>(ctx->refV), ptr<int>(ctx->refK0),
+                           boot ? ptr<double>(ctx->U0T) : (const double*)nullptr, ctx->Bpad, a.L,
+                           ptr<double>(ctx->refPart), a.refPartP, nchunk);
         LAUNCHCHK();
         a.phase = 2;
-        SMALL_LDS_DISPATCH()
+        // (two more work matrices in LDS: W of the small block and the large -> small coefficients)
+        const size_t lds2 = lds + (size_t)2 * n * ld * 8 + 16;
+        SMALL_LDS_DISPATCH(lds2)
         LAUNCHCHK();
     }
 #undef SMALL_LDS_DISPATCH
@@ -1424,7 +1432,7 @@ try {
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
-                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart})
+                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1643,8 +1651,19 @@ try {
     if (int e = run_gram(ctx, 1, false, st)) return e;
     SmallArgs a = small_args(ctx, SMALL_DECOMP);
     a.out_V = d_yw; a.out_d = d_sv;
+    const bool fix = ctx->Tp <= PLSX_JACOBI_TP && ctx->Tp > 1 && !ctx->opt[OPT_NO_REFINE];
+    if (fix) {
+        if (int e = ensure(ctx, ctx->refH, (size_t)ctx->L * ctx->L * 8)) return e;
+        a.out_H = ptr<double>(ctx->refH);
+    }
     if (int e = run_small(ctx, a, 1, st, ptr<double>(ctx->R))) return e;
     if (int e = run_urot(ctx, 1, nullptr, nullptr, d_xw, st)) return e;
+    if (fix) {
+        // graded spectrum: the small x_weights columns lose their components along the large ones
+        hipLaunchKernelGGL(k_fix_small_cols, dim3(ceil_div(ctx->B, 256)), dim3(256), 0, st, d_xw, ctx->B, ctx->L,
+                           ptr<double>(ctx->refH), ptr<int>(ctx->refK0));
+        LAUNCHCHK();
+    }
     return note_spectrum(ctx, d_sv, st);
 } PLSX_CATCH(ctx)
 

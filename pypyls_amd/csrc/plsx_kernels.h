@@ -1999,13 +1999,16 @@ struct SmallArgs {
     // Refinement of graded spectra (T' <= PLSX_JACOBI_TP, routes that keep R in HBM).  phase 0: one launch,
     // nothing parked; phase 1: a resample with a live LV below PLSX_REFINE_TAU d_max parks its rank-ordered
     // eigenvectors / eigenvalues and the first small rank k0 and returns; k_refine_gram then forms
-    // G_s = (V_s^T R)(V_s^T R)^T for the parked ones; phase 2: they re-solve G_s, rotate V_s and finish.
+    // G' = (V^T R)(V^T R)^T (and (V^T R) U0 for bootstraps) for the parked ones; phase 2: they re-solve the
+    // small block of G', rotate V_s, orthogonalise the small left vectors against the large ones and finish.
     int phase;
     double* refV;      // [nres][n][n] column k = eigenvector of rank k
     double* refLam;    // [nres][n]
     int* refK0;        // [nres] first refined rank (0: not parked)
-    const double* refPart;   // [nres][ref_nchunk][n][n] partial G_s (top-left (n - k0)^2 entries)
+    double* refPart;   // [nres][ref_nchunk][n][n] partial G' = (V^T R)(V^T R)^T; phase 2 sums the chunks into chunk 0
+    double* refPartP;  // BOOT: [nres][ref_nchunk][n][L] partial (V^T R) U0
     int ref_nchunk;
+    double* out_H;     // DECOMP of ONE resample (plsx_decompose): (L x L) coefficients of k_fix_small_cols, or nullptr
 };
 
 // LDS Jacobi variant (T' <= PLSX_JACOBI_TP): both n x (n|1) work matrices in LDS, one block per
@@ -2027,30 +2030,75 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
     const int tid = threadIdx.x;
     const double* G = a.G + (size_t)r * n * n;
 
+    // phase 2 only (its launch asks for the extra LDS): W of the small block, then g (see below)
+    double* bufW = reinterpret_cast<double*>(order + n + (n & 1));
+    double* bufG = bufW + (size_t)n * ld;
+    int k0 = 0, m = 0;
+    double* Gp = nullptr;          // (n x n) summed G' of this resample
+    double* PVg = nullptr;         // (n x L) summed (V^T R) U0
     if (a.phase == 2) {
-        // A parked resample: eigenvectors of rank >= k0 span the subspace of its small singular values to
-        // eps (d_max / d_k0)^2, but inside it the Gram-side solve is only good to eps (d_max / d_k)^2.
-        // G_s = (V_s^T R)(V_s^T R)^T was formed from R itself (k_refine_gram: its entries carry errors
-        // relative to the SMALL scale); its eigenvectors W rotate V_s, its eigenvalues replace lam.
-        const int k0 = a.refK0[r];
+        // A parked resample.  The first solve leaves two defects where d_k << d_max:
+        //  (i) inside the subspace of the small singular values the eigenvectors of G are only good to
+        //      eps (d_max / d_k)^2: G' = Y Y^T with Y = V^T R was formed from R itself (k_refine_gram; its
+        //      entries carry errors relative to the scale of THEIR rows), the eigenvectors W of its small
+        //      block rotate V_s and its eigenvalues replace lam;
+        // (ii) the implied left vectors z_c = R^T v_c of small c are not orthogonal to those of large b
+        //      beyond eps d_b / d_c (v_c cannot encode v_b^T v_c below eps): what LAPACK's SVD of R delivers
+        //      and the bootstrap's Procrustes input temp = U0^T U needs is u_c = (z_c - sum_b z_b g_bc) / d_c
+        //      with g_bc = (z_b . z_c) / (z_b . z_b) from the cross block of G' -- applied to temp through
+        //      Y U0 (BOOT) and handed to k_fix_small_cols for the original decomposition (DECOMP).
+        k0 = a.refK0[r];
         if (!k0) return;
-        const int m = n - k0;
+        m = n - k0;
+        Gp = a.refPart + (size_t)r * a.ref_nchunk * n * n;
+        for (int idx = tid; idx < n * n; idx += blockDim.x) {
+            double s2 = 0.0;
+            for (int ch = 0; ch < a.ref_nchunk; ++ch) s2 += Gp[(size_t)ch * n * n + idx];
+            Gp[idx] = s2;
+        }
+        if (a.mode == SMALL_BOOT) {
+            PVg = a.refPartP + (size_t)r * a.ref_nchunk * n * L;
+            for (int idx = tid; idx < n * L; idx += blockDim.x) {
+                double s2 = 0.0;
+                for (int ch = 0; ch < a.ref_nchunk; ++ch) s2 += PVg[(size_t)ch * n * L + idx];
+                PVg[idx] = s2;
+            }
+        }
         const double* rv = a.refV + (size_t)r * n * n;
         for (int idx = tid; idx < n * n; idx += blockDim.x) bufV[(idx / n) * ld + (idx % n)] = rv[idx];
         for (int k = tid; k < n; k += blockDim.x) lam[k] = a.refLam[(size_t)r * n + k];
-        const double* pp = a.refPart + (size_t)r * a.ref_nchunk * n * n;
+        __syncthreads();
         for (int idx = tid; idx < m * m; idx += blockDim.x) {
             const int c = idx / m, i = idx % m;
-            double s = 0.0;
-            for (int ch = 0; ch < a.ref_nchunk; ++ch) s += pp[((size_t)ch * n + i) * n + c];
-            bufA[c * ld + i] = s;
+            bufA[c * ld + i] = Gp[(size_t)(k0 + i) * n + k0 + c];
+            bufW[c * ld + i] = (i == c) ? 1.0 : 0.0;
         }
         __syncthreads();
-        jacobi_cols_reg<ITL, 8>(bufA, m, bufV + (size_t)k0 * ld, n, m, ld, &s_flag, a.jtol);
+        jacobi_cols_reg<ITL, 8>(bufA, m, bufW, m, m, ld, &s_flag, a.jtol);
         for (int c = tid; c < m; c += blockDim.x) {
             double s = 0.0;
             for (int i = 0; i < m; ++i) { double x = bufA[c * ld + i]; s += x * x; }
             lam[k0 + c] = sqrt(s);
+        }
+        // V_s <- V_s W (through bufG), then g[b][c] = (G'[b][k0:] W[:, c]) / G'[b][b] into bufG
+        for (int idx = tid; idx < m * n; idx += blockDim.x) {
+            const int c = idx / n, t = idx % n;
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += bufV[(k0 + j) * ld + t] * bufW[c * ld + j];
+            bufG[c * ld + t] = s;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * n; idx += blockDim.x) {
+            const int c = idx / n, t = idx % n;
+            bufV[(k0 + c) * ld + t] = bufG[c * ld + t];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * k0; idx += blockDim.x) {
+            const int c = idx / k0, b = idx % k0;
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += Gp[(size_t)b * n + k0 + j] * bufW[c * ld + j];
+            const double gb = Gp[(size_t)b * n + b];
+            bufG[c * ld + b] = gb > 0.0 ? s / gb : 0.0;
         }
         __syncthreads();
     } else {
@@ -2123,6 +2171,18 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
             }
             a.Mfrag[(size_t)r * tot + idx] = v;
         }
+        if (a.phase == 2 && a.out_H) {
+            // x_weights column of rank kc = R^T v_c / d_c still carries the components along the large
+            // columns: u_c = u_c(raw) - sum_b u_b(raw) H[kb][kc], H = g d_b / d_c (k_fix_small_cols)
+            for (int idx = tid; idx < L * L; idx += blockDim.x) a.out_H[idx] = 0.0;
+            __syncthreads();
+            for (int idx = tid; idx < m * k0; idx += blockDim.x) {
+                const int cc = idx / k0, b = idx % k0;
+                const int kb = rank[b], kc = rank[k0 + cc];
+                const double db = sqrt(lam[b]), dc = sqrt(lam[k0 + cc]);
+                if (kb < L && kc < L && dc > PLSX_RANK_RTOL * dmax) a.out_H[(size_t)kb * L + kc] = bufG[cc * ld + b] * db / dc;
+            }
+        }
         return;
     }
 
@@ -2157,7 +2217,16 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
             double s = 0.0;
             const double dc = sqrt(lam[c]);
             if (rank[c] < L && dc > PLSX_RANK_RTOL * dmax && a.d0[aa] > PLSX_RANK_RTOL * d0max) {
-                for (int t = 0; t < n; ++t) s += P[(size_t)t * L + aa] * bufV[c * ld + t];
+                if (a.phase == 2) {
+                    // u0_a . z_c from Y U0 of the refinement pass; small c: rotated by W, minus the large parts
+                    if (c < k0) s = PVg[(size_t)c * L + aa];
+                    else {
+                        const int cc = c - k0;
+                        for (int j = 0; j < m; ++j) s += bufW[cc * ld + j] * PVg[(size_t)(k0 + j) * L + aa];
+                        for (int b = 0; b < k0; ++b) s -= bufG[cc * ld + b] * PVg[(size_t)b * L + aa];
+                    }
+                } else
+                    for (int t = 0; t < n; ++t) s += P[(size_t)t * L + aa] * bufV[c * ld + t];
                 s /= dc;
             }
             bufA[c * ld + aa] = s;
@@ -2389,50 +2458,51 @@ void k_small(SmallArgs a)
     small_solve<ITL>(a, blockIdx.x, sm_s);
 }
 
-// Refined Gram matrix of the small-singular-value subspace of parked resamples (SmallArgs::phase):
-//   Y = V_s^T R   (m x B, m = n - k0 trailing eigenvectors of the first solve),  G_s = Y Y^T,
-// summed over the block's chunk of feature columns into part[r][chunk][n][n] (top-left m x m).  R is read
-// once; the entries of Y are O(d_small) sums of O(d_max) terms, so G_s carries eps d_max d_small -- the
-// accuracy LAPACK's SVD of R has for these singular values -- instead of the eps d_max^2 of R R^T.
+// Gram matrix of parked resamples (SmallArgs::phase) in the basis of their first eigenvectors:
+//   Y = V^T R (n x B),  G' = Y Y^T  and, for bootstraps, Y U0 (n x L),
+// summed over the block's chunk of feature columns into part[r][chunk] / partP[r][chunk].  R is read once;
+// row k of Y is an O(d_k) sum of O(d_max) terms, so G'[k][k'] carries eps d_max^2 / sqrt(B)-sized noise only
+// through rows that are themselves large -- the small block and the cross block are known relative to the
+// scale of their rows, which is what the Gram matrix R R^T cannot give (eps d_max^2 everywhere).
 // Only graded data ever gets here (blocks of resamples that are not parked return at once): plain fp64
 // VALU code, 64 columns per step -- stage 1: wave w forms rows [16 w, 16 w + 16) of Y for one column per
-// lane (V_s broadcast from LDS); stage 2: 4 x 4 register tiles of G_s over the 64 columns in LDS.
+// lane (V broadcast from LDS); stage 2 / 3: 4 x 4 register tiles of G' and Y U0 over the 64 columns in LDS.
 __global__ __launch_bounds__(256)
 void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int B, int n,
                    const double* __restrict__ refV, const int* __restrict__ refK0,
-                   double* __restrict__ part, int nchunk)
+                   const double* __restrict__ U0T, int ldu, int L,
+                   double* __restrict__ part, double* __restrict__ partP, int nchunk)
 {
     const int r = blockIdx.y, ch = blockIdx.x;
-    const int k0 = refK0[r];
-    if (!k0) return;
-    const int m = n - k0;
+    if (!refK0[r]) return;
     extern __shared__ __attribute__((aligned(16))) double sm_r[];
-    double* Vs = sm_r;                    // [n][64]: Vs[t][j] = eigenvector k0 + j, entry t (zero for j >= m)
+    double* Vs = sm_r;                    // [n][64]: Vs[t][k] = eigenvector of rank k, entry t (zero for k >= n)
     double* Yl = Vs + (size_t)n * 64;     // [64 columns][66]
+    double* Ul = Yl + 64 * 66;            // [64 columns][66]: U0 rows of the step (BOOT)
     const int tid = threadIdx.x;
     const double* rv = refV + (size_t)r * n * n;
     for (int idx = tid; idx < n * 64; idx += 256) {
-        const int t = idx >> 6, j = idx & 63;
-        Vs[idx] = j < m ? rv[(size_t)(k0 + j) * n + t] : 0.0;
+        const int t = idx >> 6, k = idx & 63;
+        Vs[idx] = k < n ? rv[(size_t)k * n + t] : 0.0;
     }
     const int cpc = ((B + nchunk - 1) / nchunk + 63) / 64 * 64;
     const int b_lo = ch * cpc, b_hi = min(B, b_lo + cpc);
     const int kg = tid >> 6, c = tid & 63;          // stage 1: rows [16 kg, 16 kg + 16) of Y, column c
-    const int ti = tid >> 4, tj = tid & 15;         // stage 2: G_s[4 ti ..][4 tj ..]
-    double acc[4][4];
+    const int ti = tid >> 4, tj = tid & 15;         // stages 2 / 3: rows 4 ti .. of G' / Y U0, columns 4 tj ..
+    double acc[4][4], accP[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < 4; ++j) { acc[i][j] = 0.0; accP[i][j] = 0.0; }
     const double* Rr = R + (size_t)r * strideR;
     __syncthreads();
     for (int b0 = b_lo; b0 < b_hi; b0 += 64) {
         double y[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) y[j] = 0.0;
-        if (16 * kg < m) {
-            const int col = b0 + c;
-            const bool ok = col < b_hi;
+        const int col = b0 + c;
+        const bool ok = col < b_hi;
+        if (16 * kg < n) {
             const double* rp = Rr + (ok ? col : b_lo);
             for (int t = 0; t < n; ++t) {
                 const double x = ok ? rp[(size_t)t * ldr] : 0.0;
@@ -2443,8 +2513,11 @@ void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) Yl[c * 66 + 16 * kg + j] = y[j];
+        if (U0T)
+            for (int aa = kg; aa < 64; aa += 4)
+                Ul[c * 66 + aa] = (ok && aa < L) ? U0T[(size_t)aa * ldu + col] : 0.0;
         __syncthreads();
-        if (4 * ti < m && 4 * tj < m) {
+        if (4 * ti < n && 4 * tj < n) {
             for (int cc = 0; cc < 64; ++cc) {
                 double ya[4], yb[4];
 #pragma unroll
@@ -2455,6 +2528,17 @@ void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(ya[i], yb[j], acc[i][j]);
             }
         }
+        if (U0T && 4 * ti < n && 4 * tj < L) {
+            for (int cc = 0; cc < 64; ++cc) {
+                double ya[4], ub[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ya[i] = Yl[cc * 66 + 4 * ti + i]; ub[i] = Ul[cc * 66 + 4 * tj + i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accP[i][j] = __builtin_fma(ya[i], ub[j], accP[i][j]);
+            }
+        }
         __syncthreads();
     }
     double* po = part + ((size_t)r * nchunk + ch) * n * n;
@@ -2462,7 +2546,33 @@ void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (4 * ti + i < m && 4 * tj + j < m) po[(size_t)(4 * ti + i) * n + 4 * tj + j] = acc[i][j];
+            if (4 * ti + i < n && 4 * tj + j < n) po[(size_t)(4 * ti + i) * n + 4 * tj + j] = acc[i][j];
+    if (U0T) {
+        double* pp = partP + ((size_t)r * nchunk + ch) * n * L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * ti + i < n && 4 * tj + j < L) pp[(size_t)(4 * ti + i) * L + 4 * tj + j] = accP[i][j];
+    }
+}
+
+// x_weights of the original decomposition (plsx_decompose) after a refinement: column kc (small) minus its
+// components along the large columns, coefficients H (L x L, zero outside large -> small) from k_small phase 2.
+// One thread per feature row.  No-op when the decomposition was not parked.
+__global__ void k_fix_small_cols(double* __restrict__ xw, int B, int L, const double* __restrict__ H,
+                                 const int* __restrict__ refK0)
+{
+    if (!refK0[0]) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    double x[PLSX_JACOBI_TP];
+    for (int k = 0; k < L; ++k) x[k] = xw[(size_t)i * L + k];
+    for (int kc = 0; kc < L; ++kc) {
+        double s = 0.0;
+        for (int kb = 0; kb < L; ++kb) s += x[kb] * H[(size_t)kb * L + kc];
+        if (s != 0.0) xw[(size_t)i * L + kc] = x[kc] - s;
+    }
 }
 
 // ---------------------------------------------------------------------------

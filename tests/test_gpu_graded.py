@@ -254,3 +254,46 @@ def test_unrefined_graded_spectrum_is_counted_and_warned(monkeypatch):
     print('refined:   per-LV rel err {}'.format(np.array2string(rel2, precision=1)))
     assert rel2.max() < 1e-8
     assert eng2.numeric_report() == (1, 0)
+
+
+@pytest.mark.parametrize('ratio', [1e4, 3e5])
+def test_frontend_graded_spectrum(ratio):
+    """The public call on graded behaviours: the original decomposition is refined (its small x_weights
+    columns are orthogonalised against the large ones, k_fix_small_cols), the analysis leaves the
+    dual-space routes, and singular values, weights, the permutation null and the bootstrap ratios
+    agree per LV with the oracle run on the same index arrays."""
+    import pypyls_amd as pls
+    S, B, T = 80, 3000, 8
+    rs = np.random.RandomState(int(7 + np.log10(ratio)))
+    X = rs.randn(S, B)
+    Y = graded_behaviours(rs, S, T, ratio, 'mix')
+    n = 24
+    res = pls.behavioral_pls(X, Y, n_perm=n, n_boot=n, test_split=0, seed=11, verbose=False)
+    want = ref.run_plsc(X, Y, method='behavioral', permsamples=res.permres.permsamples,
+                        bootsamples=res.bootres.bootsamples)
+    dv = np.diag(want['singvals']) if np.ndim(want['singvals']) == 2 else np.asarray(want['singvals'])
+    live = ref.live_lvs(dv)
+    assert live.all()
+    worst = per_lv_close(res.singvals, dv, 0, what='singvals')
+    worst = max(worst, per_lv_close(res.x_weights, want['x_weights'], 1, what='x_weights'))
+    worst = max(worst, per_lv_close(res.y_weights, want['y_weights'], 1, what='y_weights'))
+    worst = max(worst, per_lv_close(res.permres.perm_singval, want['permres']['perm_singval'], 0, what='perm_singval'))
+    assert np.array_equal(res.permres.pvals, want['permres']['pvals'])
+    # orthogonality of the device's own x_weights in the strong sense: u_b . u_c for a large b and a small c
+    gram = res.x_weights.T @ res.x_weights
+    off = np.abs(gram - np.diag(np.diag(gram)))
+    big = dv >= 1e-3 * dv[0]
+    cross = off[np.ix_(big, ~big)].max() if (~big).any() else 0.0
+    print('x_weights orthogonality: max |u_b . u_c| {:.2e} overall, {:.2e} large x small'.format(off.max(), cross))
+    # (large x small: eps d_1/d_L before k_fix_small_cols, about eps d_1 / (d_L sqrt(B)) after -- the noise of the
+    # cross block of G' that the coefficients come from)
+    assert off.max() < 1e-10 and cross < 1e-11, (off.max(), cross)
+    a, b = res.bootres.x_weights_normed, want['bootres']['x_weights_normed']
+    # (bootstrap ratios: inputs of compute.boot_rel are not returned; rtol on every LV's own scale, loosened by
+    # the cancellation of its standard-error formula on the LEADING LVs, see bsr_close)
+    for k in range(dv.size):
+        sc = np.max(np.abs(b[:, k]))
+        err = np.max(np.abs(a[:, k] - b[:, k])) / sc
+        print('ratio {:g} LV {}: d/d1 = {:.2e}, bootstrap ratio rel err {:.2e}'.format(ratio, k, dv[k] / dv[0], err))
+        assert err < (1e-5 if k >= 2 else 1e-3), (k, err)
+    print('front-end graded {:g}: d1/dL = {:.3g}, worst per-LV rel err {:.2e}'.format(ratio, dv[0] / dv[-1], worst))

@@ -285,30 +285,51 @@ class PLSC(object):
         out = {'bound': 'mfma' if mf else 'hbm', 'kernel': kname,
                'achieved': tf if mf else tb * 1e3, 'peak': PEAK_FP64_MFMA_TFLOPS if mf else PEAK_HBM_TBS * 1e3,
                'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': f_m if mf else f_h,
-               'frac_mfma': f_m, 'frac_hbm_algorithmic': f_h,
-               'avg_launch_ms': avg_ms, 'launches': launches, 'resamples_per_launch': units}
+               'frac_mfma': f_m, 'hbm_algorithmic_over_peak': f_h,
+               'avg_launch_ms': avg_ms, 'launches': launches, 'resamples_per_launch': units,
+               'work_per_resample': '2 S T\' B = {:.3e} flop (SURVEY 8d, first term of W_F); 8 S (B + T\') = {:.3e} B (W_B; '
+                                    'the resamples of a block share one pass over X, so hbm_algorithmic_over_peak may pass 1 -- '
+                                    'it is a ratio of the per-resample model to the peak, not a utilisation)'.format(
+                                        2.0 * S * Tp * B, 8.0 * S * (B + Tp))}
+        self.row_fraction = 1.0
         crow = tm.get('compact_row_fraction', 0.0)
         if crow > 0:
             out['kernel'] = out['kernel'].replace('k_xprod<', 'k_xprod_compact<', 1).replace(
                 'data-only blocks', 'one bootstrap per block, contraction over the rows it draws')
             # compact blocks: one bootstrap per block, contraction over the DISTINCT rows it draws (k-steps of
-            # 4 rows), T' rows on ceil(T'/16) tiles whose last one runs on the 4x4x4 shape when it holds <= 4
+            # 4 rows), T' rows on ceil(T'/16) tiles whose last one runs on the 4x4x4 shape when it holds <= 4.
+            # The formulation needs 2 (crow S) T' B flop per bootstrap -- undrawn rows have weight zero, rows drawn
+            # twice fold into one column of A -- and THAT is what frac prices; the dense 2 S T' B of SURVEY 8d is
+            # kept as dense_equivalent_tflops with the ratio between the two as algorithmic_speedup_vs_dense.
+            self.row_fraction = crow
             mt = -(-Tp // 16)
             rows = (mt - 1) * 16 + 4 if (mt >= 2 and Tp - (mt - 1) * 16 <= 4) else mt * 16
             issued = 2.0 * S * crow * rows * (B + self.L) * units
             t_iss = issued / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            out.update({'distinct_row_fraction': crow, 'issued_tflops': t_iss,
-                        'frac_issued': t_iss / PEAK_FP64_MFMA_TFLOPS,
-                        'note': 'achieved / frac count the dense 2 S T\' B flop of SURVEY 8d per bootstrap; the compact '
-                                'blocks merge the rows a bootstrap draws more than once and skip the ones it does not '
-                                'draw ({:.1f} % of S contracted), so the algorithmic rate can pass the MFMA peak -- '
-                                'the matrix-pipe utilisation is frac_issued (flop the kernel issues / peak)'.format(100 * crow)})
+            need = tf * crow
+            out.update({'achieved': need, 'frac': need / PEAK_FP64_MFMA_TFLOPS, 'frac_mfma': need / PEAK_FP64_MFMA_TFLOPS,
+                        'distinct_row_fraction': crow, 'algorithmic_speedup_vs_dense': 1.0 / crow,
+                        'dense_equivalent_tflops': tf,
+                        'issued_tflops': t_iss, 'frac_issued': t_iss / PEAK_FP64_MFMA_TFLOPS,
+                        'work_per_resample': '2 (r S) T\' B = {:.3e} flop with r = {:.3f} the share of the S rows a bootstrap '
+                                             'contracts (distinct rows, in k-steps of 4): the min-flop formulation; dense '
+                                             'SURVEY 8d figure 2 S T\' B = {:.3e}'.format(2.0 * S * crow * Tp * B, crow,
+                                                                                         2.0 * S * Tp * B),
+                        'note': 'frac = min-flop work / time / peak (a true fraction); frac_issued = flop the kernel issues '
+                                '(T\' padded to {} rows, score columns) / time / peak = matrix-pipe utilisation; '
+                                'dense_equivalent_tflops = what a dense contraction over all S rows would have had to '
+                                'sustain'.format(rows)})
         return out
 
     def pipeline(self, ms_per_step, primal):
-        """Whole-step fractions with the algorithmic work of the formulation."""
+        """Whole-step fractions with the work the formulation NEEDS (min-flop): per bootstrap
+        r 2 S T' B (cross-product over the r S rows it contracts) + 4 S J B (feature moments, all rows)
+        + 2 T'^2 B (Gram) + 2 T' L B (R U0) + 2 T' L B (R^T M); per feature-pass permutation
+        2 S T' B + 2 T'^2 B; per dual permutation 2 T' S^2 + 2 T'^2 S + its share of K = X X^T."""
         S, B, Tp, L = self.S, self.B, self.Tp, self.L
-        wf_boot = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
+        r = getattr(self, 'row_fraction', 1.0)
+        mom = 4.0 * S * len(self.groups) * self.n_cond * B if self.method == 'behavioral' else 0.0
+        wf_boot = r * 2.0 * S * Tp * B + mom + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
         wb = 8.0 * S * (B + Tp)
         if primal:
             wf_perm, wb_perm = 2.0 * S * Tp * B + 2.0 * Tp * Tp * B, wb
@@ -316,6 +337,9 @@ class PLSC(object):
             wf_perm = 2.0 * Tp * S * S + 2.0 * Tp * Tp * S + 2.0 * S * S * B / max(self.perms, 1)
             wb_perm = 8.0 * (S * B / max(self.perms, 1) + 3.0 * Tp * S)
         per_s = 1e3 / ms_per_step
+        self.pipeline_formula = ('per bootstrap {:.3f} x 2 S T\' B + 4 S J B + 2 T\'^2 B + 4 T\' L B = {:.3e} flop; per '
+                                 'permutation {:.3e} flop ({})'.format(r, wf_boot, wf_perm,
+                                                                      'feature pass' if primal else 'dual S x S route'))
         return (per_s * (self.perms * wf_perm + self.boots * wf_boot) / (PEAK_FP64_MFMA_TFLOPS * 1e12),
                 per_s * (self.perms * wb_perm + self.boots * wb) / (PEAK_HBM_TBS * 1e12))
 
@@ -492,12 +516,21 @@ class SplitHalf(object):
         tot = sum(v[0] for v in kt.values()) or 1.0
         dom = max(kt, key=lambda k: kt[k][0]) if kt else 'k_xprod'
         units = steps * self.arr * self.ns
-        wf = (2.0 * S * Tp * B + 8.0 * Tp * L * B) * units
+        wf_dense = (2.0 * S * Tp * B + 8.0 * Tp * L * B) * units
+        # min-flop: the fused pass contracts over the FIRST half only (gen_splits: ceil / floor of S / 2 rows; the second
+        # half follows from the arrangement's full cross-product), feature moments of that half 4 (S/2) J B, the four
+        # projections 8 T' L B as in SURVEY's W_F(split)
+        wf = (0.5 * 2.0 * S * Tp * B + 2.0 * S * B + 8.0 * Tp * L * B) * units
         tf = wf / (tot * 1e-3) / 1e12
         return {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': PEAK_FP64_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': tf / PEAK_FP64_MFMA_TFLOPS,
+                'dense_equivalent_tflops': wf_dense / (tot * 1e-3) / 1e12,
+                'algorithmic_speedup_vs_dense': wf_dense / wf,
                 'dominant_kernel_share': kt.get(dom, (0, 0))[0] / tot,
-                'note': 'achieved = W_F(split) x splits / summed kernel time of the split-half launches'}
+                'work_per_split': '0.5 x 2 S T\' B + 2 S B + 8 T\' L B = {:.3e} flop (min-flop: one half through the matrix '
+                                  'pipe); SURVEY 8d W_F(split) = 2 S T\' B + 8 T\' L B = {:.3e} (dense)'.format(
+                                      wf / units, wf_dense / units),
+                'note': 'achieved = min-flop work x splits / summed kernel time of the split-half launches'}
 
     def pipeline(self, ms_per_step, primal):
         return None, None
@@ -514,6 +547,99 @@ class SplitHalf(object):
         dt = time.perf_counter() - t0
         return 2 / dt, '2 splits of the original arrangement through oracle/cpu_ref.py split_half (numpy), ' \
                        '{:.1f} s'.format(dt)
+
+
+def run_analysis(args, real_stdout):
+    """--mode analysis: END-TO-END wall time of the PUBLIC front-end call (the counterpart of BasePLS.run_pls,
+    pyls/base.py:341-399 + behavioral.py:197-227) at --config c4 / c2 / c3 with --perms + --boots resamples
+    (default: the literal 10 000 + 10 000; --splits S adds split-half with n_split = S): index generation,
+    H2D of X, binding, original decomposition, resampling, THE collective, percentile intervals, bootstrap
+    ratios and the D2H of what PLSResults holds -- everything the resampling-step modes leave out.  A fresh
+    engine per call, as a user's call gets (after one small warm-up call: loaded code objects, a warm
+    allocator).  --emulate-world 1,2,4,8 (one GPU): the same call as rank 0 and as rank N - 1 of an emulated
+    world N -- every rank draws the full index arrays, runs its shard, and the all-gather is replaced by a
+    device-side surrogate of the same volume followed by the real rank-ordered sums
+    (parallel._surrogate_gather) -- an EMULATION of the end-to-end critical path, not a hardware curve.
+    One profiled call per world (a device sync at every phase boundary) gives the per-phase split."""
+    import torch
+    import pypyls_amd as pls
+    cfg = args.config
+    if cfg == 'c4':
+        S, B, T, groups, n_cond = args.S, args.B, args.T, [args.S], 1
+        X, Y = synth(S, B, T)
+        call = lambda **kw: pls.behavioral_pls(X, Y, test_split=0, verbose=False, **kw)
+        desc = 'behavioral_pls X({}x{}) Y({}x{}) fp64, test_split=0'.format(S, B, S, T)
+    elif cfg == 'c2':
+        S, B, T = 80, 10000, 10
+        X, Y = synth(S, B, T)
+        call = lambda **kw: pls.behavioral_pls(X, Y, test_split=0, verbose=False, **kw)
+        desc = 'behavioral_pls X(80x10000) Y(80x10) fp64, test_split=0'
+    elif cfg == 'c3':
+        rs = np.random.RandomState(0)
+        groups, n_cond = [25, 25, 25, 25], 2
+        X = rs.randn(200, 50000)
+        call = lambda **kw: pls.meancentered_pls(X, groups=groups, n_cond=n_cond, verbose=False, **kw)
+        desc = 'meancentered_pls X(200x50000) groups=[25]*4 n_cond=2 fp64'
+    else:
+        raise SystemExit('--mode analysis supports --config c4 | c2 | c3')
+    n_perm = args.perms or (5000 if cfg == 'c2' else 10000)
+    n_boot = args.boots or (5000 if cfg == 'c2' else 10000)
+    extra = {'n_split': args.splits} if args.splits else {}
+    call(n_perm=64, n_boot=64, seed=1)                      # warm-up
+    worlds = sorted({1} | {int(v) for v in args.emulate_world.split(',') if v.strip()}) if args.emulate_world else [1]
+    reps = max(args.steps, 1)
+    table = {}
+    for n in worlds:
+        row = {}
+        for label, r in (('rank0', 0), ('last_rank', n - 1)):
+            emu = {'_emulate': (r, n)} if n > 1 else {}
+            best = None
+            for rep in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = call(n_perm=n_perm, n_boot=n_boot, seed=1234, **extra, **emu)
+                torch.cuda.synchronize()
+                dt = 1e3 * (time.perf_counter() - t0)
+                best = dt if best is None else min(best, dt)
+            row[label + '_ms'] = best
+            phases = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            call(n_perm=n_perm, n_boot=n_boot, seed=1234, _phases=phases, **extra, **emu)
+            row[label + '_profiled_ms'] = 1e3 * (time.perf_counter() - t0)
+            row[label + '_phases_ms'] = {k: round(v, 2) for k, v in phases.items()}
+            if n == 1:
+                row['last_rank_ms'] = best
+                break
+        row['critical_path_ms'] = max(row['rank0_ms'], row['last_rank_ms'])
+        table[n] = row
+    base = table[1]['critical_path_ms']
+    for n, row in table.items():
+        row['ideal_ms'] = base / n
+        row['over_ideal'] = row['critical_path_ms'] * n / base
+        row['efficiency'] = base / (n * row['critical_path_ms'])
+    ph1 = table[1]['rank0_phases_ms']
+    resample_ms = sum(ph1.get(k, 0.0) for k in ('permutations', 'bootstraps', 'split_half'))
+    out = {'metric': 'end-to-end resamples/sec of the public front-end call, {}'.format(desc),
+           'value': (n_perm + n_boot) / (base * 1e-3), 'unit': 'resamples/s', 'n_gpus': 1, 'steps': reps, 'warmup': 1,
+           'ms_per_step': base, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic',
+           'config': {'workload': '{} (BASELINE config {}): ONE analysis of {} permutations + {} bootstraps{} through '
+                                  'the public call, seed-compatible index generation inside the clock'.format(
+                                      desc, cfg, n_perm, n_boot, ' + n_split={}'.format(args.splits) if args.splits else ''),
+                      'mode': 'analysis', 'per': 'analysis'},
+           'fixed_cost_ms': {'profiled_total_ms': table[1]['rank0_profiled_ms'], 'resampling_phases_ms': resample_ms,
+                             'everything_else_ms': table[1]['rank0_profiled_ms'] - resample_ms,
+                             'unprofiled_total_ms': base,
+                             'note': 'fixed cost = wall time of the call minus its permutation / bootstrap / split-half '
+                                     'phases (one profiled call with a device sync at every phase boundary)'},
+           'end_to_end_emulation': {
+               'what': 'the public call as rank 0 and as rank N - 1 of a world emulated on ONE GPU: full index '
+                       'generation, own shard, surrogate gather of the real volume, real rank-ordered sums, full '
+                       'post-processing and D2H; critical path = slower of the two; efficiency = t(1) / (N t(N)).  '
+                       'NOT a hardware scaling curve.',
+               'worlds': {str(n): row for n, row in table.items()}}}
+    os.write(real_stdout, (json.dumps(out) + '\n').encode())
 
 
 def make_workload(args):
@@ -541,7 +667,8 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--config', default='c4', choices=['c4', 'c2', 'c3', 'c5', 'c4split'])
-    ap.add_argument('--mode', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--mode', default='weak', choices=['weak', 'strong', 'analysis'])
+    ap.add_argument('--splits', type=int, default=0, help='--mode analysis: n_split of the call (0 = no split-half)')
     ap.add_argument('--S', type=int, default=500)
     ap.add_argument('--B', type=int, default=200000)
     ap.add_argument('--T', type=int, default=50)
@@ -596,6 +723,13 @@ def main():
         collective = 'none (process group init failed: {})'.format(str(exc)[:120])
     world = dist.get_world_size() if dist.is_initialized() else 1
 
+    if args.mode == 'analysis':
+        if world != 1:
+            raise SystemExit('--mode analysis runs on one GPU (use --emulate-world for the emulated critical path)')
+        run_analysis(args, real_stdout)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     wl = make_workload(args)
     n_steps = args.steps + args.warmup
     wl.setup(rank, n_steps, dev)
@@ -696,14 +830,16 @@ def main():
             cfgd['perm_path'] = 'dual (S x S kernel; included in value, excluded from value_primal)' if dual \
                 else 'feature pass'
             pm, ph = wl.pipeline(ms_step, primal=not dual)
-            roof['pipeline_frac_mfma'], roof['pipeline_frac_hbm'] = pm, ph
+            roof['pipeline_frac_mfma'], roof['pipeline_hbm_algorithmic_over_peak'] = pm, ph
+            roof['pipeline_work'] = wl.pipeline_formula
             if elapsed_primal is not None:
                 out['value_primal'] = units * args.steps / elapsed_primal
                 out['ms_per_step_primal'] = 1e3 * elapsed_primal / args.steps
                 cfgd['perm_ms_per_step_primal'] = float(np.mean([l[0] for l in legs_p]))
                 cfgd['kernel_ms_per_step_primal'] = {k: v[0] / args.steps for k, v in kt_p.items()}
                 pm, ph = wl.pipeline(out['ms_per_step_primal'], primal=True)
-                roof['pipeline_frac_mfma_primal'], roof['pipeline_frac_hbm_primal'] = pm, ph
+                roof['pipeline_frac_mfma_primal'], roof['pipeline_hbm_algorithmic_over_peak_primal'] = pm, ph
+                roof['pipeline_work_primal'] = wl.pipeline_formula
             elif not dual:
                 out['value_primal'] = value
         roof['traffic'] = None

@@ -112,6 +112,21 @@ int plsx_decompose(plsx_ctx* ctx, double* d_xw, double* d_sv, double* d_yw, void
 int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv,
                       const double* d_yw, void* stream);
 
+/* Sign convention of compute.svd (pyls/compute.py:43-50, sklearn's svd_flip applied to the decomposed matrix):
+ * in place on the DEVICE copies of the decomposition -- when T' <= B the entry of largest magnitude of every
+ * x_weights column becomes positive, otherwise that of every y_weights column; both factors get the same signs.
+ * d_xw (B, L), d_yw (T', L) as plsx_decompose wrote them.  (The host may equally apply the rule itself.) */
+int plsx_svd_flip(plsx_ctx* ctx, double* d_xw, double* d_yw, void* stream);
+
+/* d_out[i][k] = d_in[i][k] * d_scale[k] on (rows, cols) row-major arrays (in place allowed): the device side of
+ * `x_weights @ singvals` (pyls/types/behavioral.py:201, the `orig` of compute.boot_rel). */
+int plsx_scale_columns(plsx_ctx* ctx, const double* d_in, long long rows, int cols, const double* d_scale,
+                       double* d_out, void* stream);
+
+/* d_dst (cols, rows) = d_src (rows, cols)^T, both dense row-major: the (n_boot, T' L) bootstrap distributions
+ * as the (T' L, n_boot) series plsx_percentile_ci and PLSResults' (T', L, n_boot) layout want them. */
+int plsx_transpose(plsx_ctx* ctx, const double* d_src, int rows, int cols, double* d_dst, void* stream);
+
 /* Centred projection (X - colmean(X)) @ W for W given as (B, L): the device
  * part of `x_scores = X @ x_weights` (pyls/base.py:364).  d_out (S, L). */
 int plsx_project(plsx_ctx* ctx, const double* d_W, int L, double* d_out, void* stream);
@@ -173,6 +188,10 @@ int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np,
 int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, int np,
                             const uint8_t* d_masks, int ns,
                             double* d_ucorr, double* d_vcorr, void* stream);
+
+/* Mean over the splits of an arrangement -- the `.mean(axis=-1)` that closes BasePLS.split_half
+ * (pyls/base.py:770): d_in (np, ns, L) as plsx_split_half_batch wrote it -> d_out (np, L); NaN propagates. */
+int plsx_mean_splits(plsx_ctx* ctx, const double* d_in, int np, int ns, int L, double* d_out, void* stream);
 
 /*
  * Cross-validation -- BehavioralPLS.crossval / _single_crossval
@@ -296,7 +315,9 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *     4096), "inblock_moments", "no_fixed_x", "no_dual_perm"
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
  *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
- *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "epi2_nw4", "trace_alloc"
+ *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "epi2_nw4", "trace_alloc";
+ *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
+ *     size the super-batch scratch for n once instead of per call (0 = per call)
  * plsx_option_name(i) enumerates the keys (NULL past the last).  No reference counterpart.
  */
 int plsx_set_option(plsx_ctx* ctx, const char* key, int value);
@@ -310,8 +331,8 @@ const char* plsx_option_name(int index);
  * feature-pass route with T' <= 64.  A data set whose ORIGINAL spectrum is graded (plsx_decompose /
  * plsx_set_original) is taken off the dual-space routes for that reason.  This call synchronises the device and
  * returns -- and clears -- two counters since the last call: resamples whose small LVs were refined, and resamples
- * with such LVs that could NOT be (T' > 64, or a dual-space route on data whose original spectrum was not
- * graded): their LVs below ~ 6e-6 d_max may miss the 1e-5 relative tolerance; the host warns.
+ * with a live LV below 1e-5 d_max that could NOT be (T' > 64, or a dual-space route on data whose original
+ * spectrum was not graded): LVs below ~ 6e-6 d_max may miss the 1e-5 relative tolerance; the host warns.
  */
 int plsx_numeric_report(plsx_ctx* ctx, long long* refined, long long* unrefined);
 

@@ -34,13 +34,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples"};
 
 struct plsx_ctx {
     int device = 0;
@@ -86,6 +86,7 @@ struct plsx_ctx {
     int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf status;                                         // device words: [0] numerical status bits of the small solvers, [1] refined, [2] graded but unrefined resamples
+    Buf flipws;                                         // plsx_svd_flip: column maxima, their rows, the signs
     Buf refV, refLam, refK0, refPart, refPartP, refH;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
     int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
     long long n_refined = 0, n_unrefined = 0;           // host copies of status[1], status[2] since the last plsx_numeric_report
@@ -104,6 +105,7 @@ struct plsx_ctx {
     long long timed_units = 0;
     int last_compact_n = 0, last_compact_ktot = 0;   // compact launch behind the last run_xprod (0: none)
     double scratch_gb = 48.0;                           // super-batch scratch budget
+    double map_ms_per_gb = 0.0;                         // measured cost of mapping device memory (launch_groups), 0 = not yet
     int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
                           // resamples covered by the timed launches
     double last_ms = 0.0;
@@ -406,6 +408,10 @@ int ensure_scratch(plsx_ctx* ctx, int groups)
 // mapped is always used in full.
 int launch_groups(plsx_ctx* ctx, long long units, int per_group)
 {
+    // a caller that ships one analysis in chunks (as the index rows arrive) says how many resamples are coming
+    // ("expect_resamples"): the scratch is then sized once, for the whole shard, instead of growing chunk by
+    // chunk -- every growth is a hipFree (a device-wide sync in the middle of the queue) + hipMalloc + zero fill
+    units = std::max<long long>(units, ctx->opt[OPT_EXPECT_RESAMPLES]);
     const long long need = (units + per_group - 1) / std::max(per_group, 1);
     const int cap = (int)std::max<long long>(1, std::min<long long>(ctx->Gcap, need));
     if (ctx->scratch_fixed) return cap;
@@ -415,7 +421,25 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     // x (T'/200)^3 for Householder + QL (T' > PLSX_JACOBI_TP; one block per resample, latency
     // bound: only a large batch keeps the chip busy)
     const double tn = ctx->Tp / 200.0;
-    const double c_group = 40.0 * gb_per_group, c_launch = ctx->Tp > PLSX_JACOBI_TP ? std::max(2.5, 25.0 * tn * tn * tn) : 2.5;
+    // what mapping a GB costs HERE is measured once per context (2 GB: hipMalloc + first touch + free) instead of
+    // assumed: ~1 ms per GB on a device with clean pages (the model then launches 2 - 3 x larger super-batches:
+    // a 1250-bootstrap shard of c4 ran 56 per launch under the fixed 40 ms per GB and paid one 2.5 ms wave of the
+    // small solver per 10 ms of cross-product), 25+ ms per GB when the driver has to clear recycled VRAM first.
+    // Floor 3 ms per GB (the zero fill of R and a margin for the pool running dry beyond the probe), cap 40.
+    if (ctx->map_ms_per_gb <= 0.0) {
+        ctx->map_ms_per_gb = 40.0;
+        void* probe = nullptr;
+        const size_t pb = (size_t)2 << 30;
+        auto t0 = std::chrono::steady_clock::now();
+        if (hipMalloc(&probe, pb) == hipSuccess) {
+            (void)hipMemset(probe, 0, pb);
+            (void)hipDeviceSynchronize();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            (void)hipFree(probe);
+            ctx->map_ms_per_gb = std::min(40.0, std::max(3.0, 2.0 * ms / 2.0));
+        } else (void)hipGetLastError();
+    }
+    const double c_group = ctx->map_ms_per_gb * gb_per_group, c_launch = ctx->Tp > PLSX_JACOBI_TP ? std::max(2.5, 25.0 * tn * tn * tn) : 2.5;
     int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
     g = std::max(g, ctx->Galloc);
     return std::max(1, std::min(g, cap));
@@ -1432,7 +1456,7 @@ try {
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
-                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH})
+                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -2640,6 +2664,74 @@ try {
     hipLaunchKernelGGL(k_boot_rel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), d_orig, d_usum, d_usq, (double)n_boot, add_orig, count,
                        d_bsr, d_se);
+    LAUNCHCHK();
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
+
+int plsx_svd_flip(plsx_ctx* ctx, double* d_xw, double* d_yw, void* stream)
+try {
+    NEED_DATA();
+    if (!d_xw || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_svd_flip: null input");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = ctx->L;
+    // compute.svd decomposes crosscov^T when T' <= B: the flipped factor is then the (B x L) x_weights
+    const bool lead_x = ctx->Tp <= ctx->B;
+    const double* lead = lead_x ? d_xw : d_yw;
+    const long long rows = lead_x ? ctx->B : ctx->Tp;
+    if (int e = ensure(ctx, ctx->flipws, (size_t)3 * L * 8)) return e;
+    unsigned long long* gmax = ptr<unsigned long long>(ctx->flipws);
+    unsigned long long* grow = gmax + L;
+    double* signs = reinterpret_cast<double*>(grow + L);
+    HIPCHK(hipMemsetAsync(gmax, 0, (size_t)L * 8, st));
+    HIPCHK(hipMemsetAsync(grow, 0xff, (size_t)L * 8, st));
+    const int nblk = (int)((rows + 4095) / 4096);
+    hipLaunchKernelGGL(k_absmax_cols, dim3(nblk), dim3(256), (size_t)L * 8, st, lead, rows, L, gmax);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_argmax_rows, dim3(nblk), dim3(256), 0, st, lead, rows, L, gmax, grow);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_flip_signs, dim3(ceil_div(L, 64)), dim3(64), 0, st, lead, L, grow, signs);
+    LAUNCHCHK();
+    const long long cx = (long long)ctx->B * L, cy = (long long)ctx->Tp * L;
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((cx + 255) / 256)), dim3(256), 0, st, d_xw, cx, L, signs, d_xw);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((cy + 255) / 256)), dim3(256), 0, st, d_yw, cy, L, signs, d_yw);
+    LAUNCHCHK();
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
+
+int plsx_scale_columns(plsx_ctx* ctx, const double* d_in, long long rows, int cols, const double* d_scale,
+                       double* d_out, void* stream)
+try {
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_in || !d_scale || !d_out || rows < 1 || cols < 1)
+        return fail(ctx, PLSX_ERR_ARG, "plsx_scale_columns: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    const long long count = rows * cols;
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_in, count, cols, d_scale, d_out);
+    LAUNCHCHK();
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
+
+int plsx_transpose(plsx_ctx* ctx, const double* d_src, int rows, int cols, double* d_dst, void* stream)
+try {
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_src || !d_dst || rows < 1 || cols < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_transpose: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(32, 8), 0,
+                       static_cast<hipStream_t>(stream), d_src, rows, cols, cols, d_dst, rows);
+    LAUNCHCHK();
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
+
+int plsx_mean_splits(plsx_ctx* ctx, const double* d_in, int np, int ns, int L, double* d_out, void* stream)
+try {
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_in || !d_out || np < 1 || ns < 1 || L < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_mean_splits: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_mean_axis1, dim3(ceil_div(np * L, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_in, np, ns, L, d_out);
     LAUNCHCHK();
     return PLSX_OK;
 } PLSX_CATCH(ctx)

@@ -44,6 +44,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define PLSX_RANK_RTOL 1e-6     // LV is live when d > RANK_RTOL * d_max
 #define PLSX_REFINE_TAU 1e-3    // live LVs with d < REFINE_TAU * d_max are re-solved on R itself (k_refine_gram):
                                 // the Gram side loses eps (d_max / d)^2, 3.5e-10 at the threshold
+#define PLSX_WARN_TAU 1e-5      // ... and where that is not possible (no R on the route, T' > PLSX_JACOBI_TP) a live LV
+                                // below WARN_TAU * d_max (error >= 3.5e-6 from there on) is counted for plsx_numeric_report
 #define PLSX_MOM_PAIRS 192       // (resample, cell) pairs per moment-only cross-product block (12 + 12 tiles)
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c)
@@ -2140,8 +2142,18 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
                 if (sqrt(lam[order[k]]) < PLSX_REFINE_TAU * dmax) { k0 = k; break; }
             if (k0 && !(sqrt(lam[order[k0]]) > PLSX_RANK_RTOL * dmax)) k0 = 0;
             s_k0 = k0;
-            if (a.phase == 1) a.refK0[r] = k0;
-            if (k0) atomicAdd(a.status + (a.phase == 1 ? 1 : 2), 1);
+            if (a.phase == 1) {
+                a.refK0[r] = k0;
+                if (k0) atomicAdd(a.status + 1, 1);
+            } else if (k0) {
+                // not refinable on this route: counted when the Gram side really is short of the tolerance
+                double dl = dmax;
+                for (int k = k0; k < L; ++k) {
+                    const double dk = sqrt(lam[order[k]]);
+                    if (dk > PLSX_RANK_RTOL * dmax) dl = dk;
+                }
+                if (dl < PLSX_WARN_TAU * dmax) atomicAdd(a.status + 2, 1);
+            }
         }
         __syncthreads();
         if (a.phase == 1 && s_k0) {
@@ -2349,10 +2361,10 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     if (tid == 0) {
         s_dmax = sqrt(lam[order[0]]);
         // graded spectra are not refined on this path (see small_solve): counted, reported by plsx_numeric_report
-        for (int k = 1; k < L; ++k) {
+        for (int k = L - 1; k >= 1; --k) {
             const double dk = sqrt(lam[order[k]]);
-            if (dk < PLSX_REFINE_TAU * s_dmax) {
-                if (dk > PLSX_RANK_RTOL * s_dmax) atomicAdd(a.status + 2, 1);
+            if (dk > PLSX_RANK_RTOL * s_dmax) {               // the smallest live LV
+                if (dk < PLSX_WARN_TAU * s_dmax) atomicAdd(a.status + 2, 1);
                 break;
             }
         }
@@ -2852,6 +2864,65 @@ __global__ void k_transpose(const double* __restrict__ src, int rows, int cols, 
         int c = c0 + i, r = r0 + threadIdx.x;
         if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
     }
+}
+
+// Sign convention of compute.svd (pyls/compute.py:43-50: sklearn's svd_flip on the decomposed matrix): the entry
+// of largest magnitude in every column of `lead` (rows x L, row-major) becomes positive; ties go to the lowest
+// row, as numpy.argmax.  Pass 1: column maxima of |lead| (positive doubles order like their bit patterns);
+// pass 2: lowest row that attains it; pass 3 (k_flip_signs): the sign there (0 -> +1).
+__global__ void k_absmax_cols(const double* __restrict__ lead, long long rows, int L, unsigned long long* __restrict__ gmax)
+{
+    extern __shared__ unsigned long long sm_mx[];
+    for (int k = threadIdx.x; k < L; k += blockDim.x) sm_mx[k] = 0ull;
+    __syncthreads();
+    const long long total = rows * L, per = 4096LL * L;
+    const long long lo = blockIdx.x * per, hi = min(total, lo + per);
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double v = fabs(lead[i]);
+        atomicMax(&sm_mx[(int)(i % L)], (unsigned long long)__double_as_longlong(v));
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < L; k += blockDim.x) atomicMax(&gmax[k], sm_mx[k]);
+}
+
+__global__ void k_argmax_rows(const double* __restrict__ lead, long long rows, int L,
+                              const unsigned long long* __restrict__ gmax, unsigned long long* __restrict__ grow)
+{
+    const long long total = rows * L, per = 4096LL * L;
+    const long long lo = blockIdx.x * per, hi = min(total, lo + per);
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int k = (int)(i % L);
+        if ((unsigned long long)__double_as_longlong(fabs(lead[i])) == gmax[k])
+            atomicMin(&grow[k], (unsigned long long)(i / L));
+    }
+}
+
+__global__ void k_flip_signs(const double* __restrict__ lead, int L, const unsigned long long* __restrict__ grow,
+                             double* __restrict__ signs)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= L) return;
+    const double v = lead[(size_t)grow[k] * L + k];
+    signs[k] = v < 0.0 ? -1.0 : 1.0;
+}
+
+// out[i][k] = in[i][k] * scale[k]   (rows x cols, row-major; in == out allowed)
+__global__ void k_scale_cols(const double* __restrict__ in, long long count, int cols, const double* __restrict__ scale,
+                             double* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i] * scale[(int)(i % cols)];
+}
+
+// out[a][c] = mean_b in[a][b][c], terms added in order of b (NaN propagates, as numpy's mean: base.py:770)
+__global__ void k_mean_axis1(const double* __restrict__ in, int na, int nb, int nc, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na * nc) return;
+    const int a = i / nc, c = i % nc;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += in[((size_t)a * nb + b) * nc + c];
+    out[i] = s / (double)nb;
 }
 
 // out[r][t][l] = R[r][t][col0 + l]  (bootstrap distrib columns / crosscov copy-out)

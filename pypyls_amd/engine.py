@@ -67,6 +67,10 @@ def _load():
         'plsx_kernel_timing': ([vp, i32, ctypes.POINTER(c_d), ctypes.POINTER(i32)], i32),
         'plsx_kernel_class_name': ([i32], ctypes.c_char_p),
         'plsx_set_perm_path': ([vp, i32], i32),
+        'plsx_mean_splits': ([vp, vp, i32, i32, i32, vp, vp], i32),
+        'plsx_svd_flip': ([vp, vp, vp, vp], i32),
+        'plsx_scale_columns': ([vp, vp, ctypes.c_longlong, i32, vp, vp, vp], i32),
+        'plsx_transpose': ([vp, vp, i32, i32, vp, vp], i32),
         'plsx_set_option': ([vp, ctypes.c_char_p, i32], i32),
         'plsx_option_name': ([i32], ctypes.c_char_p),
         'plsx_numeric_report': ([vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)], i32),
@@ -105,7 +109,8 @@ def exported_symbols():
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
              'plsx_gen_splits', 'plsx_gen_splits_seeded', 'plsx_gen_permsamp_stream',
-             'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report']
+             'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report',
+             'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_mean_splits']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -148,7 +153,7 @@ def options_from_env(environ=None):
 
 
 class GradedSpectrumWarning(UserWarning):
-    """Resamples had live latent variables below 1e-3 of the largest singular value that the
+    """Resamples had live latent variables below 1e-5 of the largest singular value that the
     device could not refine on R (T' > 64, or a dual-space route): their smallest LVs may miss
     the 1e-5 relative tolerance against an SVD of R (include/plsx.h, plsx_numeric_report)."""
 
@@ -252,7 +257,7 @@ class Engine(object):
         self.unrefined += b.value
         if warn and b.value:
             import warnings
-            warnings.warn('{} decomposition(s) had live latent variables below 1e-3 of the largest singular '
+            warnings.warn('{} decomposition(s) had live latent variables below 1e-5 of the largest singular '
                           'value that could not be refined on the cross-covariance matrix (T\' > 64 or a '
                           'dual-space route): singular values below ~6e-6 of the largest may differ from an '
                           'SVD of R by more than 1e-5 relative'.format(b.value), GradedSpectrumWarning,
@@ -317,12 +322,98 @@ class Engine(object):
         self.sync()
         return xw.cpu().numpy(), sv.cpu().numpy(), yw.cpu().numpy()
 
+    def _as_dev(self, a):
+        """numpy array or device tensor -> contiguous fp64 device tensor."""
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            return a if (a.is_cuda and a.is_contiguous() and a.dtype == torch.float64) else \
+                a.to(self.device, dtype=torch.float64).contiguous()
+        return self._dev(a, np.float64)
+
     def set_original(self, x_weights, singvals, y_weights):
-        self._orig_xw = self._dev(x_weights, np.float64)
-        sv, yw = self._dev(singvals, np.float64), self._dev(y_weights, np.float64)
+        """Arguments: numpy arrays or device tensors (the device-resident front-end passes what
+        decompose_dev / svd_flip left on the device: no host round trip of the (B, L) weights)."""
+        self._orig_xw = self._as_dev(x_weights)
+        sv, yw = self._as_dev(singvals), self._as_dev(y_weights)
         self._check(self.lib.plsx_set_original(self.ctx, self._orig_xw.data_ptr(), sv.data_ptr(),
                                                yw.data_ptr(), self._stream()))
         self.sync()
+
+    # -- device-resident pieces of the front-end (tensors in, tensors out; no host copies) ------
+    def colmean_dev(self):
+        out = self._empty((self.B,))
+        self._check(self.lib.plsx_colmean(self.ctx, out.data_ptr(), self._stream()))
+        return out
+
+    def decompose_dev(self):
+        """-> x_weights (B, L), singvals (L,), y_weights (T', L) device tensors, raw signs."""
+        xw, sv, yw = self._empty((self.B, self.L)), self._empty((self.L,)), self._empty((self.Tp, self.L))
+        self._check(self.lib.plsx_decompose(self.ctx, xw.data_ptr(), sv.data_ptr(), yw.data_ptr(),
+                                            self._stream()))
+        return xw, sv, yw
+
+    def svd_flip(self, xw, yw):
+        """sklearn's svd_flip as compute.svd applies it (pyls/compute.py:43-50), in place on device tensors."""
+        self._check(self.lib.plsx_svd_flip(self.ctx, xw.data_ptr(), yw.data_ptr(), self._stream()))
+
+    def project_dev(self, W):
+        """(X - colmean) @ W for a device tensor W (B, L) -> device tensor (S, L)."""
+        out = self._empty((self.S, W.shape[1]))
+        self._check(self.lib.plsx_project(self.ctx, W.data_ptr(), W.shape[1], out.data_ptr(), self._stream()))
+        return out
+
+    def scale_columns(self, A, scale):
+        """A (rows, cols) * scale (cols,) on the device -> new tensor."""
+        out = self._empty(tuple(A.shape))
+        self._check(self.lib.plsx_scale_columns(self.ctx, A.data_ptr(), A.shape[0], A.shape[1], scale.data_ptr(),
+                                                out.data_ptr(), self._stream()))
+        return out
+
+    def transpose_dev(self, A):
+        """(rows, cols) device tensor -> (cols, rows) device tensor."""
+        out = self._empty((A.shape[1], A.shape[0]))
+        self._check(self.lib.plsx_transpose(self.ctx, A.data_ptr(), A.shape[0], A.shape[1], out.data_ptr(),
+                                            self._stream()))
+        return out
+
+    def boot_rel_dev(self, orig, usum, usq, n_boot, add_orig=False):
+        """compute.boot_rel on device tensors -> (bsr, se) device tensors, no sync."""
+        bsr, se = self._empty(tuple(usum.shape)), self._empty(tuple(usum.shape))
+        self._check(self.lib.plsx_boot_rel(self.ctx, orig.data_ptr(), usum.data_ptr(), usq.data_ptr(),
+                                           int(n_boot), 1 if add_orig else 0, usum.numel(),
+                                           bsr.data_ptr(), se.data_ptr(), self._stream()))
+        return bsr, se
+
+    def percentile_ci_dev(self, series, ci=95):
+        """compute.boot_ci of (nseries, n) contiguous device series -> (lo, hi) device tensors, or None when
+        n exceeds the device sort (16384): the caller falls back to numpy on the host copy."""
+        n = series.shape[-1]
+        if n > 16384:
+            return None
+        low = (100 - ci) / 2
+        idx = []
+        for q in (low, 100 - low):                      # numpy's virtual index of the quantile
+            vi = (n - 1) * np.true_divide(q, 100)
+            prev = np.floor(vi)
+            idx.append((int(prev), float(vi - prev)))
+        lo, hi = self._empty((series.shape[0],)), self._empty((series.shape[0],))
+        self._check(self.lib.plsx_percentile_ci(self.ctx, series.data_ptr(), series.shape[0], n, idx[0][0], idx[0][1],
+                                                idx[1][0], idx[1][1], lo.data_ptr(), hi.data_ptr(), self._stream()))
+        return lo, hi
+
+    def pinned_like(self, t):
+        """Page-locked host tensor of the shape of device tensor ``t`` (the destination of an asynchronous D2H
+        copy; 56 us per MB to map -- call it while the device is busy)."""
+        torch = _torch()
+        return torch.empty(tuple(t.shape), dtype=t.dtype, pin_memory=True)
+
+    def to_host_async(self, t, pinned=None):
+        """Start the D2H copy of ``t`` into page-locked memory on the current stream; the numpy view of the
+        returned tensor is valid after the next sync."""
+        if pinned is None:
+            pinned = self.pinned_like(t)
+        pinned.copy_(t, non_blocking=True)
+        return pinned
 
     def project(self, W):
         """(X - colmean) @ W for W (B, L) -> (S, L)."""
@@ -518,12 +609,20 @@ class Engine(object):
                                                     idx_dev.shape[0], usum.data_ptr(), usq.data_ptr(),
                                                     yl_dev.data_ptr(), self._stream()))
 
-    def split_half_into(self, perm_dev, masks_dev, uc_dev, vc_dev):
-        """perm_dev (np, S) int32 or None, masks_dev (np, ns, S) uint8, outputs (np, ns, L)."""
+    def split_half_into(self, perm_dev, masks_dev, uc_dev, vc_dev, ystack_dev=None):
+        """perm_dev (np, S) int32 or None, masks_dev (np, ns, S) uint8, outputs (np, ns, L);
+        ystack_dev (np, S, T): pre-permuted behaviour matrices instead of index rows."""
         n_arr, ns = masks_dev.shape[0], masks_dev.shape[1]
-        self._check(self.lib.plsx_split_half_batch(
-            self.ctx, None if perm_dev is None else perm_dev.data_ptr(), n_arr, masks_dev.data_ptr(), ns,
+        self._check(self.lib.plsx_split_half_batch_y(
+            self.ctx, None if perm_dev is None else perm_dev.data_ptr(),
+            None if ystack_dev is None else ystack_dev.data_ptr(), n_arr, masks_dev.data_ptr(), ns,
             uc_dev.data_ptr(), vc_dev.data_ptr(), self._stream()))
+
+    def mean_splits_into(self, corr_dev, out_dev):
+        """corr_dev (np, ns, L) -> out_dev (np, L): the mean over splits of BasePLS.split_half (base.py:770)."""
+        n_arr, ns, L = corr_dev.shape
+        self._check(self.lib.plsx_mean_splits(self.ctx, corr_dev.data_ptr(), n_arr, ns, L, out_dev.data_ptr(),
+                                              self._stream()))
 
     def boot_rel(self, orig, usum, usq, n_boot, add_orig=False):
         """compute.boot_rel on the device; orig numpy or tensor (B, L).  With

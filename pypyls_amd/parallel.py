@@ -172,30 +172,55 @@ def _pad_rows(t, n):
     return torch.cat([t, pad])
 
 
-def collect_slices(slices, totals, sums, cyclic=()):
-    """THE collective of a front-end call, on tensors that are already where the
-    backend wants them (device tensors under RCCL: the shard results never visit the
-    host before the gather).
-
-    slices: torch tensors whose leading axis is this rank's shard of ``totals[i]``
-            resamples -- contiguous (shard_bounds), or chunk-cyclic in the rank's
-            local order (shard_rows) for the positions listed in ``cyclic``;
-            sums: tensors to add over ranks.  Returns (list of numpy arrays with the
-            FULL leading axis in global order, list of rank-ordered sums as tensors),
-            identical on every rank.  Without a process group nothing moves."""
+def _surrogate_gather(slices, sums, world):
+    """Stand-in for the all-gather of an EMULATED world (one GPU, no peers; bench.py --emulate-world): the packed
+    buffer of this rank is replicated ``world`` times on the device -- the volume a real gather would deliver --
+    and the partial sums are added in rank order, as after a real one.  The values are of course this rank's own."""
     import torch
-    rank, world = rank_world()
+    pieces, shapes = [], []
+    for t, nmax in slices:
+        t = _pad_rows(t, nmax)
+        shapes.append(tuple(t.shape))
+        pieces.append(t.reshape(-1))
+    for t in sums:
+        shapes.append(tuple(t.shape))
+        pieces.append(t.reshape(-1))
+    flat = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.float64)
+    gathered = flat.unsqueeze(0).repeat(world, 1)
+    out_g, out_s, off = [], [], 0
+    for i, shp in enumerate(shapes):
+        n = int(np.prod(shp)) if len(shp) else 1
+        blk = gathered[:, off:off + n].reshape((world,) + shp)
+        off += n
+        if i < len(slices):
+            out_g.append(blk)
+        else:
+            acc = blk[0].clone()
+            for r in range(1, world):
+                acc += blk[r]
+            out_s.append(acc)
+    return out_g, out_s
+
+
+def collect_device(slices, totals, sums, cyclic=(), emulate=None):
+    """THE collective of a front-end call on tensors that are already where the backend wants them (device
+    tensors under RCCL: the shard results never visit the host before the gather), with the result LEFT on the
+    device of the inputs: the front-end finishes there (percentile intervals, bootstrap ratios, the layout of
+    PLSResults) and ships only what PLSResults holds, once.
+
+    slices: torch tensors whose leading axis is this rank's shard of ``totals[i]`` resamples -- contiguous
+            (shard_bounds), or chunk-cyclic in the rank's local order (shard_rows) for the positions listed in
+            ``cyclic``; sums: tensors to add over ranks.  Returns (list of tensors with the FULL leading axis
+            in global order, list of rank-ordered sums), identical on every rank.  Without a process group
+            nothing moves.  emulate = (rank, world): no peers, see _surrogate_gather."""
+    import torch
     d = _dist()
-    if d is None:
-        return [t.detach().cpu().numpy() for t in slices], list(sums)
-    if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU
-        device = torch.device('cuda', torch.cuda.current_device())
-        for t in list(slices) + list(sums):
-            if t.is_cuda:
-                device = t.device
-                break
-    else:                                   # gloo (CPU tests / single-GPU dry runs)
-        device = torch.device('cpu')
+    if emulate is None:
+        if d is None:
+            return list(slices), list(sums)
+        rank, world = d.get_rank(), d.get_world_size()
+    else:
+        rank, world = emulate
     cyclic = set(cyclic)
     counts = []
     for i, n in enumerate(totals):
@@ -204,17 +229,35 @@ def collect_slices(slices, totals, sums, cyclic=()):
         else:
             counts.append([int(np.diff(shard_bounds(n, r, world))[0]) for r in range(world)])
     padded = [(t, max(c)) for t, c in zip(slices, counts)]
-    got, summed = gather_device(padded, sums, device)
+    if emulate is not None:
+        got, summed = _surrogate_gather(padded, sums, world)
+    else:
+        if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU
+            device = torch.device('cuda', torch.cuda.current_device())
+            for t in list(slices) + list(sums):
+                if t.is_cuda:
+                    device = t.device
+                    break
+        else:                                   # gloo (CPU tests / single-GPU dry runs)
+            device = torch.device('cpu')
+        got, summed = gather_device(padded, sums, device)
     full = []
     for i, (blk, n) in enumerate(zip(got, totals)):
-        host = blk.cpu().numpy()                                        # (world, nmax, ...)
-        cat = np.concatenate([host[r][:counts[i][r]] for r in range(world)], axis=0)
-        if i in cyclic:
-            out = np.empty_like(cat)
-            out[np.concatenate([shard_rows(n, r, world) for r in range(world)])] = cat
+        home = slices[i].device
+        cat = torch.cat([blk[r][:counts[i][r]] for r in range(world)], dim=0)       # (n, ...)
+        if i in cyclic and world > 1:
+            order = torch.from_numpy(np.concatenate([shard_rows(n, r, world) for r in range(world)])).to(cat.device)
+            out = torch.empty_like(cat)
+            out[order] = cat
             cat = out
-        full.append(cat)
+        full.append(cat.to(home) if cat.device != home else cat)
     return full, summed
+
+
+def collect_slices(slices, totals, sums, cyclic=()):
+    """:func:`collect_device` with the gathered blocks as numpy arrays (regression front-end, tests)."""
+    full, summed = collect_device(slices, totals, sums, cyclic=cyclic)
+    return [t.detach().cpu().numpy() for t in full], summed
 
 
 def collect(local_perm, n_perm, local_dist, n_boot, usum, usq):

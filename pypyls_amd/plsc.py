@@ -62,6 +62,10 @@ class _PLSCRun(object):
                              'samples. Provided matrices differed: X: {}, Y: {}'
                              .format(len(X), len(Y)))
         kwargs.setdefault('permindices', True)
+        # measurement hooks of bench.py --mode analysis (not inputs of the analysis): a dict that receives
+        # per-phase wall times; (rank, world) of a world emulated on one GPU
+        self.phases = kwargs.pop('_phases', None)
+        self.emulate = kwargs.pop('_emulate', None)
         self.inputs = PLSInputs(X=X, Y=Y, groups=groups, n_cond=n_cond, **kwargs)
         # under torch.distributed every rank must draw the same index arrays
         self.rs = resampling.check_random_state(parallel.shared_seed(self.inputs.get('seed')))
@@ -149,47 +153,84 @@ class _PLSCRun(object):
         Tp = self.n_cells * Y.shape[1] if Y is not None else self.n_cells
         self.perm_given = self.boot_given = None
         draws = self._plan_draws(min(Tp, X.shape[1])).start()
+        self._mstream = None
         try:
             return self._run_device(X, Y, draws)
         finally:
-            draws.thread.join()                        # never leave the generator running on an error
+            draws.thread.join()                        # never leave the generators running on an error
+            if self._mstream is not None:
+                self._mstream.close()
 
     def _run_device(self, X, Y, draws):
+        """The analysis after the draws started.  Everything B- or n_boot-sized stays on the device from the
+        H2D copy of X to the finished statistics: the sign convention, the original's scores, the resampling,
+        THE one collective, percentile intervals, bootstrap ratios and the (T', L, n_boot) layout of the
+        distributions all run there; what PLSResults holds comes back once, into page-locked memory that is
+        mapped while the device resamples.  (Round 3 crossed PCIe with the (B, L) weights five times and
+        transposed the 200 MB distributions on the host: 0.26 - 0.30 s of fixed cost per call at c4.)"""
+        import time
         import torch
         from .engine import Engine
         inp = self.inputs
         eng = self.engine or Engine()
+        phases = self.phases                           # dict: per-phase wall times (bench.py --mode analysis)
+
+        t_last = [time.perf_counter()]
+
+        def tick(name):
+            if phases is None:
+                return
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            phases[name] = phases.get(name, 0.0) + 1e3 * (now - t_last[0])
+            t_last[0] = now
+
         eng.set_data(X, Y, self.cells, len(inp.groups), inp.n_cond, _METHOD_CODE[self.method],
                      mean_centering=inp.get('mean_centering') or 0,
                      covariance=bool(inp.get('covariance')))
+        tick('h2d_and_bind')
         L = eng.L
         res = PLSResults(inputs=inp)
         # finite-input check (sklearn check_X_y in compute.xcorr, compute.py:78):
         # a NaN / inf anywhere in a column of X makes the device column mean
         # non-finite, which avoids a host pass over the (S, B) matrix
-        xmean = eng.colmean()
-        if not np.all(np.isfinite(xmean)):
+        d_xmean = eng.colmean_dev()
+        if not bool(torch.isfinite(d_xmean).all().item()):
             raise ValueError('Input `X` contains NaN, infinity or a value too large')
         if Y is not None:
             _check_finite(Y, 'Y')
 
-        # ---- original decomposition (BasePLS.svd, base.py:362-364) -------
-        xw, sv, yw = eng.decompose()
-        xw, yw = hostmath.sign_convention(xw, yw)
-        eng.set_original(xw, sv, yw)
-        res['x_weights'], res['y_weights'] = xw, yw
-        res['x_scores'] = eng.project(xw) + (xmean @ xw)[None, :]
-        rank, world = parallel.rank_world()
+        # ---- original decomposition (BasePLS.svd, base.py:362-364), signs and scores on the device -------
+        d_xw, d_sv, d_yw = eng.decompose_dev()
+        eng.svd_flip(d_xw, d_yw)
+        eng.set_original(d_xw, d_sv, d_yw)
+        d_scores = eng.project_dev(d_xw)               # (X - mean) @ x_weights; the mean's share is added on the host
+        sv = d_sv.cpu().numpy()
+        yw = d_yw.cpu().numpy()
+        tick('decompose')
+        emulate = self.emulate                         # (rank, world) of an emulated run on one GPU (bench.py)
+        rank, world = emulate if emulate is not None else parallel.rank_world()
         rotate = bool(inp.get('rotate', True))
 
         # ---- resampling: this rank's contiguous shard of the permutations and chunk-cyclic share
         # ---- of the bootstraps, launched chunk by chunk as the index rows arrive; results stay
-        # ---- on the device until THE one collective (parallel.collect_slices) ---------
+        # ---- on the device through THE one collective (parallel.collect_device) ---------
         pstream, bstream, ystack = self.perm_stream, self.boot_stream, self.ystack
         n_perm_tot = pstream.n if pstream is not None else (ystack.shape[0] if ystack is not None else 0)
         n_boot_tot = bstream.n if bstream is not None else 0
         d_perm = d_dist = usum = usq = None
         plo, phi = parallel.shard_bounds(n_perm_tot, rank, world)
+        n_split = inp.get('n_split')
+        mstream = None
+        if n_split is not None and (pstream is not None or ystack is not None) and phi > plo:
+            # split masks of this rank's permutations: produced block by block on their own host thread, from
+            # now on, while the device runs the permutations and the bootstraps (permutation i uses
+            # RandomState(i), base.py:705-708)
+            mstream = self._mstream = resampling.MaskStream(inp.groups, inp.n_cond, n_split, plo, phi,
+                                                            given=inp.get('_perm_splitsamples'))
+        # the shard arrives in chunks: size the super-batch scratch once, for all of it
+        eng.set_option('expect_resamples', max(phi - plo, sum(hi - lo for lo, hi in parallel.shard_chunks(
+            n_boot_tot, rank, world)) if bstream is not None else 0))
         if pstream is not None:
             d_perm = eng._zeros((phi - plo, L))
             for a, b in pstream.chunks(plo, phi):
@@ -197,6 +238,7 @@ class _PLSCRun(object):
         elif ystack is not None:
             host = eng.perm_ystack(ystack[plo:phi], rotate=rotate) if phi > plo else np.zeros((L, 0))
             d_perm = torch.from_numpy(np.ascontiguousarray(host.T)).to(eng.device)
+        tick('permutations')
         if bstream is not None:
             # chunk-cyclic share (parallel.shard_chunks): no rank waits for the END of the draw
             # before its device has anything to do
@@ -209,8 +251,13 @@ class _PLSCRun(object):
                     eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                   d_dist[off + a - blo:off + b - blo])
                 off += bhi - blo
-        # host work that needs no device result runs while the device is busy: the index arrays
-        # in the reference's layout and dtype ((S, n) C-contiguous int64)
+        # host work that needs no device result runs while the device is busy: page-locked landing zones of
+        # the results (56 us per MB to map), the index arrays in the reference's layout and dtype ((S, n)
+        # C-contiguous int64), the host-sized scores of the original data
+        pin = {'xw': eng.pinned_like(d_xw), 'scores': eng.pinned_like(d_scores)}
+        if bstream is not None:
+            pin['bsr'], pin['se'] = eng.pinned_like(d_xw), eng.pinned_like(d_xw)
+            pin['dist'] = torch.empty((eng.Tp * L, n_boot_tot), dtype=torch.float64, pin_memory=True)
         permsamp = bootsamp = None
         if pstream is not None:
             permsamp = self.perm_given if self.perm_given is not None else pstream.samples
@@ -221,28 +268,33 @@ class _PLSCRun(object):
             if st is not None:
                 st.warn()
         eng.sync()                 # numerical status of the launches above is raised HERE, for the batch that set it
+        tick('bootstraps')
         orig_splits = self.orig_splits
-        n_split = inp.get('n_split')
         slices, totals = [], []
         if d_perm is not None:
             if orig_splits is not None:
-                pmasks = inp.get('_perm_splitsamples')
-                if pmasks is None:
-                    pmasks = resampling.gen_splits_seeded(inp.groups, inp.n_cond, n_split, np.arange(plo, phi),
-                                                          test_size=0.5, rows=True)
-                    rows = True
-                else:
-                    pmasks, rows = np.asarray(pmasks)[plo:phi], False
-                if phi > plo:
-                    if ystack is not None:
-                        uc, vc = eng.split_half(pmasks, ystack=ystack[plo:phi], mask_rows=rows)
-                    else:
-                        uc, vc = eng.split_half(pmasks, perms=pstream.rows[plo:phi].T, mask_rows=rows)
-                    halves = np.hstack([uc.mean(axis=-1), vc.mean(axis=-1)])          # (p_loc, 2 L)
-                else:
-                    halves = np.zeros((0, 2 * L))
+                # split-half reliability of every permuted arrangement (base.py:705-708): block by block as the
+                # masks arrive, the mean over splits (base.py:770) taken on the device; nothing visits the host
+                d_uc, d_vc = eng._zeros((phi - plo, L)), eng._zeros((phi - plo, L))
+                if mstream is not None:
+                    try:
+                        for a, b, masks in mstream:
+                            dm = torch.from_numpy(masks).to(eng.device)
+                            dp = eng.rows_tensor(pstream.rows[a:b]) if ystack is None else None
+                            dy = eng._dev(ystack[a:b], np.float64) if ystack is not None else None
+                            uc = eng._empty((b - a, masks.shape[1], L))
+                            vc = eng._empty((b - a, masks.shape[1], L))
+                            eng.split_half_into(dp, dm, uc, vc, ystack_dev=dy)
+                            eng.mean_splits_into(uc, d_uc[a - plo:b - plo])
+                            eng.mean_splits_into(vc, d_vc[a - plo:b - plo])
+                    finally:
+                        mstream.close()
+                    if mstream.duplicates:
+                        warnings.warn('WARNING: Duplicate split halves used.')
                 # ride along with the permutation block of the single collective
-                d_perm = torch.cat([d_perm, torch.from_numpy(halves).to(d_perm.device)], dim=1)
+                d_perm = torch.cat([d_perm, d_uc, d_vc], dim=1)
+                eng.sync()
+                tick('split_half')
             slices.append(d_perm)
             totals.append(n_perm_tot)
         cyclic = []
@@ -261,26 +313,51 @@ class _PLSCRun(object):
                 local_cv = np.zeros((0, 2 * Y.shape[1]))
             slices.append(torch.from_numpy(np.ascontiguousarray(local_cv)).to(eng.device))
             totals.append(cv_splits.shape[1])
+            tick('crossval')
         sums = [usum, usq] if usum is not None else []
-        full, summed = parallel.collect_slices(slices, totals, sums, cyclic=cyclic)
+        full, summed = parallel.collect_device(slices, totals, sums, cyclic=cyclic, emulate=emulate)
         if usum is not None:
             usum, usq = summed
+        tick('collective')
+
+        # ---- finish on the device; one trip home -----------------------------------------------------
         k = 0
         d_perm = distrib = None
+        lo_hi = None
         if n_perm_tot > 0:
-            blk = full[k].T                                                           # (L or 3 L, n_perm)
+            blk = full[k].cpu().numpy().T                                             # (L or 3 L, n_perm)
             k += 1
             d_perm = np.ascontiguousarray(blk[:L])
             if orig_splits is not None:
                 ucorrs, vcorrs = np.ascontiguousarray(blk[L:2 * L]), np.ascontiguousarray(blk[2 * L:])
+        h_bsr = h_se = h_dist = None
         if bstream is not None:
-            distrib = np.ascontiguousarray(np.moveaxis(full[k], 0, -1))               # (T', L, n_boot)
+            d_full = full[k]                                                           # (n_boot, T', L)
             k += 1
+            d_series = eng.transpose_dev(d_full.reshape(n_boot_tot, eng.Tp * L))       # (T' L, n_boot) series
+            lo_hi = eng.percentile_ci_dev(d_series, ci=inp.get('ci', 95))
+            h_dist = eng.to_host_async(d_series, pin['dist'])
+            d_bs = eng.scale_columns(d_xw, d_sv)                                       # x_weights @ singvals
+            if self.method == 'behavioral':
+                # add the original back, n_boot + 1 (behavioral.py:201-207)
+                d_bsr, d_se = eng.boot_rel_dev(d_bs, usum, usq, n_boot_tot + 1, add_orig=True)
+            else:
+                # no add-back, n_boot (meancentered.py:162-164)
+                d_bsr, d_se = eng.boot_rel_dev(d_bs, usum, usq, n_boot_tot, add_orig=False)
+            h_bsr, h_se = eng.to_host_async(d_bsr, pin['bsr']), eng.to_host_async(d_se, pin['se'])
+        h_xw = eng.to_host_async(d_xw, pin['xw'])
+        h_scores = eng.to_host_async(d_scores, pin['scores'])
+        xmean = d_xmean.cpu().numpy()
         if cv_splits is not None:
             Tn = Y.shape[1]
-            cv = full[k].T
+            cv = full[k].cpu().numpy().T
             res['cvres'].update(dict(pearson_r=np.ascontiguousarray(cv[:Tn]),
                                      r_squared=np.ascontiguousarray(cv[Tn:])))
+        eng.sync()
+        tick('finish_and_d2h')
+        xw = h_xw.numpy()
+        res['x_weights'], res['y_weights'] = xw, yw
+        res['x_scores'] = h_scores.numpy() + (xmean @ xw)[None, :]
         if orig_splits is not None and d_perm is not None:
             uc, vc = eng.split_half(orig_splits)
             orig_uc, orig_vc = uc[0].mean(axis=-1), vc[0].mean(axis=-1)
@@ -319,26 +396,28 @@ class _PLSCRun(object):
 
         # ---- bootstrap ratios / intervals ----------------------------------
         if bootsamp is not None:
-            bs = xw * sv[None, :]
+            distrib = h_dist.numpy().reshape(eng.Tp, L, n_boot_tot)                   # (T', L, n_boot)
+            if lo_hi is not None:
+                ci_arr = np.stack([lo_hi[0].cpu().numpy().reshape(eng.Tp, L),
+                                   lo_hi[1].cpu().numpy().reshape(eng.Tp, L)], -1)
+            else:                                       # more than 16384 bootstraps: numpy on the host copy
+                ci_arr = np.stack(hostmath.boot_ci(distrib, ci=inp.get('ci', 95)), -1)
+            bsr, se = h_bsr.numpy(), h_se.numpy()
             if self.method == 'behavioral':
-                # add the original back, n_boot + 1 (behavioral.py:201-207)
-                bsr, se = eng.boot_rel(bs, usum, usq, bootsamp.shape[1] + 1, add_orig=True)
                 res['bootres'].update(dict(
                     x_weights_normed=bsr, x_weights_stderr=se,
                     y_loadings=res['y_loadings'].copy(), y_loadings_boot=distrib,
-                    y_loadings_ci=np.stack(eng.percentile_ci(distrib, ci=inp.get('ci', 95)), -1),
-                    bootsamples=bootsamp))
+                    y_loadings_ci=ci_arr, bootsamples=bootsamp))
             else:
-                # no add-back, n_boot (meancentered.py:162-164)
-                bsr, se = eng.boot_rel(bs, usum, usq, bootsamp.shape[1], add_orig=False)
                 res['bootres'].update(dict(
                     x_weights_normed=bsr, x_weights_stderr=se, bootsamples=bootsamp,
-                    contrast=contrast, contrast_boot=distrib,
-                    contrast_ci=np.stack(eng.percentile_ci(distrib, ci=inp.get('ci', 95)), -1)))
+                    contrast=contrast, contrast_boot=distrib, contrast_ci=ci_arr))
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv
+        eng.set_option('expect_resamples', 0)
         eng.numeric_report()       # warns when graded decompositions could not be refined (T' > 64)
+        tick('host_finish')
         self.engine_used = eng
         return res
 

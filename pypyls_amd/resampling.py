@@ -258,7 +258,7 @@ def gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5):
     return _py_gen_splits(groups, n_cond, n_split, rs, test_size)
 
 
-def gen_splits_seeded(groups, n_cond, n_split, seeds, test_size=0.5, rows=False):
+def gen_splits_seeded(groups, n_cond, n_split, seeds, test_size=0.5, rows=False, warn=True):
     """Split masks of many independent streams: element i equals
     ``gen_splits(groups, n_cond, n_split, seed=seeds[i], test_size)`` -- what
     permutation ``i`` of a split-half analysis draws (pyls/base.py:705-708,
@@ -281,9 +281,12 @@ def gen_splits_seeded(groups, n_cond, n_split, seeds, test_size=0.5, rows=False)
                                     sd.ctypes.data, int(sd.size), out.ctypes.data)
     if rc < 0:
         raise ValueError('plsx_gen_splits_seeded failed with status {}'.format(rc))
+    res = out if rows else out.transpose(0, 2, 1).astype(bool)
+    if not warn:                                        # (thread use: the caller warns)
+        return res, rc == 1
     if rc == 1:
         warnings.warn('WARNING: Duplicate split halves used.')
-    return out if rows else out.transpose(0, 2, 1).astype(bool)
+    return res
 
 
 def _py_gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5):
@@ -465,3 +468,59 @@ class DrawThread(object):
         self.thread.join()
         if self.error is not None:
             raise self.error
+
+
+class MaskStream(object):
+    """Split masks of the permutations [lo, hi) of a split-half analysis, produced block by block on a host
+    thread while the device works: permutation ``i`` draws its ``n_split`` masks from a fresh
+    ``RandomState(i)`` (pyls/base.py:705-708, 738-742), so blocks are independent of each other and of the
+    analysis' own stream.  Round 3 generated all n_perm x n_split masks (500 MB at c4) before the first split
+    ran and shipped them in one piece.  Iterating yields ``(a, b, masks)`` with ``masks`` (b - a, n_split, S)
+    uint8 rows as the device consumes them; ``given``: caller-supplied (n_perm, S, n_split) boolean masks
+    (tests) are sliced instead.  An exception on the producer surfaces in the consumer."""
+
+    def __init__(self, groups, n_cond, n_split, lo, hi, block=32, depth=4, given=None, test_size=0.5):
+        import queue
+        import threading
+        self.args = (groups, n_cond, int(n_split), float(test_size))
+        self.lo, self.hi, self.block, self.given = int(lo), int(hi), int(block), given
+        self.q = queue.Queue(maxsize=depth)
+        self.duplicates = False
+        self.thread = threading.Thread(target=self._run, name='plsx-masks', daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        groups, n_cond, n_split, test_size = self.args
+        try:
+            for a in range(self.lo, self.hi, self.block):
+                b = min(self.hi, a + self.block)
+                if self.given is not None:
+                    m = np.ascontiguousarray(np.asarray(self.given)[a:b].transpose(0, 2, 1), dtype=np.uint8)
+                else:
+                    m = gen_splits_seeded(groups, n_cond, n_split, np.arange(a, b), test_size=test_size,
+                                          rows=True, warn=False)
+                    if isinstance(m, tuple):                  # native generator: (masks, duplicate limit hit)
+                        m, dup = m
+                        self.duplicates = self.duplicates or dup
+                self.q.put((a, b, m))
+            self.q.put(None)
+        except BaseException as exc:
+            self.q.put(exc)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        """Drain and join (error paths: never leave the producer blocked on a full queue)."""
+        while self.thread.is_alive():
+            try:
+                self.q.get(timeout=0.05)
+            except Exception:
+                pass
+        self.thread.join()

@@ -18,3 +18,4 @@ from .plsc import behavioral_pls, meancentered_pls  # noqa: F401
 from .regression import pls_regression  # noqa: F401
 from .matlab_io import import_matlab_result  # noqa: F401
 from .io import save_results, load_results  # noqa: F401
+from .engine import release_default_engine  # noqa: F401

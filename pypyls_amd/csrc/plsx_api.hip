@@ -105,6 +105,8 @@ struct plsx_ctx {
     long long timed_units = 0;
     int last_compact_n = 0, last_compact_ktot = 0;   // compact launch behind the last run_xprod (0: none)
     double scratch_gb = 48.0;                           // super-batch scratch budget
+    long long R_geom[3] = {0, 0, 0};                    // (T', T'pp, Bpad) the R scratch was last zeroed under
+    size_t R_zeroed_bytes = 0;
     double map_ms_per_gb = 0.0;                         // measured cost of mapping device memory (launch_groups), 0 = not yet
     int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
                           // resamples covered by the timed launches
@@ -425,7 +427,7 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     // assumed: ~1 ms per GB on a device with clean pages (the model then launches 2 - 3 x larger super-batches:
     // a 1250-bootstrap shard of c4 ran 56 per launch under the fixed 40 ms per GB and paid one 2.5 ms wave of the
     // small solver per 10 ms of cross-product), 25+ ms per GB when the driver has to clear recycled VRAM first.
-    // Floor 3 ms per GB (the zero fill of R and a margin for the pool running dry beyond the probe), cap 40.
+    // Floor 1.5 ms per GB (the zero fill of R and a margin for the pool running dry beyond the probe), cap 40.
     if (ctx->map_ms_per_gb <= 0.0) {
         ctx->map_ms_per_gb = 40.0;
         void* probe = nullptr;
@@ -436,12 +438,16 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
             (void)hipDeviceSynchronize();
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             (void)hipFree(probe);
-            ctx->map_ms_per_gb = std::min(40.0, std::max(3.0, 2.0 * ms / 2.0));
+            ctx->map_ms_per_gb = std::min(40.0, std::max(1.5, 2.0 * (ms / 2.0)));   // (safety factor 2 on the per-GB time)
         } else (void)hipGetLastError();
     }
     const double c_group = ctx->map_ms_per_gb * gb_per_group, c_launch = ctx->Tp > PLSX_JACOBI_TP ? std::max(2.5, 25.0 * tn * tn * tn) : 2.5;
     int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
     g = std::max(g, ctx->Galloc);
+    // a re-bound context (the front-ends' cached engine) keeps the R it mapped for an earlier call: groups that fit
+    // what is already there cost nothing to map
+    if (ctx->R.bytes > 0 && gb_per_group > 0.0)
+        g = std::max(g, (int)std::min<double>(cap, std::floor((double)ctx->R.bytes / (gb_per_group * 1073741824.0))));
     return std::max(1, std::min(g, cap));
 }
 
@@ -1532,7 +1538,18 @@ try {
     ctx->has_compact_maps = 0;
     // a re-bound context keeps its scratch: the padding rows (t >= T') of every R slot must
     // read as zero under the new layout too
-    if (ctx->R.p) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
+    {
+        // ... unless the layout of a slot is the one the buffer was last zeroed under (the cached engine of the
+        // front-ends re-binding data of the same shape: a 26 GB fill is 8 ms per call)
+        const int Tp_n = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
+        const int L_n = std::min(Tp_n, B);
+        const long long geom[3] = {Tp_n, round_up(Tp_n, 4), round_up(B + L_n, 128)};
+        const bool same = ctx->R.p && ctx->R_geom[0] == geom[0] && ctx->R_geom[1] == geom[1] && ctx->R_geom[2] == geom[2] &&
+                          ctx->R_zeroed_bytes == ctx->R.bytes;
+        if (ctx->R.p && !same) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
+        ctx->R_geom[0] = geom[0]; ctx->R_geom[1] = geom[1]; ctx->R_geom[2] = geom[2];
+        ctx->R_zeroed_bytes = ctx->R.bytes;
+    }
     ctx->has_okx = ctx->has_oky = false;
     ctx->Galloc = 0;
     ctx->method = method; ctx->S = S; ctx->B = B; ctx->T = (method == PLSX_MEANCENTERED) ? 0 : T;

@@ -700,3 +700,39 @@ class Engine(object):
         keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch',
                 'xprod_resamples', 'dual_perm', 'compact_row_fraction']
         return {k: buf[i] for i, k in enumerate(keys[:max(n, 0)])}
+
+
+# ---------------------------------------------------------------------------
+# the front-ends' default engine
+# ---------------------------------------------------------------------------
+_DEFAULT = {}
+
+
+def default_engine(device=None):
+    """The engine the public calls use when none is passed: ONE per (process, device), created on first use and
+    kept -- its context, the resident copy of the last X and the super-batch scratch stay mapped between calls.
+
+    Why not a fresh engine per call (rounds 1-3): mapping device memory is not free on a shared MI355X.  The
+    driver clears recycled VRAM lazily, so a call that maps the tens of GB its predecessor just released waits
+    for the clear (25 ms per GB: 1 - 5 s measured for the c4 shape, ten times the analysis' own fixed cost),
+    while a context that is re-bound (plsx_set_data) reuses what it holds.  ``release_default_engine()`` gives
+    the memory back."""
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    key = int(device)
+    eng = _DEFAULT.get(key)
+    if eng is None or not getattr(eng, 'ctx', None):
+        if not _DEFAULT:
+            import atexit
+            atexit.register(release_default_engine)     # free the device memory before the runtime goes away
+        eng = _DEFAULT[key] = Engine(device=key)
+    return eng
+
+
+def release_default_engine(device=None):
+    """Destroy the cached default engine(s) and free their device memory."""
+    for key in ([int(device)] if device is not None else list(_DEFAULT)):
+        eng = _DEFAULT.pop(key, None)
+        if eng is not None:
+            eng.close()

@@ -170,9 +170,9 @@ class _PLSCRun(object):
         transposed the 200 MB distributions on the host: 0.26 - 0.30 s of fixed cost per call at c4.)"""
         import time
         import torch
-        from .engine import Engine
+        from .engine import default_engine
         inp = self.inputs
-        eng = self.engine or Engine()
+        eng = self.engine or default_engine()
         phases = self.phases                           # dict: per-phase wall times (bench.py --mode analysis)
 
         t_last = [time.perf_counter()]

@@ -172,12 +172,12 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
 def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,
                 bootsamples_out, k, ci, engine):
     import torch
-    from .engine import Engine
+    from .engine import default_engine
     S = len(X)
     # regression.py:395-397 (on copies: the reference centres the caller's X in place)
     Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
     B, T = X.shape[1], Yc.shape[1]
-    eng = engine or Engine()
+    eng = engine or default_engine()
     if np.isfinite(X.mean(axis=0)).all() and np.isfinite(Yc).all():
         # no missing data (one cheap pass): the device centres X itself (plsx_set_data),
         # so the S x B matrix is not copied / centred / scanned on the host

@@ -34,13 +34,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3"};
 
 struct plsx_ctx {
     int device = 0;
@@ -1236,17 +1236,17 @@ inline int urot_waves(const plsx_ctx* ctx, int nks_template, int B)
 }
 
 // One launch of the rotation kernel for the chunk of L tiles [lt0, lt0 + LT).
-template <int LT, int NKS, bool TAIL = false>
+template <int LT, int NKS, bool TAIL = false, int NST = 2>
 int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
                 double* ps, double* pq, hipStream_t st)
 {
     const int nw = urot_waves(ctx, NKS, ctx->B);
     const int nblk = ceil_div(ceil_div(ctx->B, 16), nw);
-    // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
-    const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
-    HIPCHK(set_lds(k_urot<LT, NKS, TAIL>, lds));
+    // NST LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
+    const size_t lds = (size_t)NST * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
+    HIPCHK(set_lds((k_urot<LT, NKS, TAIL, NST>), lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
-    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL>), dim3(nblk, nsplit), dim3(64 * nw), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL, NST>), dim3(nblk, nsplit), dim3(64 * nw), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
                        ctx->L, lt0 * 16, usum, usq, out, rps, ps, pq);
     LAUNCHCHK();
@@ -1298,7 +1298,9 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     // next resample prefetched
     // the last tile of L on the 4x4x4 shape when it holds at most 4 live columns (see k_urot)
     const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !ctx->opt[OPT_UROT_NO_TAIL4];
-    if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
+    if (!generic && ctx->opt[OPT_UROT_M3] && nks == 13 && LT == 4 && tail4)
+        rc = launch_urot<4, 13, true, 3>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st);
+    else if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: rc = tail4 ? launch_urot<(N + 3) / 4, N, true>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
                                     : launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;

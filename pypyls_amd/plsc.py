@@ -220,6 +220,12 @@ class _PLSCRun(object):
         n_boot_tot = bstream.n if bstream is not None else 0
         d_perm = d_dist = usum = usq = None
         plo, phi = parallel.shard_bounds(n_perm_tot, rank, world)
+        # Chunked shipping (IndexStream.chunks: 256 rows, then 4 x longer ranges) lets the device start while the
+        # generator thread still draws -- worth it when the shard is device-seconds long (c4: 2 s against 25 ms of
+        # drawing).  A small analysis (c2: 5000 bootstraps = 3 ms of device work) is launch bound and loses to its
+        # own extra launches: one range then.  The rule looks at the shape only (reproducible launch sizes).
+        est_ms = 2.0 * eng.S * eng.Tp * eng.B * max(n_perm_tot, n_boot_tot) / max(world, 1) / 4e10
+        first = 256 if est_ms > 50.0 else 1 << 30
         n_split = inp.get('n_split')
         mstream = None
         if n_split is not None and (pstream is not None or ystack is not None) and phi > plo:
@@ -233,7 +239,7 @@ class _PLSCRun(object):
             n_boot_tot, rank, world)) if bstream is not None else 0))
         if pstream is not None:
             d_perm = eng._zeros((phi - plo, L))
-            for a, b in pstream.chunks(plo, phi):
+            for a, b in pstream.chunks(plo, phi, first=first):
                 eng.perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - plo:b - plo], rotate=rotate)
         elif ystack is not None:
             host = eng.perm_ystack(ystack[plo:phi], rotate=rotate) if phi > plo else np.zeros((L, 0))
@@ -247,7 +253,7 @@ class _PLSCRun(object):
             d_dist = eng._zeros((sum(hi - lo for lo, hi in bchunks), eng.Tp, L))
             off = 0
             for blo, bhi in bchunks:
-                for a, b in bstream.chunks(blo, bhi):
+                for a, b in bstream.chunks(blo, bhi, first=first):
                     eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                   d_dist[off + a - blo:off + b - blo])
                 off += bhi - blo

@@ -240,3 +240,29 @@ def test_errors_and_layout():
     assert res.bootres.y_loadings_boot.shape == (5, 5, 8)
     assert res.bootres.y_loadings_ci.shape == (5, 5, 2)
     assert 'PLSResults' in repr(res)
+
+
+def test_default_engine_is_reused_and_rebinding_changes_nothing():
+    """The public calls share ONE cached engine per device (engine.default_engine): a call after calls of other
+    shapes and other methods returns bit-identical results to the first call of its kind, and to a call on a
+    fresh engine; release_default_engine() frees it."""
+    import pypyls_amd as pls
+    from pypyls_amd import engine
+    rs = np.random.RandomState(5)
+    X1, Y1 = rs.randn(40, 600), rs.randn(40, 4)
+    X2 = rs.randn(48, 900)
+    kw = dict(n_perm=20, n_boot=20, test_split=0, seed=3, verbose=False)
+    a = pls.behavioral_pls(X1, Y1, **kw)
+    eng = engine.default_engine()
+    pls.meancentered_pls(X2, groups=[8, 8], n_cond=3, n_perm=15, n_boot=15, seed=4, verbose=False)
+    pls.pls_regression(X1, Y1, n_components=3, n_perm=10, n_boot=10, seed=5, verbose=False)
+    assert engine.default_engine() is eng
+    b = pls.behavioral_pls(X1, Y1, **kw)
+    c = pls.behavioral_pls(X1, Y1, _engine=engine.Engine(), **kw)
+    for key in ('x_weights', 'singvals', 'x_scores', 'y_loadings'):
+        assert np.array_equal(a[key], b[key]) and np.array_equal(a[key], c[key]), key
+    for key in ('x_weights_normed', 'y_loadings_boot', 'y_loadings_ci'):
+        assert np.array_equal(a.bootres[key], b.bootres[key]) and np.array_equal(a.bootres[key], c.bootres[key]), key
+    assert np.array_equal(a.permres.perm_singval, b.permres.perm_singval)
+    pls.release_default_engine()
+    assert engine.default_engine() is not eng

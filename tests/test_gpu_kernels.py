@@ -245,8 +245,8 @@ def test_bootstrap_kernel_variants_agree(shape, monkeypatch):
     boots = rsmp.gen_bootsamp(groups, n_cond, 12, seed=4)
     got = {}
     for key, env in (('default', {}), ('gram16', {'PLSX_NO_GRAM4': '1'}), ('urot_generic', {'PLSX_UROT_GENERIC': '1'}),
-                     ('no_tail4', {'PLSX_UROT_NO_TAIL4': '1'})):
-        for k in ('PLSX_NO_GRAM4', 'PLSX_UROT_GENERIC', 'PLSX_UROT_NO_TAIL4'):
+                     ('no_tail4', {'PLSX_UROT_NO_TAIL4': '1'}), ('urot_m3', {'PLSX_UROT_M3': '1'})):
+        for k in ('PLSX_NO_GRAM4', 'PLSX_UROT_GENERIC', 'PLSX_UROT_NO_TAIL4', 'PLSX_UROT_M3'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -258,6 +258,8 @@ def test_bootstrap_kernel_variants_agree(shape, monkeypatch):
         got[key] = (usum.cpu().numpy(), usq.cpu().numpy(), dist)
     for a, b in zip(got['no_tail4'], got['urot_generic']):
         assert np.array_equal(a, b)                       # same arithmetic, same order
+    for a, b in zip(got['urot_m3'], got['default']):
+        assert np.array_equal(a, b)                       # three LDS stages of M (T' = 50 only): same arithmetic
     for a, b in zip(got['default'], got['no_tail4']):
         assert_close(a, b, 1e-12, what='4x4x4 tail tile vs 16x16x4')
     for a, b in zip(got['default'], got['gram16']):
@@ -425,3 +427,36 @@ np.savez(sys.argv[1], usum=usum.cpu().numpy(), usq=usq.cpu().numpy(), dist=dist,
         if ok.any():
             scale = np.max(np.abs(b[ok]))
             assert np.max(np.abs(a[ok] - b[ok])) <= 1e-8 * scale, 'lopsided resamples, compact vs dense: ' + k
+
+
+def test_device_side_finishing_steps():
+    """The pieces the device-resident front-end finishes with (round 4), each against numpy: the sign convention
+    of compute.svd (plsx_svd_flip vs hostmath.sign_convention, both branches T' <= B and T' > B), column scaling,
+    the (n, T' L) -> (T' L, n) transpose, the mean over splits, percentile intervals of device series."""
+    import torch
+    from pypyls_amd import resampling as rsmp, hostmath
+    for S, B, T in ((40, 700, 6), (30, 5, 9)):              # T' <= B: flip on x_weights; T' > B: on y_weights
+        X, Y, rs = _data(S, B, T, seed=3)
+        eng = _engine()
+        _setup(eng, X, Y, [S], 1)
+        xw, sv, yw = eng.decompose_dev()
+        want_x, want_y = hostmath.sign_convention(xw.cpu().numpy(), yw.cpu().numpy())
+        eng.svd_flip(xw, yw)
+        eng.sync()
+        assert np.array_equal(xw.cpu().numpy(), want_x) and np.array_equal(yw.cpu().numpy(), want_y)
+        lead = want_x if T <= B else want_y
+        assert (lead[np.argmax(np.abs(lead), axis=0), np.arange(lead.shape[1])] > 0).all()
+        sc = eng.scale_columns(xw, sv)
+        assert np.array_equal(sc.cpu().numpy(), want_x * sv.cpu().numpy()[None, :])
+    A = torch.rand((37, 91), dtype=torch.float64, device=eng.device)
+    assert np.array_equal(eng.transpose_dev(A).cpu().numpy(), A.cpu().numpy().T)
+    C = torch.rand((5, 7, 3), dtype=torch.float64, device=eng.device)
+    C[2, 4, 1] = float('nan')
+    out = torch.zeros((5, 3), dtype=torch.float64, device=eng.device)
+    eng.mean_splits_into(C, out)
+    want = C.cpu().numpy().mean(axis=1)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-15, equal_nan=True)
+    series = torch.randn((11, 1000), dtype=torch.float64, device=eng.device)
+    lo, hi = eng.percentile_ci_dev(series, ci=95)
+    wl, wh = np.percentile(series.cpu().numpy(), [2.5, 97.5], axis=-1)
+    assert np.array_equal(lo.cpu().numpy(), wl) and np.array_equal(hi.cpu().numpy(), wh)

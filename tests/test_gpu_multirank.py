@@ -177,3 +177,25 @@ def test_bench_config_lines(config):
     assert out['dtype'] == 'f64' and out['roofline']['bound'] in ('hbm', 'mfma')
     assert 0 < out['roofline']['frac'] <= 1.0 and out['cpu_baseline']['kind'] == 'port'
     assert out['value_primal'] > 0 and 'k_xprod' in out['config']['kernel_ms_per_step']
+
+
+def test_bench_analysis_mode_line():
+    """`bench.py --mode analysis`: the end-to-end line of the public call with per-phase times and the emulated
+    end-to-end critical path (small config, two emulated worlds)."""
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--mode', 'analysis', '--config', 'c2',
+                           '--perms', '300', '--boots', '300', '--steps', '1', '--emulate-world', '1,2'],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['config']['mode'] == 'analysis' and out['value'] > 0
+    w = out['end_to_end_emulation']['worlds']
+    assert set(w) == {'1', '2'}
+    for key in ('h2d_and_bind', 'decompose', 'permutations', 'bootstraps', 'collective', 'finish_and_d2h', 'host_finish'):
+        assert key in w['1']['rank0_phases_ms'], key
+    assert w['2']['critical_path_ms'] > 0 and 0 < w['2']['efficiency'] <= 1.5
+    assert out['fixed_cost_ms']['everything_else_ms'] >= 0

@@ -4,7 +4,7 @@
 #   <rNN>_bench.json, <rNN>_bench_kernel_stats.csv    default bench.py line + kernel trace stats of the SAME command
 #   <rNN>_<cfg>_kernel_stats.csv, <rNN>_bench_<cfg>.json   c4split, c5, c2, c3
 #   <rNN>_pmc_<counter>.csv                           per-kernel PMC sums (separate passes, counters only)
-tag=${1:-r03}
+tag=${1:-r04}
 repo=$(pwd); mkdir -p "$repo/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 
@@ -52,4 +52,4 @@ echo "== c5"; stats c5 --config c5 --steps 2 --warmup 1
 echo "== c2"; stats c2 --config c2 --steps 3 --warmup 1
 echo "== c3"; stats c3 --config c3 --steps 3 --warmup 1
 echo "== pmc"; pmc FETCH_SIZE; pmc WRITE_SIZE; pmc "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
-echo "== traffic"; cd "$repo"; for c in c4 c3 c5 c4split; do tools/traffic.sh $c $tag; done
+echo "== traffic"; cd "$repo"; for c in c4 c3 c5 c4split c2; do tools/traffic.sh $c $tag; done

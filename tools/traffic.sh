@@ -3,7 +3,7 @@
 # HBM bytes per launch of the dominant kernel of `bench.py --config <cfg>` from two SEPARATE rocprofv3
 # counter passes (FETCH_SIZE, then WRITE_SIZE; counters only, with --kernel-trace -- MI355X_MICROARCH.md,
 # section HBM / rocprofv3) -> gpurun_out/traffic_<cfg>.json (copy to profiles/ for bench.py to report it).
-cfg=${1:-c4}; tag=${2:-r03}
+cfg=${1:-c4}; tag=${2:-r04}
 repo=$(pwd); mkdir -p "$repo/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -130,18 +130,19 @@ def test_config_c4_split_half_500x200000(fused, monkeypatch):
     eng = _engine()
     eng.set_data(X, Y, rsmp.cell_of_row([S], 1), 1, 1, 0)
     spec = ref.Spec('behavioral', [S], 1)
-    ns = 3
-    masks = np.stack([rsmp.gen_splits([S], 1, ns, seed=30 + i) for i in range(2)])
-    perm = rsmp.gen_permsamp([S], 1, 1, seed=7)
+    ns, npm = 3, 3                                       # the original + three permuted arrangements x three splits
+    masks = np.stack([rsmp.gen_splits([S], 1, ns, seed=30 + i) for i in range(1 + npm)])
+    perm = rsmp.gen_permsamp([S], 1, npm, seed=7)
     uc0, vc0 = eng.split_half(masks[:1])
     uc1, vc1 = eng.split_half(masks[1:], perms=perm)
-    for (uc, vc, Yp, mk) in ((uc0, vc0, Y, masks[0]), (uc1, vc1, Y[perm[:, 0]], masks[1])):
+    cases = [(uc0[0], vc0[0], Y, masks[0])] + [(uc1[p], vc1[p], Y[perm[:, p]], masks[1 + p]) for p in range(npm)]
+    for a, (uc, vc, Yp, mk) in enumerate(cases):
         U, d, V = ref.decompose(spec, X, Yp)
         di = np.linalg.inv(d)
         for i in range(ns):
             u, v = ref.split_half(spec, X, Yp, U @ di, V @ di, mk[:, [i]])
-            assert_close(uc[0][:, i], u, 1e-6, what='c4 ucorr split {}'.format(i))
-            assert_close(vc[0][:, i], v, 1e-6, what='c4 vcorr split {}'.format(i))
+            assert_close(uc[:, i], u, 1e-6, what='c4 ucorr arrangement {} split {}'.format(a, i))
+            assert_close(vc[:, i], v, 1e-6, what='c4 vcorr arrangement {} split {}'.format(a, i))
 
 
 def test_config_c5_regression_1000x100000():

@@ -225,11 +225,11 @@ def test_context_rebinding_matches_fresh_context():
             assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_full_size_one_resample_against_oracle():
-    """One permutation and one bootstrap at the BASELINE size, directly against
-    the oracle (~10 s of host time)."""
+def test_full_size_resamples_against_oracle():
+    """Eight permutations (both routes) and eight bootstraps at the BASELINE size, directly against the
+    oracle, per resample (~25 s of host time on the box's 256 cores)."""
     from pypyls_amd import hostmath, resampling as rsmp
-    S, B, T = 500, 200000, 50
+    S, B, T, n = 500, 200000, 50, 8
     rs = np.random.RandomState(3)
     X = rs.randn(S, B)
     Y = rs.randn(S, T) + 0.3 * X[:, :T]
@@ -238,15 +238,24 @@ def test_full_size_one_resample_against_oracle():
     xw, sv, yw = eng.decompose()
     xw, yw = hostmath.sign_convention(xw, yw)
     eng.set_original(xw, sv, yw)
-    perm = rsmp.gen_permsamp([S], 1, 1, seed=11)
-    boot = rsmp.gen_bootsamp([S], 1, 1, seed=12)
-    got_p = eng.perm(perm)[:, 0]
-    want_p = ref.single_perm(spec, X, Y, perm[:, 0], yw)[0]
-    assert_close(got_p, want_p, 1e-7, what='perm singvals at full size')
-    usum, usq, dist = eng.boot(boot)
-    wd, wu = ref.single_boot(spec, X, Y, boot[:, 0], xw, np.diag(sv))
-    assert_close(usum.cpu().numpy(), wu, 1e-6, what='rotated bootstrap weights at full size')
-    assert_close(dist[:, :, 0], wd, 1e-7, what='bootstrap distrib at full size')
+    perms = rsmp.gen_permsamp([S], 1, n, seed=11)
+    boots = rsmp.gen_bootsamp([S], 1, n, seed=12)
+    want_p = np.stack([ref.single_perm(spec, X, Y, perms[:, i], yw)[0] for i in range(n)], -1)
+    for dual in (True, False):
+        eng.set_perm_path(dual)
+        got_p = eng.perm(perms)
+        for i in range(n):
+            assert_close(got_p[:, i], want_p[:, i], 1e-9, what='perm singvals at full size, dual={} #{}'.format(dual, i))
+    eng.set_perm_path(True)
+    for i in range(n):                                   # one at a time: sum U of ONE bootstrap is its rotated weights
+        usum, usq, dist = eng.boot(boots[:, [i]])
+        wd, wu = ref.single_boot(spec, X, Y, boots[:, i], xw, np.diag(sv))
+        assert_close(usum.cpu().numpy(), wu, 1e-8, what='rotated bootstrap weights at full size #{}'.format(i))
+        assert_close(usq.cpu().numpy(), wu ** 2, 1e-8, what='squared bootstrap weights at full size #{}'.format(i))
+        assert_close(dist[:, :, 0], wd, 1e-9, what='bootstrap distrib at full size #{}'.format(i))
+    usum, usq, dist = eng.boot(boots)                    # ... and the batch of eight together
+    ws = sum(ref.single_boot(spec, X, Y, boots[:, i], xw, np.diag(sv))[1] for i in range(n))
+    assert_close(usum.cpu().numpy(), ws, 1e-8, what='sum U of eight bootstraps at full size')
 
 
 def test_randomised_parity_sweep():

@@ -62,7 +62,23 @@ def _boots_full_rank(g):
                for i in range(boots.shape[1]) for c in cells)
 
 
-def _compare(res, g, want, keep, boot_tight):
+def _compare(res, g, want, keep, boot_tight, per_lv=False):
+    if per_lv:
+        # against the ORACLE (same conventions): every live latent variable on its own scale
+        from conftest import assert_close_per_lv
+        assert_close_per_lv(res['singvals'], want['singvals'], 0, RTOL, 'singvals (per LV)', keep)
+        for k in ('x_weights', 'y_weights', 'x_scores', 'y_scores', 'y_loadings'):
+            if want.get(k) is not None and res.get(k) is not None:
+                assert_close_per_lv(res[k], want[k], 1, RTOL, k + ' (per LV)', keep)
+        if want.get('permres') and bool(g.get('rotate', True)) is False:
+            # unrotated: row k of the null is the k-th singular value of the permuted data (its own scale);
+            # rotated rows mix all of them
+            assert_close_per_lv(res['permres']['perm_singval'], want['permres']['perm_singval'], 0, RTOL,
+                                'perm_singval (per LV)', keep)
+        if want.get('bootres'):
+            for k in ('y_loadings_boot', 'contrast_boot', 'x_weights_stderr'):
+                if want['bootres'].get(k) is not None:
+                    assert_close_per_lv(res['bootres'][k], want['bootres'][k], 1, RTOL, k + ' (per LV)', keep)
     assert_close(res['singvals'][keep], want['singvals'][keep], RTOL, what='singvals')
     assert_close(res['varexp'][keep], want['varexp'][keep], RTOL, what='varexp')
     for k in ('x_weights', 'y_weights', 'x_scores', 'y_scores', 'y_loadings'):
@@ -120,7 +136,7 @@ def test_behavioral_vs_reference_and_oracle(name):
     res = _run(g, 'behavioral')
     keep = live_lvs(g['ref_singvals'])
     # (b) oracle: same algorithmic conventions -> tight everywhere
-    _compare(res, g, _oracle(g, 'behavioral'), keep, boot_tight=True)
+    _compare(res, g, _oracle(g, 'behavioral'), keep, boot_tight=True, per_lv=True)
     _compare_split(res, _oracle(g, 'behavioral'), keep)
     _compare_split(res, _ref_as_dict(g), keep)
     if 'cv_splits' in g:
@@ -140,7 +156,7 @@ def test_meancentered_vs_reference_and_oracle(name):
     g = load_golden(name)
     res = _run(g, 'meancentered')
     keep = live_lvs(g['ref_singvals'])
-    _compare(res, g, _oracle(g, 'meancentered'), keep, boot_tight=True)
+    _compare(res, g, _oracle(g, 'meancentered'), keep, boot_tight=True, per_lv=True)
     _compare_split(res, _oracle(g, 'meancentered'), keep)
     _compare_split(res, _ref_as_dict(g), keep)
     _compare(res, g, _ref_as_dict(g), keep, boot_tight=False)

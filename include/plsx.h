@@ -315,7 +315,8 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *     4096), "inblock_moments", "no_fixed_x", "no_dual_perm"
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
  *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
- *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "epi2_nw4", "trace_alloc";
+ *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "urot_m3", "epi2_nw4", "simpls_jacobi"
+ *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "trace_alloc";
  *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
  *     size the super-batch scratch for n once instead of per call (0 = per call)
  * plsx_option_name(i) enumerates the keys (NULL past the last).  No reference counterpart.

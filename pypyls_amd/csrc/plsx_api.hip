@@ -34,13 +34,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi"};
 
 struct plsx_ctx {
     int device = 0;
@@ -2413,6 +2413,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     if (int e = ensure_scratch(ctx, std::min(groups, ctx->Gcap))) return e;
     SdArgs a;
     memset(&a, 0, sizeof(a));
+    a.jacobi_eig = ctx->opt[OPT_SIMPLS_JACOBI] ? 1 : 0;
     a.S = S; a.T = T; a.k = k; a.nres = nres;
     a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
     a.y_stride = ystack ? (long long)S * T : 0;

@@ -99,6 +99,7 @@ struct SdArgs {
     const double* Qs;           // [S][k] Xc . W0c^T (centred original weights): bootstrap sign alignment in dual space, or nullptr
     size_t group_stride;
     GroupLayout lay;
+    int jacobi_eig;             // 1: full one-sided Jacobi for the leading eigenpair (round 3) instead of wave_top_eig
 };
 
 // doubles of LDS one wave of k_sd_step needs
@@ -369,6 +370,221 @@ __device__ void wave_jacobi_cols(double* A, int m, int n, int ld, int lane, doub
     }
 }
 
+// Leading eigenpair of a symmetric PSD matrix by ONE wavefront without Jacobi sweeps (round 4): SIMPLS needs
+// only the top eigenpair of the T x T matrix H per component (pyls/types/regression.py:106-112 takes the leading
+// singular triplet of the cross-covariance), and the full one-sided Jacobi solve was the longest phase of
+// k_sd_step (152 dependent pair-steps per sweep at T = 20, ~8 sweeps: 0.16 ms of a 0.38 ms launch).
+//   1. Householder reduction to tridiagonal form, in place (A: n x n, A[c * ld + r], both triangles stored):
+//      for k = 0 .. n-3 the unit reflector v_k (rows k+1 ..) annihilates column k below the subdiagonal,
+//      A22 <- A22 - 2 v w^T - 2 w v^T with p = A22 v, w = p - (v.p) v; lanes own rows, v_k stays in column k.
+//   2. Largest eigenvalue of the tridiagonal (d, e) by MULTIsection: every lane evaluates the Sturm count
+//      (number of eigenvalues below its abscissa) at one of 64 points of the bracket, a ballot finds the
+//      sub-interval: 65 x narrower per round, 9 rounds from the Gershgorin bracket to eps (robust for
+//      clustered eigenvalues -- permuted data has closely spaced singular values).
+//   3. Its eigenvector by inverse iteration on the tridiagonal (LU with partial pivoting as LAPACK's dlagtf /
+//      dlagts, three iterations from a flat start vector; one lane, n-step recurrences).
+//   4. Back-transformation y <- H_0 H_1 ... H_{n-3} y.
+// n <= 64.  Measured with the s_memtime probes at c5 (T = 20): see DESIGN.md.  ws: n doubles of the wave's LDS.
+// Returns lambda_max; vec[0..n)
+// = unit eigenvector (sign arbitrary, as with Jacobi: SIMPLS is invariant to it, the front-end's sign rule
+// and the bootstrap's sign alignment act on the weights).
+// Value of lane `i` (wave-uniform, runtime) of a per-lane double: two v_readlane_b32 -- a few cycles, where a
+// broadcast through the wave's LDS costs a ~64-cycle round trip on every link of a serial recurrence.
+__device__ __forceinline__ double lane_get(double v, int i)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), i);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ double wave_top_eig(double* A, int n, int ld, int lane, double* ws, double* vec)
+{
+    // n <= 64: the vectors of the tridiagonal stage live one element per lane (d, e, the LU factors, the iterate);
+    // serial recurrences read them with lane_get.
+    double* pw = ws;             // [n] p / w of the reflector step (LDS)
+    if (n == 1) {
+        if (lane == 0) vec[0] = 1.0;
+        wave_sync();
+        return A[0];
+    }
+    double dl = 0.0, el = 0.0;   // d[lane], e[lane] (e[i] couples rows i and i + 1)
+    for (int k = 0; k + 2 < n; ++k) {
+        double s2 = 0.0;
+        for (int i = k + 2 + lane; i < n; i += 64) { const double x = A[(size_t)k * ld + i]; s2 += x * x; }
+        s2 = wave_sum(s2);
+        const double x0 = A[(size_t)k * ld + k + 1];
+        const double dk = A[(size_t)k * ld + k];
+        if (lane == k) dl = dk;
+        if (!(s2 > 0.0)) {                                 // already tridiagonal in this column: H_k = I
+            if (lane == k) el = x0;
+            wave_sync();
+            if (lane == 0) A[(size_t)k * ld + k + 1] = 0.0;
+            wave_sync();
+            continue;
+        }
+        const double alpha = -copysign(sqrt(__builtin_fma(x0, x0, s2)), x0);
+        if (lane == k) el = alpha;
+        const double v0 = x0 - alpha;
+        const double inv = 1.0 / sqrt(__builtin_fma(v0, v0, s2));
+        wave_sync();
+        for (int i = k + 1 + lane; i < n; i += 64)
+            A[(size_t)k * ld + i] = (i == k + 1 ? v0 : A[(size_t)k * ld + i]) * inv;
+        wave_sync();
+        const double* v = A + (size_t)k * ld;             // v[i], i = k + 1 .. n - 1
+        // p = A22 v, rows lane-strided; operands of eight columns are fetched before they are used (independent
+        // LDS reads in flight instead of one round trip per column)
+        const int i = k + 1 + lane;                        // (n <= 64: one row per lane)
+        const int ic = min(i, n - 1);
+        double pi = 0.0;
+        for (int j0 = k + 1; j0 < n; j0 += 8) {
+            double av[8], vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, n - 1); av[u] = A[(size_t)j * ld + ic]; vv[u] = v[j]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pi = __builtin_fma(av[u], (j0 + u < n) ? vv[u] : 0.0, pi);
+        }
+        const double vi = i < n ? v[ic] : 0.0;
+        const double K = wave_sum(i < n ? vi * pi : 0.0);
+        const double wi = __builtin_fma(-K, vi, pi);      // w = p - K v
+        if (i < n) pw[i] = wi;
+        wave_sync();
+        for (int j0 = k + 1; j0 < n; j0 += 8) {
+            double av[8], vv[8], ww[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = min(j0 + u, n - 1);
+                av[u] = A[(size_t)j * ld + ic]; vv[u] = v[j]; ww[u] = pw[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double t = __builtin_fma(vi, ww[u], wi * vv[u]);
+                av[u] = __builtin_fma(-2.0, t, av[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i < n && j0 + u < n) A[(size_t)(j0 + u) * ld + i] = av[u];
+        }
+        wave_sync();
+    }
+    {
+        const double a = A[(size_t)(n - 2) * ld + n - 2], b = A[(size_t)(n - 2) * ld + n - 1], c = A[(size_t)(n - 1) * ld + n - 1];
+        if (lane == n - 2) { dl = a; el = b; }
+        if (lane == n - 1) { dl = c; el = 0.0; }
+    }
+    // ---- lambda_max by multisection on the Sturm count
+    double hi = -1e300, lo = -1e300, emax = 0.0;
+    {
+        const double eup = __shfl_up(el, 1);               // (unconditionally: every source lane must be active)
+        const double em = lane > 0 ? fabs(eup) : 0.0, ep = lane + 1 < n ? fabs(el) : 0.0;
+        double g = lane < n ? dl + em + ep : -1e300, dd = lane < n ? dl : -1e300, ee = lane < n ? ep : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            g = fmax(g, __shfl_xor(g, o)); dd = fmax(dd, __shfl_xor(dd, o)); ee = fmax(ee, __shfl_xor(ee, o));
+        }
+        hi = g; lo = dd; emax = ee;                          // lambda_max >= every diagonal entry
+    }
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax * emax);
+    const double span0 = fmax(fabs(hi), fabs(lo));
+    lo -= 4.0 * 2.220446049250313e-16 * span0 + pivmin;
+    hi += 4.0 * 2.220446049250313e-16 * span0 + pivmin;
+    const double e2l = el * el;
+    for (int round = 0; round < 14; ++round) {
+        const double x = lo + (hi - lo) * ((double)(lane + 1) * (1.0 / 65.0));
+        // Sturm count without divisions: the sign changes of the leading principal minors p_i of (T - x I),
+        // p_i = (d_i - x) p_{i-1} - e_{i-1}^2 p_{i-2}, equal the number of eigenvalues below x (a zero minor takes
+        // the sign opposite to its predecessor, as the pivot rule q = -pivmin of the quotient form does); the
+        // pair (p_{i-1}, p_i) is rescaled by a power of two when it leaves [2^-200, 2^200].  d_i, e_{i-1}^2 come
+        // from lane i / i - 1 by readlane: two dependent FMAs per row is what a round costs.
+        double pm = 1.0, pc = lane_get(dl, 0) - x;
+        bool nprev = pc < 0.0 || pc == 0.0;                // sign assigned to the latest minor (p_0 = 1 is positive)
+        int cnt = nprev;
+        for (int i = 1; i < n; ++i) {
+            const double di = lane_get(dl, i), e2 = lane_get(e2l, i - 1);
+            const double pn = __builtin_fma(di - x, pc, -e2 * pm);
+            const bool nnew = pn < 0.0 || (pn == 0.0 && !nprev);
+            cnt += nnew != nprev;
+            nprev = nnew;
+            pm = pc; pc = pn;
+            const double mag = fmax(fabs(pm), fabs(pc));
+            if (mag > 0x1p200) { pm *= 0x1p-200; pc *= 0x1p-200; }
+            else if (mag < 0x1p-200 && mag > 0.0) { pm *= 0x1p200; pc *= 0x1p200; }
+        }
+        const unsigned long long above = __ballot(cnt >= n);          // abscissas above every eigenvalue
+        const int jf = above ? __builtin_ctzll(above) : 64;
+        const double span = hi - lo;
+        const double nlo = jf > 0 ? lo + span * ((double)jf * (1.0 / 65.0)) : lo;
+        const double nhi = jf < 64 ? lo + span * ((double)(jf + 1) * (1.0 / 65.0)) : hi;
+        lo = nlo; hi = nhi;
+        if (hi - lo <= 2.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+    }
+    const double lam = 0.5 * (lo + hi);
+    // ---- eigenvector of the tridiagonal: LU with partial pivoting of (T - lam I) (as LAPACK's dlagtf / dlagts),
+    // ---- three inverse iterations.  Element i of every vector lives in lane i; each step of the recurrences is
+    // ---- computed by every lane from readlane values (wave-uniform) and kept by the lane that owns it.
+    double la = dl - lam;                                  // diagonal of U
+    double lb = lane + 1 < n ? el : 0.0;                   // first superdiagonal of U
+    double lc = 0.0, l2 = 0.0;                             // multipliers, second superdiagonal (fill-in of row swaps)
+    bool sw = false;
+    {
+        const double eup = __shfl_up(el, 1);
+        double tn = fabs(la) + (lane > 0 ? fabs(eup) : 0.0) + (lane + 1 < n ? fabs(el) : 0.0);
+        if (lane >= n) tn = 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tn = fmax(tn, __shfl_xor(tn, o));
+        const double tiny = fmax(2.220446049250313e-16 * tn, pivmin);
+        for (int i = 0; i + 1 < n; ++i) {
+            const double sub = lane_get(el, i);                // entry (i + 1, i) before elimination
+            const double ai = lane_get(la, i), bi = lane_get(lb, i);
+            const double a1 = lane_get(la, i + 1), b1 = lane_get(lb, i + 1);
+            if (fabs(ai) >= fabs(sub)) {
+                double piv = ai;
+                if (fabs(piv) < tiny) piv = copysign(tiny, piv == 0.0 ? 1.0 : piv);
+                const double m = sub / piv;
+                if (lane == i) { la = piv; lc = m; }
+                if (lane == i + 1) la = a1 - m * bi;
+            } else {                                           // swap rows i and i + 1
+                const double m = ai / sub;
+                if (lane == i) { lc = m; sw = true; la = sub; lb = a1; l2 = b1; }
+                if (lane == i + 1) { la = bi - m * a1; lb = -m * b1; }
+            }
+        }
+        const double an = lane_get(la, n - 1);
+        if (lane == n - 1 && fabs(an) < tiny) la = copysign(tiny, an == 0.0 ? 1.0 : an);
+    }
+    double y = lane < n ? ((lane & 1) ? 0.9 : 1.1) : 0.0;
+    const unsigned long long swm = __ballot(sw);
+    for (int it = 0; it < 3; ++it) {
+        for (int i = 0; i + 1 < n; ++i) {                   // forward: the same row operations on the right-hand side
+            const double yi = lane_get(y, i), y1 = lane_get(y, i + 1), m = lane_get(lc, i);
+            if ((swm >> i) & 1) {
+                if (lane == i) y = y1;
+                if (lane == i + 1) y = yi - m * y1;
+            } else if (lane == i + 1) y = y1 - m * yi;
+        }
+        for (int i = n - 1; i >= 0; --i) {                  // back substitution with (la, lb, l2)
+            double t = lane_get(y, i);
+            if (i + 1 < n) t -= lane_get(lb, i) * lane_get(y, i + 1);
+            if (i + 2 < n) t -= lane_get(l2, i) * lane_get(y, i + 2);
+            t /= lane_get(la, i);
+            if (lane == i) y = t;
+        }
+        double nr = lane < n ? fabs(y) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nr = fmax(nr, __shfl_xor(nr, o));
+        y *= 1.0 / nr;
+    }
+    y *= 1.0 / sqrt(wave_sum(lane < n ? y * y : 0.0));
+    // ---- back-transformation: y <- H_k y for k = n - 3 .. 0 (lane i holds y_i and reads v_k[i] from column k)
+    for (int k = n - 3; k >= 0; --k) {
+        const double vk = (lane > k && lane < n) ? A[(size_t)k * ld + lane] : 0.0;
+        const double dp = wave_sum(vk * y);
+        y = __builtin_fma(-2.0 * dp, vk, y);
+    }
+    if (lane < n) vec[lane] = y;
+    wave_sync();
+    return lam;
+}
+
 // Component step c (see the header): closes component c - 1 when c > 0, opens component c
 // unless c == k.  dynamic LDS: sd_step_lds(S, T, k) doubles per wave.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
@@ -500,24 +716,34 @@ void k_sd_step(SdArgs a)
     for (int idx = lane; idx < T * T; idx += 64) Hw[(idx % T) * ldh + idx / T] = H[idx];
     wave_sync();
     SD_MARK(4);
-    // rows per lane of a column (4 lanes per pair): 8 covers T <= 32, 36 the LDS limit of T
-    if (T <= 32) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
-    else if (T <= 64) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
-    else wave_jacobi_cols<36>(Hw, T, T, ldh, lane, 1e-15);
-    SD_MARK(5);
-    for (int col = lane; col < T; col += 64) {
-        double s = 0.0;
-        for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }
-        gv[col] = sqrt(s);
+    double lam;
+    if (!a.jacobi_eig && T <= 64 && T <= S) {
+        // the leading eigenpair alone (Householder + multisection + inverse iteration); the [S] scatter buffer,
+        // idle until the end of the launch, is its workspace
+        lam = wave_top_eig(Hw, T, ldh, lane, buf, cv);
+        SD_MARK(5);
+        for (int t = lane; t < T; t += 64) a.cvec[((size_t)r * T + t) * k + c] = cv[t];
+    } else {
+        // rows per lane of a column (4 lanes per pair): 8 covers T <= 32, 36 the LDS limit of T
+        if (T <= 32) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
+        else if (T <= 64) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
+        else wave_jacobi_cols<36>(Hw, T, T, ldh, lane, 1e-15);
+        SD_MARK(5);
+        for (int col = lane; col < T; col += 64) {
+            double s = 0.0;
+            for (int i = 0; i < T; ++i) { const double x = Hw[col * ldh + i]; s += x * x; }
+            gv[col] = sqrt(s);
+        }
+        wave_sync();
+        int best = 0;
+        for (int col = 1; col < T; ++col) if (gv[col] > gv[best]) best = col;
+        lam = gv[best];
+        for (int t = lane; t < T; t += 64) {
+            cv[t] = Hw[best * ldh + t] / lam;
+            a.cvec[((size_t)r * T + t) * k + c] = cv[t];
+        }
     }
-    wave_sync();
-    int best = 0;
-    for (int col = 1; col < T; ++col) if (gv[col] > gv[best]) best = col;
-    const double lam = gv[best], si = sqrt(lam);
-    for (int t = lane; t < T; t += 64) {
-        cv[t] = Hw[best * ldh + t] / lam;
-        a.cvec[((size_t)r * T + t) * k + c] = cv[t];
-    }
+    const double si = sqrt(lam);
     wave_sync();
     for (int j0 = 0; j0 < c; j0 += 4) {        // gc_j = g_j . c, lanes over t (each reads its own entries of G)
         double s4[4] = {0.0, 0.0, 0.0, 0.0};

@@ -168,3 +168,36 @@ def test_single_pass_bootstrap_equals_two_pass(monkeypatch):
     np.testing.assert_array_equal(a.bootres.bootsamples, b.bootres.bootsamples)
     for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot', 'y_loadings_ci'):
         assert_close(a['bootres'][key], b['bootres'][key], 1e-9, what='single vs two pass ' + key)
+
+
+@pytest.mark.parametrize('S,B,T,k', [(70, 900, 1, 1), (70, 900, 2, 2), (90, 1500, 5, 4), (120, 2000, 11, 6), (200, 2500, 20, 9)])
+def test_leading_eigenpair_solver_equals_jacobi_and_oracle(S, B, T, k, monkeypatch):
+    """SIMPLS takes only the leading eigenpair of the T x T matrix H per component: Householder + multisection +
+    inverse iteration on one wavefront (round 4, wave_top_eig; needs 8 T + 8 <= S of the wave's scatter buffer)
+    against the full one-sided Jacobi solve it replaces (PLSX_SIMPLS_JACOBI -> plsx_set_option) and the oracle's
+    exact SIMPLS -- including behaviours that are near copies of each other (clustered eigenvalues of H)."""
+    import pypyls_amd as pls
+    from pypyls_amd.engine import Engine, options_from_env
+    rs = np.random.RandomState(S + T)
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.4 * X[:, :T]
+    if T >= 5:
+        Y[:, 1] = Y[:, 0] + 1e-7 * rs.randn(S)            # two nearly identical behaviours
+    out = {}
+    for route in ('top', 'jacobi'):
+        monkeypatch.delenv('PLSX_SIMPLS_JACOBI', raising=False)
+        if route == 'jacobi':
+            monkeypatch.setenv('PLSX_SIMPLS_JACOBI', '1')
+        out[route] = pls.pls_regression(X, Y, n_components=k, n_perm=40, n_boot=40, seed=9, verbose=False,
+                                        _engine=Engine(**options_from_env()))
+    monkeypatch.delenv('PLSX_SIMPLS_JACOBI', raising=False)
+    a, b = out['top'], out['jacobi']
+    assert_close(a.x_weights, b.x_weights, 1e-9, what='x_weights top vs jacobi')
+    assert_close(a.varexp, b.varexp, 1e-10, what='pctvar top vs jacobi')
+    assert_close(a.permres.perm_singval, b.permres.perm_singval, 1e-9, what='perm pctvar top vs jacobi')
+    assert_close(a.bootres.x_weights_stderr, b.bootres.x_weights_stderr, 1e-7, what='stderr top vs jacobi')
+    Xc, Yc = X - X.mean(axis=0), Y - Y.mean(axis=0)
+    fit = ref.simpls(Xc, Yc, k)
+    sgn = np.sign(np.sum(fit['x_weights'] * a.x_weights, axis=0))
+    assert_close(a.x_weights * sgn, fit['x_weights'], 1e-6, what='x_weights vs oracle')
+    assert_close(a.varexp, fit['pctvar'][1], 1e-8, what='pctvar vs oracle')

@@ -221,11 +221,11 @@ class _PLSCRun(object):
         d_perm = d_dist = usum = usq = None
         plo, phi = parallel.shard_bounds(n_perm_tot, rank, world)
         # Chunked shipping (IndexStream.chunks: 256 rows, then 4 x longer ranges) lets the device start while the
-        # generator thread still draws -- worth it when the shard is device-seconds long (c4: 2 s against 25 ms of
-        # drawing).  A small analysis (c2: 5000 bootstraps = 3 ms of device work) is launch bound and loses to its
-        # own extra launches: one range then.  The rule looks at the shape only (reproducible launch sizes).
-        est_ms = 2.0 * eng.S * eng.Tp * eng.B * max(n_perm_tot, n_boot_tot) / max(world, 1) / 4e10
-        first = 256 if est_ms > 50.0 else 1 << 30
+        # generator thread still draws.  It pays at both ends of the size range: c4's shard is device-seconds long
+        # against 25 ms of drawing, and c2's 5000 + 5000 index rows take the host about as long to DRAW (4 - 9 ms)
+        # as the device needs to process them -- shipping them as one range when the draw ends (tried: est. device
+        # time < 50 ms -> one range) made the call slower, 9.9 -> 11.4 ms.  Caller-supplied arrays are one range.
+        first = 256
         n_split = inp.get('n_split')
         mstream = None
         if n_split is not None and (pstream is not None or ystack is not None) and phi > plo:

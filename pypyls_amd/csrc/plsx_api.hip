@@ -997,9 +997,11 @@ int run_gram4(plsx_ctx* ctx, int nres, int nb4, int mode, const double* E, int E
 }
 
 int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, double* Pout,
-                hipStream_t st)
+                hipStream_t st, const double* Rsrc = nullptr)
 {
-    const double* R = ptr<double>(ctx->R);
+    // Rsrc: the (nres x T'pp x Bpad) blocks to multiply when they are not the cross-product scratch itself
+    // (cross-validation's rescaled copies)
+    const double* R = Rsrc ? Rsrc : ptr<double>(ctx->R);
     double* Gm = ptr<double>(ctx->Gm);
     const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
     if ((ctx->Tp > 64 || Erows > 64) && !ctx->opt[OPT_GRAM_NT]) {
@@ -2384,9 +2386,16 @@ int crossval_impl(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, dou
                            ptr<double>(ctx->R2), ptr<double>(ctx->cvc), Tp, ctx->gps, ptr<int>(ctx->cell_momrow));
         LAUNCHCHK();
         if (int e2 = ensure(ctx, ctx->Qm, (size_t)mm * J * Tp * S * 8)) return e2;
-        if (int e2 = run_nt(ctx, ptr<double>(ctx->R2), ctx->strideR, ctx->Bpad, Tp, ptr<double>(ctx->Xc), 0,
-                            ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, mm * J, ptr<double>(ctx->Qm),
-                            (long long)Tp * S, S, nullptr, 0, 0, st))
+        // Q = Rs . Xc^T (T' x S per split and cell): the product that dominates a split (2 T' S B flop = 1e10 at c4,
+        // twice a bootstrap's cross-product).  Round 4: on the 64 x 64-block Gram kernel (P = R . E^T with E = Xc
+        // shared by every split: L2 holds it) instead of the generic LDS-tiled NT GEMM
+        if (ctx->opt[OPT_GRAM_NT]) {
+            if (int e2 = run_nt(ctx, ptr<double>(ctx->R2), ctx->strideR, ctx->Bpad, Tp, ptr<double>(ctx->Xc), 0,
+                                ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, mm * J, ptr<double>(ctx->Qm),
+                                (long long)Tp * S, S, nullptr, 0, 0, st))
+                return e2;
+        } else if (int e2 = run_gram_ex(ctx, mm * J, 2, ptr<double>(ctx->Xc), S, ptr<double>(ctx->Qm), st,
+                                        ptr<double>(ctx->R2)))
             return e2;
         if (int e2 = ensure(ctx, ctx->ybar, (size_t)mm * J * T * 8)) return e2;
         if (int e2 = ensure(ctx, ctx->pred, (size_t)mm * S * T * 8)) return e2;

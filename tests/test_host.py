@@ -287,3 +287,29 @@ def test_options_from_env_translates_known_keys_only():
                                   'PLSX_UNKNOWN': '1', 'HOME': '/root'})
     assert kw == {'options': {'no_dual_perm': 1, 'min_batch': 512}, 'scratch_gb': 6.0}
     assert engine.options_from_env({}) == {'options': {}}
+
+
+def test_collect_device_emulated_world_orders_and_sums_like_a_real_one():
+    """parallel.collect_device with emulate=(rank, world) (bench.py --mode analysis --emulate-world): no peers,
+    the surrogate gather replicates this rank's packed buffer; the bookkeeping -- padded shard sizes, the global
+    order of chunk-cyclic shards, the rank-ordered sums -- is the code path of a real gather."""
+    import torch
+    from pypyls_amd import parallel
+    n_perm, n_boot, world = 11, 13, 4
+    for rank in range(world):
+        plo, phi = parallel.shard_bounds(n_perm, rank, world)
+        rows = parallel.shard_rows(n_boot, rank, world)
+        perm = torch.arange(plo, phi, dtype=torch.float64)[:, None] * torch.ones(1, 3, dtype=torch.float64)
+        dist = torch.from_numpy(rows.astype(np.float64))[:, None, None] * torch.ones(1, 2, 2, dtype=torch.float64)
+        usum = torch.full((5, 2), float(rank + 1), dtype=torch.float64)
+        full, summed = parallel.collect_device([perm, dist], [n_perm, n_boot], [usum], cyclic=[1],
+                                               emulate=(rank, world))
+        assert full[0].shape == (n_perm, 3) and full[1].shape == (n_boot, 2, 2)
+        # this rank's own rows sit where the global order puts them (the other ranks' slots hold copies)
+        np.testing.assert_array_equal(full[0][plo:phi, 0].numpy(), np.arange(plo, phi))
+        np.testing.assert_array_equal(full[1][rows, 0, 0].numpy(), rows)
+        np.testing.assert_array_equal(summed[0].numpy(), np.full((5, 2), world * (rank + 1.0)))
+    # without a process group and without emulation nothing moves
+    t = torch.ones(3, 2, dtype=torch.float64)
+    full, summed = parallel.collect_device([t], [3], [t])
+    assert full[0] is t and summed[0] is t

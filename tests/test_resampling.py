@@ -253,3 +253,30 @@ def test_chunk_boundaries_do_not_depend_on_arrival():
     assert list(st.chunks(1250, 2500)) == [(1250, 1506), (1506, 2500)]
     assert list(st.chunks(0, 700, limit=256)) == [(0, 256), (256, 512), (512, 700)]
     assert list(st.chunks(0, 300)) == [(0, 300)]
+
+
+def test_mask_stream_blocks_equal_the_seeded_generator():
+    """MaskStream (streamed split-half, round 4): the blocks a host thread produces while the device works are
+    the masks permutation i draws from RandomState(i) (pyls/base.py:705-708), in order, for any shard."""
+    groups, n_cond, n_split = [9, 7], 2, 6
+    want = rsmp.gen_splits_seeded(groups, n_cond, n_split, np.arange(40), rows=True)
+    for lo, hi, block in ((0, 40, 32), (5, 23, 4), (39, 40, 32)):
+        st = rsmp.MaskStream(groups, n_cond, n_split, lo, hi, block=block)
+        got, pos = [], lo
+        for a, b, m in st:
+            assert a == pos and b <= hi and m.dtype == np.uint8 and m.shape == (b - a, n_split, 32)
+            got.append(m)
+            pos = b
+        st.close()
+        assert pos == hi
+        np.testing.assert_array_equal(np.concatenate(got), want[lo:hi])
+    # caller-supplied masks (the tests' way in): sliced, transposed to rows
+    given = want.transpose(0, 2, 1).astype(bool)                        # (n_perm, S, n_split)
+    st = rsmp.MaskStream(groups, n_cond, n_split, 3, 11, block=5, given=given)
+    np.testing.assert_array_equal(np.concatenate([m for _, _, m in st]), want[3:11])
+    st.close()
+    # an exception on the producer surfaces in the consumer
+    bad = rsmp.MaskStream(groups, n_cond, -3, 0, 4)
+    with pytest.raises(Exception):
+        list(bad)
+    bad.close()

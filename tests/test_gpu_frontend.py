@@ -282,3 +282,27 @@ def test_default_engine_is_reused_and_rebinding_changes_nothing():
     assert np.array_equal(a.permres.perm_singval, b.permres.perm_singval)
     pls.release_default_engine()
     assert engine.default_engine() is not eng
+
+
+@pytest.mark.parametrize('n_perm,n_boot', [(0, 0), (7, 0), (0, 7)])
+def test_calls_without_permutations_or_bootstraps(n_perm, n_boot):
+    """Only the legs that were asked for run and only their results exist (BasePLS.run_pls, base.py:366-397):
+    the device-resident finish must cope with an absent null / absent bootstrap block."""
+    import pypyls_amd as pls
+    rs = np.random.RandomState(2)
+    X, Y = rs.randn(36, 400), rs.randn(36, 3)
+    for res, method in ((pls.behavioral_pls(X, Y, n_perm=n_perm, n_boot=n_boot, test_split=0, seed=1, verbose=False),
+                         'behavioral'),
+                        (pls.meancentered_pls(X, groups=[9, 9], n_cond=2, n_perm=n_perm, n_boot=n_boot, seed=1,
+                                              verbose=False), 'meancentered')):
+        want = ref.run_plsc(X, Y if method == 'behavioral' else None, method=method,
+                            groups=[36] if method == 'behavioral' else [9, 9], n_cond=1 if method == 'behavioral' else 2)
+        keep = live_lvs(want['singvals'])
+        assert_close(res.singvals[keep], want['singvals'][keep], RTOL, what='singvals')
+        assert_close(np.abs(res.x_weights[:, keep]), np.abs(want['x_weights'][:, keep]), RTOL, what='x_weights')
+        assert ('perm_singval' in res.permres) == (n_perm > 0)
+        assert ('x_weights_normed' in res.bootres) == (n_boot > 0)
+        if n_perm:
+            assert res.permres.perm_singval.shape == (len(res.singvals), n_perm)
+        if n_boot:
+            assert res.bootres.x_weights_normed.shape == res.x_weights.shape

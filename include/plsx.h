@@ -252,7 +252,9 @@ int plsx_boot_rel(plsx_ctx* ctx, const double* d_orig, const double* d_usum,
  * numpy.percentile, default 'linear' interpolation).  d_data (nseries, n)
  * contiguous series; the two quantiles are given by their virtual index
  * (i, g) = (floor((n-1) q), fractional part) as numpy computes them.
- * d_lo, d_hi (nseries,) out.  n <= 16384. */
+ * d_lo, d_hi (nseries,) out.  n <= 16384.  Long series whose two ranks lie in the tails (a 95 % interval of 10 000
+ * bootstraps) are settled by selection -- pivots from a sorted sample, one counting pass, a sort of the <= 2048
+ * values beyond the pivots -- with the full LDS sort as the fallback; both are exact order statistics. */
 int plsx_percentile_ci(plsx_ctx* ctx, const double* d_data, long long nseries, int n, int i_lo, double g_lo,
                        int i_hi, double g_hi, double* d_lo, double* d_hi, void* stream);
 
@@ -316,7 +318,8 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
  *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
  *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "urot_m3", "epi2_nw4", "simpls_jacobi"
- *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "trace_alloc";
+ *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "percentile_sort" (plsx_percentile_ci: always the
+ *     full sort instead of the tail selection), "trace_alloc";
  *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
  *     size the super-batch scratch for n once instead of per call (0 = per call)
  * plsx_option_name(i) enumerates the keys (NULL past the last).  No reference counterpart.

@@ -34,13 +34,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort"};
 
 struct plsx_ctx {
     int device = 0;
@@ -86,6 +86,7 @@ struct plsx_ctx {
     int npg_w = 0;                                      // resamples per group of the W operand (MT * 16 / L)
     Buf gws;                                            // small-solver workspace (T' > PLSX_JACOBI_TP)
     Buf status;                                         // device words: [0] numerical status bits of the small solvers, [1] refined, [2] graded but unrefined resamples
+    Buf pflags;                                         // plsx_percentile_ci: series the selection kernel left to the full sort
     Buf flipws;                                         // plsx_svd_flip: column maxima, their rows, the signs
     Buf refV, refLam, refK0, refPart, refPartP, refH;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
     int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
@@ -1466,7 +1467,7 @@ try {
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
-                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws})
+                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws, &ctx->pflags})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -2802,8 +2803,20 @@ try {
     HIPCHK(hipSetDevice(ctx->device));
     const size_t lds = (size_t)p2 * 8;
     HIPCHK(set_lds(k_percentile2, lds));
-    hipLaunchKernelGGL(k_percentile2, dim3((unsigned)nseries), dim3(256), lds, static_cast<hipStream_t>(stream),
-                       d_data, n, p2, i_lo, g_lo, i_hi, g_hi, d_lo, d_hi);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int* only = nullptr;
+    // long series with both ranks in the tails (the 95 % interval of 10 000 bootstraps): selection instead of a
+    // full sort; the few series it cannot settle (pathological pivots) fall through to the sort below
+    if (n >= 4096 && std::min(i_lo + 1, n - 1) + 1 <= PSEL_CAP / 2 && n - i_hi <= PSEL_CAP / 2 &&
+        !ctx->opt[OPT_PERCENTILE_SORT]) {
+        if (int e = ensure(ctx, ctx->pflags, (size_t)nseries * sizeof(int))) return e;
+        hipLaunchKernelGGL(k_percentile_sel, dim3((unsigned)nseries), dim3(256), 0, st, d_data, n, i_lo, g_lo, i_hi,
+                           g_hi, d_lo, d_hi, ptr<int>(ctx->pflags));
+        LAUNCHCHK();
+        only = ptr<int>(ctx->pflags);
+    }
+    hipLaunchKernelGGL(k_percentile2, dim3((unsigned)nseries), dim3(256), lds, st,
+                       d_data, n, p2, i_lo, g_lo, i_hi, g_hi, d_lo, d_hi, only);
     LAUNCHCHK();
     return PLSX_OK;
 } PLSX_CATCH(ctx)

@@ -3372,8 +3372,10 @@ void k_cv_final(const double* __restrict__ Q /* [m*J][Tp][S] */, const double* _
 __global__ __launch_bounds__(256)
 void k_percentile2(const double* __restrict__ data, int n, int npow2,
                    int i_lo, double g_lo, int i_hi, double g_hi,
-                   double* __restrict__ out_lo, double* __restrict__ out_hi)
+                   double* __restrict__ out_lo, double* __restrict__ out_hi, const int* __restrict__ only = nullptr)
 {
+    // only != nullptr: the series the selection kernel (k_percentile_sel) could not settle; the others return
+    if (only && !only[blockIdx.x]) return;
     extern __shared__ double sv[];
     __shared__ int s_nan;
     const int tid = threadIdx.x;
@@ -3411,6 +3413,114 @@ void k_percentile2(const double* __restrict__ data, int n, int npow2,
         asm volatile("" : "+v"(prod));
         double r = (g >= 0.5) ? b - prod : a + prod;
         if (s_nan) r = __builtin_nan("");
+        (tid ? out_hi : out_lo)[blockIdx.x] = r;
+    }
+}
+
+// Bitonic sort (ascending) of P doubles in LDS by the 256 threads of a block; P a power of two.
+__device__ __forceinline__ void lds_bitonic(double* v, int P, int tid)
+{
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                const int q = i ^ j;
+                if (q > i) {
+                    const double a = v[i], b = v[q];
+                    const bool up = ((i & k) == 0);
+                    if ((a > b) == up) { v[i] = b; v[q] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// The two order statistics a percentile interval needs, WITHOUT sorting the series (round 4: the full bitonic
+// sort of 16384 padded values in 128 KB of LDS -- one block per CU -- was 7 ms for the 2500 series of 10 000
+// bootstraps at c4, the largest piece of the front-end's finish).  A 95 % interval reads ranks near 2.5 % and
+// 97.5 %: a pivot from a sorted pseudo-random sample of 1024 values brackets each tail, one pass counts and
+// collects the values strictly beyond the pivots (and counts the ties with them), and only those <= 2048
+// values are sorted.  Exact: the value of ascending rank r is tail_sorted[r] when r < #{v < pivot}, the pivot
+// itself when r < #{v < pivot} + #{v == pivot} (heavy ties, constant series), and a pivot that brackets too
+// little or too much is moved (four tries) before the series is handed to the full sort (`need_full`).
+// Interpolation exactly as k_percentile2 (numpy's _lerp).  One block per series.
+#define PSEL_CAP 2048
+#define PSEL_SAMPLE 1024
+__global__ __launch_bounds__(256)
+void k_percentile_sel(const double* __restrict__ data, int n, int i_lo, double g_lo, int i_hi, double g_hi,
+                      double* __restrict__ out_lo, double* __restrict__ out_hi, int* __restrict__ need_full)
+{
+    __shared__ double smp[PSEL_SAMPLE];
+    __shared__ double lowb[PSEL_CAP], highb[PSEL_CAP];
+    __shared__ int s_cnt[5];                               // lt, eq_lo, gt, eq_hi, nan
+    const int tid = threadIdx.x;
+    const double* src = data + (size_t)blockIdx.x * n;
+    for (int j = tid; j < PSEL_SAMPLE; j += 256) {
+        const unsigned pos = (unsigned)(((unsigned long long)j * 2654435761ull + 40503ull) % (unsigned long long)n);
+        double v = src[pos];
+        if (v != v) v = __builtin_inf();
+        smp[j] = v;
+    }
+    __syncthreads();
+    lds_bitonic(smp, PSEL_SAMPLE, tid);
+    const int rl1 = min(i_lo + 1, n - 1);                  // largest ascending rank needed on the low side
+    const int qh = n - 1 - i_hi;                           // largest descending position needed on the high side
+    int sl = min(PSEL_SAMPLE - 1, (int)(((long long)(rl1 + 1) * PSEL_SAMPLE * 13) / ((long long)n * 10)) + 24);
+    int sh = max(0, PSEL_SAMPLE - 1 - ((int)(((long long)(qh + 1) * PSEL_SAMPLE * 13) / ((long long)n * 10)) + 24));
+    double pl = 0.0, ph = 0.0;
+    int lt = 0, eql = 0, gt = 0, eqh = 0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+        pl = smp[sl]; ph = smp[sh];
+        if (tid < 5) s_cnt[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            double v = src[i];
+            if (v != v) { s_cnt[4] = 1; v = __builtin_inf(); }
+            if (v < pl) { const int k = atomicAdd(&s_cnt[0], 1); if (k < PSEL_CAP) lowb[k] = v; }
+            else if (v == pl) atomicAdd(&s_cnt[1], 1);
+            if (v > ph) { const int k = atomicAdd(&s_cnt[2], 1); if (k < PSEL_CAP) highb[k] = v; }
+            else if (v == ph) atomicAdd(&s_cnt[3], 1);
+        }
+        __syncthreads();
+        lt = s_cnt[0]; eql = s_cnt[1]; gt = s_cnt[2]; eqh = s_cnt[3];
+        const bool ok_lo = lt + eql > rl1 && lt <= PSEL_CAP, ok_hi = gt + eqh > qh && gt <= PSEL_CAP;
+        ok = ok_lo && ok_hi;
+        if (!ok_lo) sl = (lt + eql <= rl1) ? min(PSEL_SAMPLE - 1, 2 * sl + 8) : sl / 2;
+        if (!ok_hi) {
+            const int th = PSEL_SAMPLE - 1 - sh;           // sample index counted from the top
+            sh = PSEL_SAMPLE - 1 - ((gt + eqh <= qh) ? min(PSEL_SAMPLE - 1, 2 * th + 8) : th / 2);
+        }
+        __syncthreads();
+    }
+    if (!ok) {
+        if (tid == 0) need_full[blockIdx.x] = 1;
+        return;
+    }
+    if (tid == 0) need_full[blockIdx.x] = 0;
+    int pl2 = 1, ph2 = 1;
+    while (pl2 < lt) pl2 <<= 1;
+    while (ph2 < gt) ph2 <<= 1;
+    for (int i = lt + tid; i < pl2; i += 256) lowb[i] = __builtin_inf();
+    for (int i = gt + tid; i < ph2; i += 256) highb[i] = __builtin_inf();
+    __syncthreads();
+    lds_bitonic(lowb, pl2, tid);
+    lds_bitonic(highb, ph2, tid);
+    if (tid < 2) {
+        const int i0 = tid ? i_hi : i_lo;
+        const double g = tid ? g_hi : g_lo;
+        double ab[2];
+        for (int u = 0; u < 2; ++u) {
+            const int r = min(i0 + u, n - 1);
+            if (tid == 0) ab[u] = r < lt ? lowb[r] : pl;                      // (lt + eql > rl1 >= r)
+            else { const int q = n - 1 - r; ab[u] = q < gt ? highb[gt - 1 - q] : ph; }
+        }
+        const double a = ab[0], b = ab[1];
+        double diff = b - a;
+        // numpy rounds the product and the sum separately: keep hipcc from contracting them into one fma
+        double prod = (g >= 0.5) ? diff * (1.0 - g) : diff * g;
+        asm volatile("" : "+v"(prod));
+        double r = (g >= 0.5) ? b - prod : a + prod;
+        if (s_cnt[4]) r = __builtin_nan("");
         (tid ? out_hi : out_lo)[blockIdx.x] = r;
     }
 }

@@ -178,6 +178,35 @@ def test_percentile_ci_matches_numpy(n):
     assert np.isnan(lo[0, 0]) and np.isnan(hi[0, 0]) and np.isfinite(lo[1, 1])
 
 
+def test_percentile_selection_equals_full_sort_and_numpy(monkeypatch):
+    """Long series with both ranks in the tails are settled by selection (k_percentile_sel: pivots from a sorted
+    sample, one counting pass, a sort of the values beyond the pivots) instead of a full sort -- the same order
+    statistics bit for bit: random, heavily tied, constant, sorted, periodic, heavy-tailed, with infinities and
+    NaN, at the lengths and intervals the front-ends use and at the edge of the selection's range."""
+    rs = np.random.RandomState(7)
+    for n in (4096, 5000, 10000, 16384):
+        rows = [rs.randn(n), np.round(rs.randn(n), 1), np.full(n, 3.25), np.sort(rs.randn(n)),
+                np.sort(rs.randn(n))[::-1].copy(), np.tile(rs.randn(8), n // 8 + 1)[:n], rs.standard_cauchy(n),
+                np.where(rs.rand(n) < 0.97, 0.0, rs.randn(n)), np.arange(n, dtype=float) % 3,
+                np.concatenate([np.full(n - 5, 1.0), [np.inf, -np.inf, 2.0, -2.0, 0.5]])]
+        boot = np.stack(rows)
+        for ci in (95, 99, 90, 80):
+            monkeypatch.delenv('PLSX_PERCENTILE_SORT', raising=False)
+            lo, hi = _engine().percentile_ci(boot, ci=ci)
+            monkeypatch.setenv('PLSX_PERCENTILE_SORT', '1')
+            lo2, hi2 = _engine().percentile_ci(boot, ci=ci)
+            low = (100 - ci) / 2
+            wlo, whi = np.percentile(boot, [low, 100 - low], axis=-1)
+            for a, b, c, what in ((lo, lo2, wlo, 'lower'), (hi, hi2, whi, 'upper')):
+                np.testing.assert_array_equal(a, b, err_msg='selection vs sort, {} n={} ci={}'.format(what, n, ci))
+                np.testing.assert_array_equal(a, c, err_msg='selection vs numpy, {} n={} ci={}'.format(what, n, ci))
+    monkeypatch.delenv('PLSX_PERCENTILE_SORT', raising=False)
+    boot = rs.randn(4, 10000)
+    boot[2, 17] = np.nan
+    lo, hi = _engine().percentile_ci(boot)
+    assert np.isnan(lo[2]) and np.isnan(hi[2]) and np.isfinite(lo[[0, 1, 3]]).all()
+
+
 def test_nonfinite_input_rejected():
     import pypyls_amd as pls
     rs = np.random.RandomState(0)

@@ -186,7 +186,9 @@ class PLSC(object):
             eng.perm_into(self.perm_idx[i], self.out_sv, rotate=True)
             if ev:
                 ev[1].record()
+            eng.boot_begin(self.boots)                  # the step's bootstraps are one series (plsx_boot_begin)
             eng.boot_into(self.boot_idx[i], self.usum, self.usq, self.dist_out)
+            eng.boot_finish(self.usum, self.usq)
         else:
             self._strong_step(i)
             if ev:
@@ -221,11 +223,14 @@ class PLSC(object):
             for a, b in ps.chunks(lo, hi):
                 eng.perm_into(eng.rows_tensor(ps.rows[a:b]), self.out_sv[a - lo:b - lo], rotate=True)
             off = 0
-            for lo, hi in parallel.shard_chunks(self.boots, rank, world):      # chunk-cyclic share
+            bchunks = parallel.shard_chunks(self.boots, rank, world)           # chunk-cyclic share
+            eng.boot_begin(sum(hi - lo for lo, hi in bchunks))
+            for lo, hi in bchunks:
                 for a, b in bs.chunks(lo, hi):
                     eng.boot_into(eng.rows_tensor(bs.rows[a:b]), self.usum, self.usq,
                                   self.dist_out[off + a - lo:off + b - lo])
                 off += hi - lo
+            eng.boot_finish(self.usum, self.usq)
         finally:
             draws.thread.join()
         if draws.error is not None:
@@ -419,7 +424,9 @@ class Simpls(object):
         self.eng.simpls_perm_into(self.perm_idx[i], self.out)
         if ev:
             ev[1].record()
+        self.eng.boot_begin(self.boots)                 # the step's bootstraps are one series (plsx_boot_begin)
         self.eng.simpls_boot_into(self.boot_idx[i], self.usum, self.usq, self.yl)
+        self.eng.boot_finish(self.usum, self.usq)
         if ev:
             ev[2].record()
         self.result = parallel.gather_device([(self.out, self.perms), (self.yl, self.boots)],

@@ -166,6 +166,29 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
                     double* d_usum, double* d_usq, double* d_distrib, void* stream);
 
 /*
+ * A SERIES of bootstrap batches that accumulate into the same (d_usum, d_usq) -- the whole `for i in range(n_boot)`
+ * of BasePLS.bootstrap (pyls/base.py:490-511) on this rank -- may be announced, so that the library can move the
+ * pass over the B features out of the loop:
+ *   plsx_boot_begin(ctx, n_total)   before the first batch; n_total = bootstraps this context will see until
+ *                                   plsx_boot_finish
+ *   plsx_boot_batch / plsx_simpls_boot_batch ...  as ever
+ *   plsx_boot_finish(ctx, d_usum, d_usq)   after the last batch, before d_usum / d_usq are read: adds what the
+ *                                   series still owes them; a no-op when every batch already accumulated in place
+ * Where the rotated bootstrap weights are linear in the bound, unscaled feature matrix -- U_b = Xc^T V_b with V_b
+ * (S x L) known in dual space: mean-centred PLS and covariance-mode behavioral PLS (single-pass route), SIMPLS --
+ *   sum_b U_b = Xc^T (sum_b V_b),     sum_b U_b[j,l]^2 = x_j^T C_l x_j,     C_l = sum_b v_bl v_bl^T   (S x S)
+ * so a series of n_total >~ 1.25 S bootstraps accumulates C_l (a batched S x S product per batch) and passes the
+ * features ONCE, in plsx_boot_finish (2 S^2 L B flop), instead of once per bootstrap (2 S L B n_total): the same
+ * sums to rounding.  Between begin and finish of such a series the batches do NOT touch d_usum / d_usq
+ * (plsx_boot_route() = 1); d_distrib / d_yload are written per batch as ever.  Without plsx_boot_begin, for short
+ * series, correlation-mode behavioral PLS (the features are re-scaled per bootstrap) and with option "quad_sums" = -1
+ * every batch accumulates in place (route 0).  plsx_set_original / plsx_set_data end an open series.
+ */
+int plsx_boot_begin(plsx_ctx* ctx, long long n_total, void* stream);
+int plsx_boot_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, void* stream);
+int plsx_boot_route(const plsx_ctx* ctx);
+
+/*
  * Split-half reliability -- BasePLS.split_half (pyls/base.py:714-770) for np
  * data arrangements (the original data and/or permuted data, base.py:705-708)
  * with ns split masks each.  For every arrangement the library decomposes
@@ -318,7 +341,8 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
  *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
  *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "urot_m3", "epi2_nw4", "simpls_jacobi"
- *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "percentile_sort" (plsx_percentile_ci: always the
+ *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "quad_sums" (plsx_boot_begin: 1 = the quadratic-form route
+ *     whenever it applies, -1 = never), "percentile_sort" (plsx_percentile_ci: always the
  *     full sort instead of the tail selection), "trace_alloc";
  *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
  *     size the super-batch scratch for n once instead of per call (0 = per call)

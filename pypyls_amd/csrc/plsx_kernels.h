@@ -375,6 +375,35 @@ void k_build_W(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
         }
 }
 
+// The same W_r = A_r^T M_r, dense: Vd[r][l * S + i] (the quadratic-form route of the bootstrap sums, k_quad_* below).
+__global__ __launch_bounds__(256)
+void k_build_Vd(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
+                const double* __restrict__ Mfrag, int nks_t, int LT, double* __restrict__ Vd)
+{
+    extern __shared__ __attribute__((aligned(16))) double sM[];      // [Tp][L]
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const double* M = Mfrag + (size_t)r * nks_t * LT * 64;
+    for (int idx = tid; idx < Tp * L; idx += blockDim.x) {
+        const int t = idx / L, l = idx - t * L;
+        sM[idx] = M[mfrag_index(t, l, nks_t, LT)];
+    }
+    __syncthreads();
+    const double* A = Adense + (size_t)r * Tp * ld;
+    double* out = Vd + (size_t)r * L * S;
+    for (int i = tid; i < S; i += blockDim.x)
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            double w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < Tp; ++t) {
+                const double a = A[(size_t)t * ld + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] += a * sM[t * L + min(l0 + u, L - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (l0 + u < L) out[(size_t)(l0 + u) * S + i] = w[u];
+        }
+}
+
 // Column sums of Xc and Xc^2 per cell: S1[j][b], S2[j][b] (full-sample moments
 // the fused split-half epilogue subtracts the first half's from).
 __global__ void k_cell_moments(const double* __restrict__ Xc, int ldx, int B, int J,
@@ -824,6 +853,32 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
             for (int i = 0; i < 4; ++i)
                 if (orow[i] >= 0 && orow[i] < rows_valid) Rg[(size_t)orow[i] * ldr] = acc[m][i] * sc[i];
         }
+        return;
+    }
+    if constexpr (EPI == 7) {
+        // quadratic form (k_quad_*): the group's rows are rows s0 .. s0 + MT * 16 - 1 of ONE symmetric S x S matrix
+        // C_l (group g: l = g / gpl, s0 = (g % gpl) * MT * 16; gpl = se.npairs, S = se.accB), acc = (C_l X)[s][col];
+        // the block adds X[s][col] * acc over its rows -- its share of x_col^T C_l x_col -- and writes ONE value per
+        // column: se.acc_sum[grp][ldr].  The X rows are the ones the main loop just streamed (L2).
+        if (NW > 4 && col >= ldr) return;
+        const int s0 = (grp % se.npairs) * (MT * 16);
+        const int Srows = se.accB;
+        const double* Xc = X + col;
+        double part = 0.0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            double xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sr = s0 + m * 16 + kq + 4 * i;
+                xv[i] = sr < Srows ? Xc[(size_t)sr * ldx] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part += xv[i] * acc[m][i];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (kq == 0) se.acc_sum[(size_t)grp * ldr + col] = part;
         return;
     }
     if constexpr (EPI == 2) {
@@ -1827,7 +1882,8 @@ void k_gram4(const double* __restrict__ R, long long strideR, int ldr, int Tp,
 // C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
 __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
                               int mtiles, int ntiles, int which,
-                              double* __restrict__ C, long long strideC, int ldc, int M, int N, int sym)
+                              double* __restrict__ C, long long strideC, int ldc, int M, int N, int sym,
+                              int accumulate = 0)
 {
     const int b = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1841,7 +1897,8 @@ __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int b
     double s = 0.0;
     for (int c = 0; c < nchunk; ++c)
         s += part[(((size_t)c * batch + b) * 2) * tiles * 4096 + off];
-    C[(size_t)b * strideC + (size_t)mo * ldc + no] = s;
+    double* dst = &C[(size_t)b * strideC + (size_t)mo * ldc + no];
+    *dst = accumulate ? *dst + s : s;
 }
 
 // ---------------------------------------------------------------------------
@@ -2899,6 +2956,84 @@ __global__ void k_add_splits(const double* __restrict__ psum, const double* __re
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
+// Quadratic-form route of the bootstrap sums (fixed feature matrix: U_b = X^T V_b, V_b S x L in dual space)
+//   sum_b U_b          = X^T (sum_b V_b)
+//   sum_b U_b[j,l]^2   = x_j^T C_l x_j,   C_l = sum_b v_{b,l} v_{b,l}^T   (S x S, accumulated by k_nt_gemm)
+// so the feature pass runs ONCE per analysis (L products C_l X through k_xprod EPI 7) instead of once per
+// bootstrap: 2 S^2 L B flop against 2 S L B n_boot.
+// ---------------------------------------------------------------------------
+// Vsum[row] += sum_b Vt[row][b]: one wave per row, fixed order.
+__global__ __launch_bounds__(256)
+void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, double* __restrict__ Vsum)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const double* p = Vt + (size_t)row * ldv;
+    double s = 0.0;
+    for (int b = lane; b < m; b += 64) s += p[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) Vsum[row] += s;
+}
+
+// Rows s0 .. of C_l (S x S, row-major) into the fragment-ordered A operand of group g = l * gpl + part.
+__global__ __launch_bounds__(256)
+void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride)
+{
+    const int g = blockIdx.y, l = g / gpl, s0 = (g % gpl) * MT * 16;
+    const int rows = min(MT * 16, S - s0);
+    const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S;
+    double* out = Afrag + (size_t)g * group_stride;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)rows * S;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / S), k = (int)(idx - (long long)r * S);
+        out[afrag_off(r, k, MT)] = Cl[idx];
+    }
+}
+
+// usq[j][l0 + l] += sum over the gpl groups of l of part[(l * gpl + g)][j], l < nl
+__global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp, int B, int nl, int L, int l0,
+                              double* __restrict__ usq)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * nl) return;
+    const int j = (int)(i / nl), l = (int)(i - (long long)j * nl);
+    double s = 0.0;
+    for (int g = 0; g < gpl; ++g) s += part[(size_t)(l * gpl + g) * ldp + j];
+    usq[(size_t)j * L + l0 + l] += s;
+}
+
+// usum[j][l] += sum_s X[s][j] Vsum[l][s]; thread = feature j, blockIdx.y = chunk of 8 l's.
+__global__ __launch_bounds__(256)
+void k_xt_vsum(const double* __restrict__ X, int ldx, int S, int B, const double* __restrict__ Vsum, int L,
+               double* __restrict__ usum)
+{
+    __shared__ double sV[8][64];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, l0 = blockIdx.y * 8;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int sbeg = 0; sbeg < S; sbeg += 64) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * 64; i += blockDim.x) {
+            const int u = i >> 6, s = sbeg + (i & 63);
+            sV[u][i & 63] = (l0 + u < L && s < S) ? Vsum[(size_t)(l0 + u) * S + s] : 0.0;
+        }
+        __syncthreads();
+        if (j < B) {
+            const int n = min(64, S - sbeg);
+            for (int s = 0; s < n; ++s) {
+                const double x = X[(size_t)(sbeg + s) * ldx + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += x * sV[u][s];
+            }
+        }
+    }
+    if (j < B)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (l0 + u < L) usum[(size_t)j * L + l0 + u] += acc[u];
+}
 
 // dst (C x Rr) = src (Rr x C)^T ; tiled through LDS.
 __global__ void k_transpose(const double* __restrict__ src, int rows, int cols, int lds_,

@@ -96,6 +96,7 @@ struct SdArgs {
     double* yload;              // [nres][T][k]  Y[ys]^T (X[xs] W), signs not yet aligned
     double* cvec;               // [nres][T][k]  right singular vectors c_c (sign rule when B <= T)
     double* Afrag;              // dual weights scattered into k_xprod's A operand (or nullptr)
+    double* Vd;                 // or: scattered dense, [nres][k][S] (zeroed by the caller; quadratic-form route), or nullptr
     const double* Qs;           // [S][k] Xc . W0c^T (centred original weights): bootstrap sign alignment in dual space, or nullptr
     size_t group_stride;
     GroupLayout lay;
@@ -972,6 +973,13 @@ void k_sd_final(SdArgs a)
         for (int idx = lane; idx < S * k; idx += 64) {
             const int c = idx / S, p = idx - c * S;
             if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), flip[c] * WD[(size_t)c * S + p]);
+        }
+    }
+    if (a.Vd) {
+        double* V = a.Vd + (size_t)r * k * S;
+        for (int idx = lane; idx < S * k; idx += 64) {
+            const int c = idx / S, p = idx - c * S;
+            if (xs[p] >= 0) atomicAdd(V + (size_t)c * S + xs[p], flip[c] * WD[(size_t)c * S + p]);
         }
     }
 }

@@ -59,6 +59,9 @@ def _load():
         'plsx_perm_batch_y': ([vp, vp, i32, i32, vp, vp], i32),
         'plsx_crossval_batch': ([vp, vp, i32, vp, vp, vp], i32),
         'plsx_boot_batch': ([vp, vp, i32, vp, vp, vp, vp], i32),
+        'plsx_boot_begin': ([vp, ctypes.c_longlong, vp], i32),
+        'plsx_boot_finish': ([vp, vp, vp, vp], i32),
+        'plsx_boot_route': ([vp], i32),
         'plsx_split_half_batch': ([vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_split_half_batch_y': ([vp, vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
@@ -103,7 +106,7 @@ def exported_symbols():
     names = ['plsx_version', 'plsx_max_tprime', 'plsx_ctx_create', 'plsx_ctx_destroy',
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
-             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_split_half_batch', 'plsx_split_half_batch_y',
+             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_boot_begin', 'plsx_boot_finish', 'plsx_boot_route', 'plsx_split_half_batch', 'plsx_split_half_batch_y',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_kernel_timing',
              'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
@@ -455,8 +458,10 @@ class Engine(object):
         if usum is None:
             usum, usq = self._zeros((self.B, self.L)), self._zeros((self.B, self.L))
         dist = self._empty((n, self.Tp, self.L))
+        self.boot_begin(n)                       # a series of one call
         self._check(self.lib.plsx_boot_batch(self.ctx, idx.data_ptr(), n, usum.data_ptr(),
                                              usq.data_ptr(), dist.data_ptr(), self._stream()))
+        self.boot_finish(usum, usq)
         self.sync()
         return usum, usq, np.ascontiguousarray(dist.cpu().numpy().transpose(1, 2, 0))
 
@@ -566,9 +571,11 @@ class Engine(object):
             if tuple(dys.shape) != (n, self.S, self.T):
                 raise ValueError('ystack must have shape ({}, {}, {})'.format(n, self.S, self.T))
         yl = self._empty((n, self.T, self.k))
+        self.boot_begin(n)                       # a series of one call
         self._check(self.lib.plsx_simpls_boot_batch(
             self.ctx, idx.data_ptr(), None if dys is None else dys.data_ptr(), n, usum.data_ptr(),
             usq.data_ptr(), yl.data_ptr(), self._stream()))
+        self.boot_finish(usum, usq)
         self.sync()
         return usum, usq, np.ascontiguousarray(yl.cpu().numpy().transpose(1, 2, 0))
 
@@ -586,6 +593,17 @@ class Engine(object):
         """idx_dev (n, S) int32 device tensor, out_dev (n, L) fp64 device tensor."""
         self._check(self.lib.plsx_perm_batch(self.ctx, idx_dev.data_ptr(), idx_dev.shape[0],
                                              1 if rotate else 0, out_dev.data_ptr(), self._stream()))
+
+    def boot_begin(self, n_total):
+        """Announce a series of n_total bootstraps accumulating into one (usum, usq) (include/plsx.h,
+        plsx_boot_begin).  Returns 1 when the library moved the pass over the features out of the loop (the
+        quadratic-form route: the batches then leave usum / usq alone until boot_finish), 0 otherwise."""
+        self._check(self.lib.plsx_boot_begin(self.ctx, int(n_total), self._stream()))
+        return int(self.lib.plsx_boot_route(self.ctx))
+
+    def boot_finish(self, usum, usq):
+        """Close the series: adds what it still owes usum / usq (a no-op on the in-place route)."""
+        self._check(self.lib.plsx_boot_finish(self.ctx, usum.data_ptr(), usq.data_ptr(), self._stream()))
 
     def boot_into(self, idx_dev, usum, usq, dist_dev):
         """idx_dev (n, S) int32; usum / usq (B, L) accumulated in place; dist_dev

@@ -252,11 +252,15 @@ class _PLSCRun(object):
             usum, usq = eng._zeros((eng.B, L)), eng._zeros((eng.B, L))
             d_dist = eng._zeros((sum(hi - lo for lo, hi in bchunks), eng.Tp, L))
             off = 0
+            # the series of this rank's bootstraps: where the weights are linear in the (unscaled) features the
+            # library accumulates S x S moments per batch and passes the features once, in boot_finish
+            eng.boot_begin(sum(hi - lo for lo, hi in bchunks))
             for blo, bhi in bchunks:
                 for a, b in bstream.chunks(blo, bhi, first=first):
                     eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                   d_dist[off + a - blo:off + b - blo])
                 off += bhi - blo
+            eng.boot_finish(usum, usq)
         # host work that needs no device result runs while the device is busy: page-locked landing zones of
         # the results (56 us per MB to map), the index arrays in the reference's layout and dtype ((S, n)
         # C-contiguous int64), the host-sized scores of the original data

@@ -229,6 +229,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
         d_yl = eng._zeros((sum(hi - lo for lo, hi in bchunks), T, k))
         off = 0
+        eng.boot_begin(sum(hi - lo for lo, hi in bchunks))     # (plsx_boot_begin: the feature pass may move to boot_finish)
         for lo, hi in bchunks:
             for a, b in bstream.chunks(lo, hi, first=256, grow=4 if third is None else 1,
                                        limit=None if third is None else 256):
@@ -243,6 +244,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
                 eng.simpls_boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                      d_yl[off + a - lo:off + b - lo], ystack=ystack)
             off += hi - lo
+        eng.boot_finish(usum, usq)
     permsamp = bootsamp = None
     if pstream is not None:
         permsamp = np.asarray(permsamples) if permsamples is not None else pstream.samples

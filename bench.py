@@ -105,6 +105,18 @@ def self_launch(args):
 # workloads
 # ---------------------------------------------------------------------------
 
+def quad_closing_work(S, mt, gpl):
+    """Closing pass of a bootstrap series on the quadratic-form route (plsx_boot_finish): per latent variable and
+    feature column the kernel multiplies gpl row blocks of mt tiles of C_l (S x S, symmetric), each from its own first
+    row on.  Returns (flop it NEEDS per LV and column = the upper triangle incl. the diagonal, 2 x S (S + 1) / 2;
+    flop it ISSUES per LV and column)."""
+    issued = 0.0
+    for p in range(gpl):
+        s0 = p * mt * 16
+        issued += 2.0 * (mt * 16) * max(4 * ((S + 3) // 4) - s0, 0)
+    return float(S) * (S + 1), issued
+
+
 class PLSC(object):
     """behavioral / mean-centred PLS: permutations + bootstraps."""
 
@@ -271,6 +283,8 @@ class PLSC(object):
         2 S T' B flop (first term of SURVEY 8d W_F) and 8 S (B + T') bytes (W_B)."""
         S, B, Tp = self.S, self.B, self.Tp
         tm = self.eng.last_timing()
+        if tm.get('quad_series', 0) > 0:
+            return self._roofline_quad(kt, steps, tm)
         launches = max(int(tm.get('xprod_launches', 0)), 1)
         avg_ms = tm.get('xprod_ms', 0.0) / launches
         units = tm.get('xprod_resamples', 0) / launches
@@ -326,12 +340,62 @@ class PLSC(object):
                                 'sustain'.format(rows)})
         return out
 
+    def _roofline_quad(self, kt, steps, tm):
+        """Unscaled modes on the quadratic-form route: per bootstrap only dual-space products (S x S kernel,
+        k_nt_gemm), per SERIES one pass over the features (k_xprod EPI 7: x_j^T C_l x_j).  The dominant kernel by
+        time is reported with its own work; the closing pass beside it."""
+        S, B, Tp, L = self.S, self.B, self.Tp, self.L
+        self.row_fraction = 1.0
+        self.quad_route = True
+        mt, gpl = int(tm.get('quad_m_tiles', 24)), int(tm.get('quad_blocks_per_lv', 1))
+        need, issued = quad_closing_work(S, mt, gpl)
+        x_ms, x_n = kt.get('k_xprod', (0.0, 0))
+        nt_ms, nt_n = kt.get('k_nt_gemm', (0.0, 0))
+        series = max(int(tm.get('quad_series', 1)), 1)
+        x_need = need * L * B * series / (x_ms * 1e-3) / 1e12 if x_ms > 0 else 0.0
+        x_iss = issued * L * B * series / (x_ms * 1e-3) / 1e12 if x_ms > 0 else 0.0
+        nt_tf = tm.get('nt_flops', 0.0) / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
+        dom = max(kt, key=lambda n: kt[n][0]) if kt else 'k_nt_gemm'
+        closing = {'kernel': 'k_xprod<{},8,1,0,7> (closing pass of a bootstrap series: x_j^T C_l x_j, {} row blocks per LV)'.format(mt, gpl),
+                   'ms_per_series': x_ms / series, 'achieved': x_need, 'frac': x_need / PEAK_FP64_MFMA_TFLOPS,
+                   'issued_tflops': x_iss, 'frac_issued': x_iss / PEAK_FP64_MFMA_TFLOPS,
+                   'work': 'S (S + 1) L B = {:.3e} flop per series (upper triangle of L symmetric S x S forms per column), '
+                           '{:.3e} issued (row blocks from their own first row on)'.format(need * L * B, issued * L * B)}
+        direct = 2.0 * S * L * B * self.boots          # what the per-bootstrap feature pass of one step multiplies
+        if dom == 'k_xprod':
+            out = dict(closing)
+            out.update({'bound': 'mfma', 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'avg_launch_ms': x_ms / max(x_n, 1),
+                        'launches': x_n})
+        else:
+            out = {'bound': 'mfma', 'kernel': 'k_nt_gemm (dual-space products of the batch: A K, W A^T, A Sc per resample, '
+                                              'C_l += V_l^T V_l per batch; LDS-tiled 64 x 64 blocks, contraction 200 - 1000)',
+                   'achieved': nt_tf, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': nt_tf / PEAK_FP64_MFMA_TFLOPS,
+                   'avg_launch_ms': nt_ms / max(nt_n, 1), 'launches': nt_n,
+                   'work': '{:.3e} flop in the timed launches (products issued; symmetric ones by half)'.format(tm.get('nt_flops', 0.0)),
+                   'closing_pass': closing}
+        out.update({'dominant_by_time': dom, 'route': 'quadratic form (plsx_boot_begin / plsx_boot_finish)',
+                    'frac_mfma': out['frac'], 'hbm_algorithmic_over_peak': None,
+                    'per_bootstrap_pass_flop_per_step': direct,
+                    'algorithmic_speedup_vs_per_bootstrap_pass': direct / max(need * L * B, 1.0),
+                    'note': 'the bootstrap weights are linear in the fixed features here (U_b = Xc^T V_b): sum U_b^2 = '
+                            'x_j^T (sum_b v v^T) x_j, one feature pass per series instead of one per bootstrap'})
+        return out
+
     def pipeline(self, ms_per_step, primal):
         """Whole-step fractions with the work the formulation NEEDS (min-flop): per bootstrap
         r 2 S T' B (cross-product over the r S rows it contracts) + 4 S J B (feature moments, all rows)
         + 2 T'^2 B (Gram) + 2 T' L B (R U0) + 2 T' L B (R^T M); per feature-pass permutation
         2 S T' B + 2 T'^2 B; per dual permutation 2 T' S^2 + 2 T'^2 S + its share of K = X X^T."""
         S, B, Tp, L = self.S, self.B, self.Tp, self.L
+        if getattr(self, 'quad_route', False) and not primal:
+            # quadratic-form route: S (S + 1) L B per series + per resample the dual-space products
+            per = 2.0 * Tp * S * S + 2.0 * Tp * Tp * S + 2.0 * Tp * L * S
+            wf = (self.perms + self.boots) * per + self.boots * 1.0 * S * S * L + float(S) * (S + 1) * L * B + 2.0 * S * S * B
+            self.pipeline_formula = ('quadratic-form route: per resample 2 T\' S^2 + 2 T\'^2 S + 2 T\' L S (dual space), per '
+                                     'bootstrap S^2 L (C_l, symmetric), per step S (S + 1) L B (closing pass) + 2 S^2 B '
+                                     '(K = X X^T) = {:.3e} flop'.format(wf))
+            return (1e3 / ms_per_step * wf / (PEAK_FP64_MFMA_TFLOPS * 1e12),
+                    1e3 / ms_per_step * 8.0 * (2.0 * S * B) / (PEAK_HBM_TBS * 1e12))
         r = getattr(self, 'row_fraction', 1.0)
         mom = 4.0 * S * len(self.groups) * self.n_cond * B if self.method == 'behavioral' else 0.0
         wf_boot = r * 2.0 * S * Tp * B + mom + 2.0 * Tp * Tp * B + 4.0 * Tp * L * B
@@ -372,7 +436,7 @@ class Simpls(object):
     def __init__(self, args):
         self.args, self.name = args, 'c5'
         self.S, self.B, self.T, self.k = 1000, 100000, 20, 15
-        self.perms, self.boots = args.perms or 1000, args.boots or 1000
+        self.perms, self.boots = args.perms or 5000, args.boots or 5000          # BASELINE configs[4], literally
         self.unit = 'resamples/s'
 
     def describe(self, world):
@@ -456,6 +520,28 @@ class Simpls(object):
         # would load an X fragment per two MFMAs, 12 x the cache traffic per flop of the dense blocks: 505 GB per
         # 1000 bootstraps through L2): frac_issued = what the matrix pipe does.
         r = getattr(self, 'row_fraction', 1.0)
+        tm = self.eng.last_timing()
+        if tm.get('quad_series', 0) > 0:
+            # quadratic-form route: ONE feature pass per series (k_xprod EPI 7), the rest in dual space
+            mt, gpl = int(tm.get('quad_m_tiles', 24)), int(tm.get('quad_blocks_per_lv', 1))
+            need, issued = quad_closing_work(S, mt, gpl)
+            series = max(int(tm['quad_series']), 1)
+            x_need = need * k * B * series / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            x_iss = issued * k * B * series / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out = {'bound': 'mfma', 'kernel': 'k_xprod<{},8,1,0,7> (closing pass of the bootstrap series: sum_b w_b[j,c]^2 = '
+                                              'x_j^T C_c x_j, {} row blocks per component)'.format(mt, gpl),
+                   'dominant_by_time': dom, 'achieved': x_need, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                   'frac': x_need / PEAK_FP64_MFMA_TFLOPS, 'issued_tflops': x_iss, 'frac_issued': x_iss / PEAK_FP64_MFMA_TFLOPS,
+                   'avg_launch_ms': ms / max(n, 1), 'launches': n, 'route': 'quadratic form (plsx_boot_begin / plsx_boot_finish)',
+                   'work': 'S (S + 1) k B = {:.3e} flop per series (upper triangle of k symmetric S x S forms per column), '
+                           '{:.3e} issued'.format(need * k * B, issued * k * B),
+                   'per_bootstrap_pass_flop_per_step': fl / max(steps, 1),
+                   'algorithmic_speedup_vs_per_bootstrap_pass': fl / max(steps, 1) / (need * k * B),
+                   'dual_solver_ms_per_resample': sms / max(steps * (self.perms + self.boots), 1),
+                   'dual_solver_tflops': sfl / (sms * 1e-3) / 1e12 if sms > 0 else 0.0,
+                   'note': 'frac = needed flop of the closing pass / its time / peak; the per-bootstrap feature pass it '
+                           'replaces multiplies 2 S k B per bootstrap'}
+            return out
         return {'bound': 'mfma', 'kernel': 'k_xprod<24> (bootstrap x_weights = X0_r^T Wd)',
                 'dominant_by_time': dom, 'achieved': tf * r, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf * r / PEAK_FP64_MFMA_TFLOPS, 'frac_issued': tf / PEAK_FP64_MFMA_TFLOPS,
@@ -866,8 +952,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                roof['traffic'] = tj['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/traffic_{}.json ({})'.format(wl.name, tj.get('kernel', ''))
+                prefix = roof.get('kernel', 'k_xprod').split('<')[0].split(' ')[0]
+                kname = tj.get('kernel', '')
+                if not kname.startswith(prefix):           # the file's pick is the busiest k_xprod; ours may be another class
+                    cands = {k: v for k, v in tj.get('kernels', {}).items() if k.startswith(prefix)}
+                    kname = max(cands, key=lambda k: cands[k]['total_over_run']) if cands else kname
+                roof['traffic'] = tj['kernels'][kname]['hbm_bytes_per_launch'] if kname in tj.get('kernels', {}) \
+                    else tj['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/traffic_{}.json ({})'.format(wl.name, kname)
             except Exception:
                 pass
         roof['measured_mfma_f64_peak_tflops'] = eng.mfma_f64_peak()

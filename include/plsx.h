@@ -292,7 +292,11 @@ int plsx_mfma_f64_peak(plsx_ctx* ctx, double* tflops);
  * permutations take the dual (S x S kernel) path and launch no cross-product
  * kernel, [7] compact blocks (one bootstrap per block contracting over the
  * rows it draws): contracted rows / S of the last launch, 0 when the last
- * launch used the dense layouts. Returns the number written. */
+ * launch used the dense layouts, [8] flop of the timed dual-space products
+ * (k_nt_gemm), [9] bootstrap series closed on the quadratic-form route
+ * (plsx_boot_finish) since timing was switched on, [10] / [11] tile rows of a
+ * block / blocks per latent variable of the last closing pass.
+ * Returns the number written. */
 int plsx_last_timing(const plsx_ctx* ctx, double* out, int cap);
 /* Scratch budget of the resampling super-batches (default 48 GB; the R block
  * of one bootstrap is 8 T' B bytes).  fixed = 1: every launch uses budget-sized

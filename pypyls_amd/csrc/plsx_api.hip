@@ -109,6 +109,8 @@ struct plsx_ctx {
     struct TimedEv { int cls; hipEvent_t e0, e1; };
     std::vector<TimedEv> events;
     long long timed_units = 0;
+    double nt_flops = 0.0;                              // flop of the timed k_nt_gemm launches (products issued, symmetric ones by half)
+    int quad_MT = 0, quad_gpl = 0, quad_series = 0;     // block height / blocks per LV of the last closing pass; series closed on that route while timing
     int last_compact_n = 0, last_compact_ktot = 0;   // compact launch behind the last run_xprod (0: none)
     double scratch_gb = 48.0;                           // super-batch scratch budget
     long long R_geom[3] = {0, 0, 0};                    // (T', T'pp, Bpad) the R scratch was last zeroed under
@@ -921,6 +923,7 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     const size_t bytes = (size_t)nchunk * batch * 2 * tiles * 4096 * 8;
     if (int e = ensure(ctx, ctx->part, bytes)) return e;
     a.part = ptr<double>(ctx->part);
+    if (ctx->timing) ctx->nt_flops += 2.0 * Ma * (double)(N1 + (B2 ? N2 : 0)) * K * batch * (a.sym ? 0.5 : 1.0);
     KTimer tm(ctx, KC_NT, st);
     if (a.mtiles >= 2 && !B2) {
         // two tile rows per block (32 x 64 per wave): the S x S products of the dual paths
@@ -941,6 +944,30 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
                            a.ntiles, 1, C2, strideC2, ldc2, Ma, N2, 0);
         LAUNCHCHK();
     }
+    return 0;
+}
+
+// G_r = W_r A_r^T (T' x T') and, with ScT, P_r = A_r Sc (T' x L) of the dual-space routes.  Small T' (mean-centred
+// PLS: T' = cells, a handful): the batched 64 x 64-tile GEMM would multiply (64 / T')^2 x padding -- at c3 (T' = 8)
+// 16 of every 16.3 GFLOP -- so one block per resample takes the T'^2 + T' L dot products over the S positions.
+int run_dual_gp(plsx_ctx* ctx, int m, int Sd, const double* ScT, int L, hipStream_t st)
+{
+    const int S = ctx->S, Tp = ctx->Tp;
+    if (Tp <= 16 && L <= 16) {
+        KTimer tm(ctx, KC_NT, st);
+        hipLaunchKernelGGL(k_dual_gp, dim3(m), dim3(256), 0, st, ptr<double>(ctx->Wd), ptr<double>(ctx->Ad), Sd, S, Tp,
+                           ScT, L, ptr<double>(ctx->Gm), ScT ? ptr<double>(ctx->Pm) : nullptr);
+        LAUNCHCHK();
+        return 0;
+    }
+    if (int e = run_nt(ctx, ptr<double>(ctx->Wd), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->Ad),
+                       (long long)Tp * Sd, Sd, Tp, nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Gm),
+                       (long long)Tp * Tp, Tp, nullptr, 0, 0, st))
+        return e;
+    if (ScT)
+        if (int e = run_nt(ctx, ptr<double>(ctx->Ad), (long long)Tp * Sd, Sd, Tp, ScT, 0, Sd, L,
+                           nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Pm), (long long)Tp * L, L, nullptr, 0, 0, st))
+            return e;
     return 0;
 }
 
@@ -1479,7 +1506,8 @@ try {
                    &ctx->momout, &ctx->R2, &ctx->cvc, &ctx->Qm, &ctx->Vs, &ctx->ds, &ctx->ybar, &ctx->pred,
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
-                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws, &ctx->pflags})
+                   &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws, &ctx->pflags,
+                   &ctx->Cq, &ctx->Vsumq, &ctx->Vdq, &ctx->Vtq, &ctx->Afrag_q, &ctx->qpart})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -1855,10 +1883,7 @@ int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, 
                            nullptr, 0, 0, 0, S, 1, ptr<double>(ctx->Wd), 0, Sd, nullptr, 0, 0, st))
             return e;
         // G_p = W_p A_p^T
-        if (int e = run_nt(ctx, ptr<double>(ctx->Wd), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->Ad),
-                           (long long)Tp * Sd, Sd, Tp, nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Gm),
-                           (long long)Tp * Tp, Tp, nullptr, 0, 0, st))
-            return e;
+        if (int e = run_dual_gp(ctx, m, Sd, nullptr, 0, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_PERM);
         a.rotate = rotate ? 1 : 0;
         a.out_sv = d_out_sv + (size_t)off * ctx->L;
@@ -1935,18 +1960,14 @@ int quad_accumulate(plsx_ctx* ctx, int m, hipStream_t st)
 }
 
 // The closing pass of a series: usum += Xc^T Vsum, usq[j][l] += x_j^T C_l x_j.
-int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
+template <int MT>
+int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
 {
-    constexpr int MT = 24, KT = 1, NW = 8;
+    constexpr int KT = 1, NW = 8;
     const int S = ctx->S, L = ctx->method == PLSX_REGRESSION ? ctx->ncomp : ctx->L, B = ctx->B;
-    {
-        KTimer tm(ctx, KC_UROT, st);
-        hipLaunchKernelGGL(k_xt_vsum, dim3(ceil_div(B, 256), ceil_div(L, 8)), dim3(256), 0, st, ptr<double>(ctx->Xc),
-                           ctx->Bpad, S, B, ptr<double>(ctx->Vsumq), L, d_usum);
-        LAUNCHCHK();
-    }
-    const int gpl = ceil_div(S, MT * 16);
     const size_t gstride = (size_t)ctx->nks * MT * 64;
+    ctx->quad_MT = MT; ctx->quad_gpl = gpl;
+    if (ctx->timing) ++ctx->quad_series;
     // l's per pass: A operands within 1 GB
     const int lmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, (1ULL << 30) / (gstride * 8 * gpl)));
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8;
@@ -1983,6 +2004,25 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
         }
     }
     return 0;
+}
+
+int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
+{
+    const int S = ctx->S, L = ctx->method == PLSX_REGRESSION ? ctx->ncomp : ctx->L, B = ctx->B;
+    {
+        KTimer tm(ctx, KC_UROT, st);
+        hipLaunchKernelGGL(k_xt_vsum, dim3(ceil_div(B, 256), ceil_div(L, 8)), dim3(256), 0, st, ptr<double>(ctx->Xc),
+                           ctx->Bpad, S, B, ptr<double>(ctx->Vsumq), L, d_usum);
+        LAUNCHCHK();
+    }
+    // the S rows of a C_l in gpl blocks of MT tiles, as evenly as the instantiated block heights allow
+    const int tiles = ceil_div(S, 16), gpl = ceil_div(tiles, 24), need = ceil_div(tiles, gpl);
+    if (need <= 12) return quad_finish_t<12>(ctx, d_usq, ceil_div(tiles, 12), st);
+    if (need <= 16) return quad_finish_t<16>(ctx, d_usq, ceil_div(tiles, 16), st);
+    if (need <= 20) return quad_finish_t<20>(ctx, d_usq, ceil_div(tiles, 20), st);
+    if (need <= 21) return quad_finish_t<21>(ctx, d_usq, ceil_div(tiles, 21), st);
+    if (need <= 22) return quad_finish_t<22>(ctx, d_usq, ceil_div(tiles, 22), st);
+    return quad_finish_t<24>(ctx, d_usq, gpl, st);
 }
 }  // namespace
 
@@ -2066,13 +2106,7 @@ int boot_single_pass(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_
         if (int e = run_nt(ctx, ptr<double>(ctx->Ad), 0, Sd, m * Tp, ptr<double>(ctx->Kd), 0, Sd, S,
                            nullptr, 0, 0, 0, S, 1, ptr<double>(ctx->Wd), 0, Sd, nullptr, 0, 0, st))
             return e;
-        if (int e = run_nt(ctx, ptr<double>(ctx->Wd), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->Ad),
-                           (long long)Tp * Sd, Sd, Tp, nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Gm),
-                           (long long)Tp * Tp, Tp, nullptr, 0, 0, st))
-            return e;
-        if (int e = run_nt(ctx, ptr<double>(ctx->Ad), (long long)Tp * Sd, Sd, Tp, ptr<double>(ctx->ScT), 0, Sd, L,
-                           nullptr, 0, 0, 0, S, m, ptr<double>(ctx->Pm), (long long)Tp * L, L, nullptr, 0, 0, st))
-            return e;
+        if (int e = run_dual_gp(ctx, m, Sd, ptr<double>(ctx->ScT), L, st)) return e;
         SmallArgs a = small_args(ctx, SMALL_BOOT);
         if (int e = run_small(ctx, a, m, st)) return e;
         // gen_distrib of a resample is its cross-product with the score columns: P_r itself
@@ -2836,7 +2870,9 @@ try {
     if (force < 0) return PLSX_OK;
     // per-bootstrap pass: 2 S L B n flop; closing pass 2 S^2 L B (rows of C_l in blocks of 384) + 2 S^2 L n for C
     // on the slower tiled GEMM + its transposes: worth it from n ~ 1.25 x the rows the closing pass multiplies
-    const double rows_closing = (double)ceil_div(S, 384) * 384.0;
+    // (the closing pass contracts a row block of C_l from its own first row on: ~(1 + 1/blocks) / 2 of S^2)
+    const int tiles_q = ceil_div(S, 16), gpl_q = ceil_div(tiles_q, 24);
+    const double rows_closing = (double)ceil_div(tiles_q, gpl_q) * gpl_q * 16.0 * 0.5 * (1.0 + 1.0 / gpl_q);
     if (force == 0 && (double)n_total < 1.25 * rows_closing + 64.0) return PLSX_OK;
     const size_t cbytes = (size_t)L * S * S * 8;
     if (cbytes > (size_t)(0.25 * ctx->scratch_gb * 1073741824.0)) return PLSX_OK;
@@ -3018,6 +3054,8 @@ try {
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     ctx->events.clear();
     ctx->timed_units = 0;
+    ctx->nt_flops = 0.0;
+    ctx->quad_series = 0;
     return PLSX_OK;
 } PLSX_CATCH(ctx)
 
@@ -3046,10 +3084,11 @@ try {
         }
     }
     const bool cmp = ctx->last_compact_n > 0;
-    double vals[8] = {ms, (double)launches, (double)(cmp ? 1 : (ctx->sepmom_used ? ctx->npg_d : ctx->npg)),
-                      (double)(cmp ? ceil_div(ctx->Tp, 16) : (ctx->sepmom_used ? ctx->MTd : ctx->MT)),
-                      (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)use_dual(ctx), crows};
-    int n = std::min(cap, 8);
+    double vals[12] = {ms, (double)launches, (double)(cmp ? 1 : (ctx->sepmom_used ? ctx->npg_d : ctx->npg)),
+                       (double)(cmp ? ceil_div(ctx->Tp, 16) : (ctx->sepmom_used ? ctx->MTd : ctx->MT)),
+                       (double)ctx->Gcap * ctx->npg, (double)ctx->timed_units, (double)use_dual(ctx), crows,
+                       ctx->nt_flops, (double)ctx->quad_series, (double)ctx->quad_MT, (double)ctx->quad_gpl};
+    int n = std::min(cap, 12);
     for (int i = 0; i < n; ++i) out[i] = vals[i];
     return n;
 } PLSX_CATCH(const_cast<plsx_ctx*>(cctx))

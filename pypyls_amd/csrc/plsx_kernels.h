@@ -706,7 +706,12 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     const int col = colblk * (NW * 16) + wave * 16 + (lane & 15);
     const int kq = lane >> 4;
 
-    const double* Ag = Afrag + (size_t)grp * group_stride;
+    // EPI 7 (rows s0.. of a SYMMETRIC matrix, quadratic form): the contraction starts at the block's own first row --
+    // the packer doubled the entries right of the diagonal block and dropped those left of it
+    static_assert(EPI != 7 || KT == 1, "EPI 7: one k-step per stage");
+    const int ks0 = (EPI == 7) ? (grp % se.npairs) * (MT * 4) : 0;
+    if (EPI == 7) { X += (size_t)ks0 * 4 * ldx; nks -= ks0; }
+    const double* Ag = Afrag + (size_t)grp * group_stride + (size_t)ks0 * (KT * MT * 64);
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int xvoff = (kq * ldx + min(col, ldx - 1)) * 8;   // per-lane byte offset inside a 4-row k-step (a block of
                                                             // 8 waves may hang over the last 64 columns)
@@ -863,7 +868,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         if (NW > 4 && col >= ldr) return;
         const int s0 = (grp % se.npairs) * (MT * 16);
         const int Srows = se.accB;
-        const double* Xc = X + col;
+        const double* Xc = X + col - (size_t)s0 * ldx;          // (X was advanced to the block's first row, = s0)
         double part = 0.0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -2957,6 +2962,31 @@ __global__ void k_add_splits(const double* __restrict__ psum, const double* __re
 // small helpers
 // ---------------------------------------------------------------------------
 
+// G_r = W_r A_r^T (T' x T'), P_r = A_r ScT^T (T' x L) for T', L <= 16: block = resample, every wave takes output
+// entries in turn, its lanes stride over the S positions (rows of W_r / A_r / ScT of pitch ld; L1 holds the 2 T' rows).
+__global__ __launch_bounds__(256)
+void k_dual_gp(const double* __restrict__ W, const double* __restrict__ A, int ld, int S, int Tp,
+               const double* __restrict__ ScT, int L, double* __restrict__ G, double* __restrict__ P)
+{
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* Wr = W + (size_t)r * Tp * ld;
+    const double* Ar = A + (size_t)r * Tp * ld;
+    const int nG = Tp * Tp, nP = P ? Tp * L : 0;
+    for (int o = wave; o < nG + nP; o += 4) {
+        const double *x, *y;
+        if (o < nG) { x = Wr + (size_t)(o / Tp) * ld; y = Ar + (size_t)(o % Tp) * ld; }
+        else { const int q = o - nG; x = Ar + (size_t)(q / L) * ld; y = ScT + (size_t)(q % L) * ld; }
+        double s = 0.0;
+        for (int i = lane; i < S; i += 64) s += x[i] * y[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) {
+            if (o < nG) G[(size_t)r * nG + o] = s;
+            else P[(size_t)r * nP + (o - nG)] = s;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Quadratic-form route of the bootstrap sums (fixed feature matrix: U_b = X^T V_b, V_b S x L in dual space)
 //   sum_b U_b          = X^T (sum_b V_b)
@@ -2978,18 +3008,21 @@ void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, doub
     if (lane == 0) Vsum[row] += s;
 }
 
-// Rows s0 .. of C_l (S x S, row-major) into the fragment-ordered A operand of group g = l * gpl + part.
+// Rows s0 .. of C_l (S x S, row-major, symmetric) into the fragment-ordered A operand of group g = l * gpl + part:
+// x^T C x = sum over the row blocks of x_blk^T (C[blk, blk] x_blk + 2 C[blk, right of blk] x_right), so a block
+// only holds the columns from its own first row on, the ones right of the diagonal block doubled.
 __global__ __launch_bounds__(256)
 void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride)
 {
     const int g = blockIdx.y, l = g / gpl, s0 = (g % gpl) * MT * 16;
-    const int rows = min(MT * 16, S - s0);
-    const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S;
+    const int rows = min(MT * 16, S - s0), w = S - s0;
+    const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S + s0;
     double* out = Afrag + (size_t)g * group_stride;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)rows * S;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)rows * w;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(idx / S), k = (int)(idx - (long long)r * S);
-        out[afrag_off(r, k, MT)] = Cl[idx];
+        const int r = (int)(idx / w), k = (int)(idx - (long long)r * w);
+        const double v = Cl[(size_t)r * S + k];
+        out[afrag_off(r, s0 + k, MT)] = k < MT * 16 ? v : 2.0 * v;
     }
 }
 

@@ -713,10 +713,11 @@ class Engine(object):
         return bool(rc)
 
     def last_timing(self):
-        buf = (ctypes.c_double * 8)()
-        n = self.lib.plsx_last_timing(self.ctx, buf, 8)
+        buf = (ctypes.c_double * 12)()
+        n = self.lib.plsx_last_timing(self.ctx, buf, 12)
         keys = ['xprod_ms', 'xprod_launches', 'resamples_per_group', 'm_tiles', 'superbatch',
-                'xprod_resamples', 'dual_perm', 'compact_row_fraction']
+                'xprod_resamples', 'dual_perm', 'compact_row_fraction', 'nt_flops', 'quad_series', 'quad_m_tiles',
+                'quad_blocks_per_lv']
         return {k: buf[i] for i, k in enumerate(keys[:max(n, 0)])}
 
 

@@ -86,7 +86,7 @@ def test_quadratic_form_sums_equal_per_bootstrap_pass_and_oracle(case):
 
 
 def test_route_choice():
-    """Auto: the closing pass multiplies ceil(S / 384) * 384 rows per LV, a bootstrap L rows -- the series has to be
+    """Auto: the closing pass multiplies about (1 + 1 / blocks) / 2 of the S (padded) rows per LV, a bootstrap L rows -- the series has to be
     longer than that to win; correlation-mode behavioral PLS re-scales the features per bootstrap and never
     qualifies; an engine without plsx_boot_begin never leaves the in-place route."""
     from pypyls_amd import resampling as rsmp
@@ -97,7 +97,7 @@ def test_route_choice():
     eng = _engine()
     eng.set_data(X, None, cells, len(groups), n_cond, 1, mean_centering=0)
     eng.set_original(U, np.diag(d), V)
-    assert eng.boot_begin(100) == 0 and eng.boot_begin(543) == 0 and eng.boot_begin(544) == 1
+    assert eng.boot_begin(100) == 0 and eng.boot_begin(203) == 0 and eng.boot_begin(204) == 1          # S = 111: 7 tiles, one block
     eng.set_original(U, np.diag(d), V)                                    # ends the open series
     assert eng.lib.plsx_boot_route(eng.ctx) == 0
     Xb = rs.randn(40, 500)

@@ -26,8 +26,13 @@ res = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=0, see
 Xm = rs.randn(36, 200); Xm[:12] += 1.0
 rm = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=7, n_boot=7, seed=3, verbose=False)
 rr = pls.pls_regression(X, Y, n_components=3, n_perm=6, n_boot=5, seed=5, verbose=False)
+# long series: every rank announces its share (plsx_boot_begin) and takes the quadratic-form route of the sums
+rm2 = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=4, n_boot=700, seed=3, verbose=False)
+rr2 = pls.pls_regression(X, Y, n_components=3, n_perm=4, n_boot=400, seed=5, verbose=False)
 if dist.get_rank() == 0:
-    np.savez({out!r}, perm=res.permres.perm_singval, bsr=res.bootres.x_weights_normed,
+    np.savez({out!r}, m2bsr=rm2.bootres.x_weights_normed, m2se=rm2.bootres.x_weights_stderr,
+             r2bsr=rr2.bootres.x_weights_normed, r2se=rr2.bootres.x_weights_stderr,
+             perm=res.permres.perm_singval, bsr=res.bootres.x_weights_normed,
              ylb=res.bootres.y_loadings_boot, uc=res.splitres.ucorr_pvals, ul=res.splitres.ucorr_uplim,
              mperm=rm.permres.perm_singval, mbsr=rm.bootres.x_weights_normed,
              rperm=rr.permres.perm_singval, rbsr=rr.bootres.x_weights_normed)
@@ -64,6 +69,23 @@ def test_two_ranks_equal_one_rank(tmp_path):
     np.testing.assert_allclose(two['mbsr'], rm.bootres.x_weights_normed, rtol=1e-9)
     np.testing.assert_allclose(two['rperm'], rr.permres.perm_singval, rtol=1e-12)
     np.testing.assert_allclose(two['rbsr'], rr.bootres.x_weights_normed, rtol=1e-9)
+    # series long enough for the quadratic-form route of the bootstrap sums, on one rank and on each of two
+    from pypyls_amd import engine
+    rm2 = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=4, n_boot=700, seed=3, verbose=False)
+    rr2 = pls.pls_regression(X, Y, n_components=3, n_perm=4, n_boot=400, seed=5, verbose=False)
+    live = rm2.singvals > 1e-8 * rm2.singvals.max()
+    np.testing.assert_allclose(two['m2bsr'][:, live], rm2.bootres.x_weights_normed[:, live], rtol=1e-7)
+    np.testing.assert_allclose(two['m2se'][:, live], rm2.bootres.x_weights_stderr[:, live], rtol=1e-7)
+    np.testing.assert_allclose(two['r2bsr'], rr2.bootres.x_weights_normed, rtol=1e-7)
+    np.testing.assert_allclose(two['r2se'], rr2.bootres.x_weights_stderr, rtol=1e-7)
+    eng = engine.default_engine()
+    try:                                            # ... and the per-bootstrap pass agrees with both
+        eng.set_option('quad_sums', -1)
+        rm3 = pls.meancentered_pls(Xm, groups=[6, 6, 6], n_cond=2, n_perm=4, n_boot=700, seed=3, verbose=False)
+    finally:
+        eng.set_option('quad_sums', 0)
+    np.testing.assert_allclose(rm3.bootres.x_weights_stderr[:, live], rm2.bootres.x_weights_stderr[:, live], rtol=1e-7)
+    assert np.max(np.abs(rm3.bootres.x_weights_stderr - rm2.bootres.x_weights_stderr)[:, live]) > 0
 
 
 _NCCL_WORKER = r'''

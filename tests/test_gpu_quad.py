@@ -155,3 +155,51 @@ def test_plsc_front_end_takes_the_route_by_itself():
     assert_close_per_lv(a.x_weights_stderr, b.x_weights_stderr, 1, 1e-8, what='standard errors', keep=live)
     assert_close(a.contrast_ci, b.contrast_ci, 1e-10, what='contrast CIs')
     assert np.max(np.abs(a.x_weights_normed - b.x_weights_normed)[:, live]) > 0.0       # (two routes did run)
+
+
+@pytest.fixture
+def forced_route():
+    """The front-ends' cached engine with the route forced on: the goldens' bootstrap series (20 - 100) are shorter
+    than what the library would pick it for."""
+    from pypyls_amd import engine
+    eng = engine.default_engine()
+    eng.set_option('quad_sums', 1)
+    try:
+        yield eng
+    finally:
+        eng.set_option('quad_sums', 0)
+
+
+_UNSCALED = ['mpls_1g3c_norot', 'mpls_2g2c_split', 'mpls_3g1c', 'mpls_3g2c_mc0', 'mpls_3g2c_mc1', 'mpls_3g2c_mc2',
+             'mat_mpls_multigroup_onecond_nosplit', 'mat_mpls_multigroup_onecond_split',
+             'bpls_1g1c_cov', 'bpls_2g2c_cov', 'bpls_cv_cov']
+
+
+@pytest.mark.parametrize('name', _UNSCALED)
+def test_reference_goldens_on_the_route(name, forced_route):
+    """Every golden of an unscaled mode (the reference's own outputs and the oracle, key by key) with the bootstrap
+    sums taken as quadratic forms."""
+    import test_gpu_frontend as tf
+    if name in tf.MEANC:
+        tf.test_meancentered_vs_reference_and_oracle(name)
+    else:
+        tf.test_behavioral_vs_reference_and_oracle(name)
+    assert forced_route.boot_begin(10) == 1           # (the route is what ran: it applies to this binding)
+    forced_route.boot_finish(forced_route._zeros((forced_route.B, forced_route.L)),
+                             forced_route._zeros((forced_route.B, forced_route.L)))
+
+
+@pytest.mark.parametrize('which', ['t4', 't8', 't16', '3d_mean', '3d_median', '3d_nan', 'nan'])
+def test_regression_goldens_on_the_route(which, forced_route):
+    import test_gpu_regression as tr
+    if which.startswith('t'):
+        tr.test_pls_regression(which)
+    elif which == '3d_nan':
+        tr.test_pls_regression_3d_y_with_nan_rows()
+    elif which == 'nan':
+        tr.test_pls_regression_nan_rows()
+    else:
+        tr.test_pls_regression_3d_y(which[3:])
+    assert forced_route.boot_begin(10) == 1
+    forced_route.boot_finish(forced_route._zeros((forced_route.B, forced_route.k)),
+                             forced_route._zeros((forced_route.B, forced_route.k)))

@@ -38,7 +38,7 @@ def timed(obj, name):
 
 
 for n in ['set_data', 'colmean_dev', 'simpls_decompose', 'simpls_set_original', 'project', 'boot_rel', 'percentile_ci',
-          'simpls_perm_into', 'simpls_boot_into', 'rows_tensor', 'sync']:
+          'simpls_perm_into', 'simpls_boot_into', 'boot_begin', 'boot_finish', 'rows_tensor', 'sync', '_dev', 'set_data_regression']:
     timed(E.Engine, n)
 timed(parallel, 'collect_slices')
 torch.cuda.synchronize()

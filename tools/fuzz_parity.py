@@ -57,6 +57,10 @@ def one_case(rs, idx):
         return desc, 'skipped'
     from pypyls_amd.engine import options_from_env
     eng = Engine(**options_from_env())
+    # bootstrap sums: quadratic-form route forced on / off (it only applies to the unscaled modes; plsx_boot_begin)
+    quad = bool(rs.rand() < 0.5)
+    eng.set_option('quad_sums', 1 if quad else -1)
+    desc['quad_sums'] = quad
     eng.set_data(X, Y if method == 'behavioral' else None, rsmp.cell_of_row(groups, n_cond), n_groups, n_cond,
                  0 if method == 'behavioral' else 1, mean_centering=mc, covariance=cov)
     spec = ref.Spec(method, groups, n_cond, cov, mc, rotate)
@@ -79,12 +83,14 @@ def one_case(rs, idx):
     want = np.stack([ref.single_perm(spec, X, Yo, perms[:, i], V)[0] for i in range(nres)], -1)
     close(got[live], want[live], 1e-6, 'perm')
     usum, usq, dist = eng.boot(boots)
-    ws, wd = np.zeros_like(U), []
+    ws, wq, wd = np.zeros_like(U), np.zeros_like(U), []
     for i in range(nres):
         dd, ub = ref.single_boot(spec, X, Yo, boots[:, i], U, d)
         ws += ub
+        wq += ub ** 2
         wd.append(dd)
     close(usum.cpu().numpy()[:, live], ws[:, live], 1e-5, 'u_sum')
+    close(usq.cpu().numpy()[:, live], wq[:, live], 1e-5, 'u_square')
     close(dist[:, live], np.stack(wd, -1)[:, live], 1e-6, 'distrib')
     if method == 'behavioral' and not cov and min(per) >= 8:
         masks = rsmp.gen_splits(groups, n_cond, 3, seed=int(rs.randint(1 << 30)))
@@ -115,12 +121,19 @@ def regression_case(rs, idx):
         Y[int(rs.randint(S))] = np.nan
         k = min(k, S - 5)
     LAST = desc = dict(i=idx, method='regression', S=S, B=B, T=T, k=k, nan_rows=bool(nan_rows))
-    res = pls.pls_regression(X, Y, n_components=k, n_perm=6, n_boot=5, seed=int(rs.randint(1 << 30)), verbose=False)
+    from pypyls_amd.engine import Engine, options_from_env
+    eng = Engine(**options_from_env())
+    quad = bool(rs.rand() < 0.5)
+    eng.set_option('quad_sums', 1 if quad else -1)
+    desc['quad_sums'] = quad
+    res = pls.pls_regression(X, Y, n_components=k, n_perm=6, n_boot=5, seed=int(rs.randint(1 << 30)), verbose=False,
+                             _engine=eng)
     want = ref.run_regression(X, Y, k, permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples)
     for key in ('x_weights', 'y_loadings', 'varexp'):
         close(res[key], want[key], 1e-5, key)
     close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-5, 'perm varexp')
     close(res.bootres.x_weights_normed, want['bootres']['x_weights_normed'], 1e-5, 'bsr')
+    close(res.bootres.x_weights_stderr, want['bootres']['x_weights_stderr'], 1e-5, 'stderr')
     close(res.bootres.y_loadings_boot, want['bootres']['y_loadings_boot'], 1e-5, 'y_loadings_boot')
     return desc, 'ok'
 

@@ -346,7 +346,8 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
  *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "urot_m3", "epi2_nw4", "simpls_jacobi"
  *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "quad_sums" (plsx_boot_begin: 1 = the quadratic-form route
- *     whenever it applies, -1 = never), "percentile_sort" (plsx_percentile_ci: always the
+ *     whenever it applies, -1 = never), "quad_mt" (tile rows of a row block of its closing pass, 0 = chosen),
+ *     "quad_full_rows" (closing pass without the symmetry), "quad_launch_per_block", "percentile_sort" (plsx_percentile_ci: always the
  *     full sort instead of the tail selection), "trace_alloc";
  *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
  *     size the super-batch scratch for n once instead of per call (0 = per call)

@@ -34,13 +34,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_QUAD_MT, OPT_QUAD_FULL_ROWS, OPT_QUAD_LAUNCH_PER_BLOCK, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort", "quad_sums"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort", "quad_sums", "quad_mt", "quad_full_rows", "quad_launch_per_block"};
 
 struct plsx_ctx {
     int device = 0;
@@ -1967,6 +1967,7 @@ int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
     const int S = ctx->S, L = ctx->method == PLSX_REGRESSION ? ctx->ncomp : ctx->L, B = ctx->B;
     const size_t gstride = (size_t)ctx->nks * MT * 64;
     ctx->quad_MT = MT; ctx->quad_gpl = gpl;
+    const bool full = ctx->opt[OPT_QUAD_FULL_ROWS] != 0;      // A/B: every row block over all S columns (no use of the symmetry)
     if (ctx->timing) ++ctx->quad_series;
     // l's per pass: A operands within 1 GB
     const int lmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, (1ULL << 30) / (gstride * 8 * gpl)));
@@ -1981,18 +1982,25 @@ int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
         {
             KTimer tm(ctx, KC_BUILD, st);
             hipLaunchKernelGGL(k_pack_afrag, dim3(64, groups), dim3(256), 0, st,
-                               ptr<double>(ctx->Cq) + (size_t)l0 * S * S, S, gpl, MT, ptr<double>(ctx->Afrag_q), gstride);
+                               ptr<double>(ctx->Cq) + (size_t)l0 * S * S, S, gpl, MT, ptr<double>(ctx->Afrag_q), gstride, full ? 1 : 0);
             LAUNCHCHK();
         }
         SplitEpi se;
         memset(&se, 0, sizeof(se));
-        se.acc_sum = ptr<double>(ctx->qpart); se.npairs = gpl; se.accB = S;
-        {
+        se.acc_sum = ptr<double>(ctx->qpart); se.npairs = gpl; se.accB = S; se.nmu = full ? 1 : 0; se.J = nl;
+        // Groups are numbered row block first: the groups of a sweep go to the eight XCDs in lockstep, and with the
+        // blocks of an LV next to each other (contraction lengths S, 2 S / 3, S / 3 at c5) the XCDs with short blocks
+        // waited for the one with the long block: 38.7 ms, block-major 35.1, one launch per row block (A/B option) 34.9
+        const bool per_block = ctx->opt[OPT_QUAD_LAUNCH_PER_BLOCK] != 0;
+        for (int pb = 0; pb < (per_block ? gpl : 1); ++pb) {
+            const int ng = per_block ? nl : groups;
+            se.Tpp = pb;
+            se.acc_sum = ptr<double>(ctx->qpart) + (size_t)pb * nl * ctx->Bpad;
             KTimer tm(ctx, KC_XPROD, st);
-            hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 7>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), stage, st,
-                               ptr<double>(ctx->Afrag_q), gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
-                               (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
-                               (const double*)nullptr, 0, groups, ncolblk, (double*)nullptr, se, 1);
+            hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 7>), dim3(ncolblk * round_up(ng, 8)), dim3(NW * 64), stage, st,
+                               ptr<double>(ctx->Afrag_q) + (size_t)pb * nl * gstride, gstride, ptr<double>(ctx->Xc), ctx->Bpad,
+                               ctx->nks, (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                               (const double*)nullptr, 0, ng, ncolblk, (double*)nullptr, se, 1);
             LAUNCHCHK();
         }
         {
@@ -2016,7 +2024,8 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
         LAUNCHCHK();
     }
     // the S rows of a C_l in gpl blocks of MT tiles, as evenly as the instantiated block heights allow
-    const int tiles = ceil_div(S, 16), gpl = ceil_div(tiles, 24), need = ceil_div(tiles, gpl);
+    const int tiles = ceil_div(S, 16), gpl = ceil_div(tiles, 24);
+    const int need = ctx->opt[OPT_QUAD_MT] > 0 ? std::min(24, ctx->opt[OPT_QUAD_MT]) : ceil_div(tiles, gpl);
     if (need <= 12) return quad_finish_t<12>(ctx, d_usq, ceil_div(tiles, 12), st);
     if (need <= 16) return quad_finish_t<16>(ctx, d_usq, ceil_div(tiles, 16), st);
     if (need <= 20) return quad_finish_t<20>(ctx, d_usq, ceil_div(tiles, 20), st);

@@ -709,7 +709,10 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     // EPI 7 (rows s0.. of a SYMMETRIC matrix, quadratic form): the contraction starts at the block's own first row --
     // the packer doubled the entries right of the diagonal block and dropped those left of it
     static_assert(EPI != 7 || KT == 1, "EPI 7: one k-step per stage");
-    const int ks0 = (EPI == 7) ? (grp % se.npairs) * (MT * 4) : 0;
+    // groups are numbered row block first (grp = block * se.J + lv, se.J = LVs of the pass): the eight groups of a
+    // sweep -- one per XCD, dispatched in lockstep -- then have the same contraction length
+    const int qblk = (EPI == 7) ? se.Tpp + grp / max(se.J, 1) : 0;      // (se.Tpp: first row block of the launch)
+    const int ks0 = (EPI == 7 && !se.nmu) ? qblk * (MT * 4) : 0;      // (se.nmu: A/B, full rows)
     if (EPI == 7) { X += (size_t)ks0 * 4 * ldx; nks -= ks0; }
     const double* Ag = Afrag + (size_t)grp * group_stride + (size_t)ks0 * (KT * MT * 64);
     const int swave = __builtin_amdgcn_readfirstlane(wave);
@@ -862,13 +865,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     }
     if constexpr (EPI == 7) {
         // quadratic form (k_quad_*): the group's rows are rows s0 .. s0 + MT * 16 - 1 of ONE symmetric S x S matrix
-        // C_l (group g: l = g / gpl, s0 = (g % gpl) * MT * 16; gpl = se.npairs, S = se.accB), acc = (C_l X)[s][col];
+        // C_l (group g: l = g % nl, s0 = (g / nl) * MT * 16; nl = se.J, S = se.accB), acc = (C_l X)[s][col];
         // the block adds X[s][col] * acc over its rows -- its share of x_col^T C_l x_col -- and writes ONE value per
         // column: se.acc_sum[grp][ldr].  The X rows are the ones the main loop just streamed (L2).
         if (NW > 4 && col >= ldr) return;
-        const int s0 = (grp % se.npairs) * (MT * 16);
+        const int s0 = qblk * (MT * 16);
         const int Srows = se.accB;
-        const double* Xc = X + col - (size_t)s0 * ldx;          // (X was advanced to the block's first row, = s0)
+        const double* Xc = X + col - (size_t)(ks0 * 4) * ldx;   // (X was advanced to the block's first contraction row)
         double part = 0.0;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -3008,25 +3011,28 @@ void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, doub
     if (lane == 0) Vsum[row] += s;
 }
 
-// Rows s0 .. of C_l (S x S, row-major, symmetric) into the fragment-ordered A operand of group g = l * gpl + part:
+// Rows s0 .. of C_l (S x S, row-major, symmetric) into the fragment-ordered A operand of group g = block * nl + l:
 // x^T C x = sum over the row blocks of x_blk^T (C[blk, blk] x_blk + 2 C[blk, right of blk] x_right), so a block
 // only holds the columns from its own first row on, the ones right of the diagonal block doubled.
 __global__ __launch_bounds__(256)
-void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride)
+void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride,
+                  int full)
 {
-    const int g = blockIdx.y, l = g / gpl, s0 = (g % gpl) * MT * 16;
-    const int rows = min(MT * 16, S - s0), w = S - s0;
-    const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S + s0;
+    const int nl = gridDim.y / gpl;                         // group g = block * nl + l (see k_xprod EPI 7)
+    const int g = blockIdx.y, l = g % nl, s0 = (g / nl) * MT * 16;
+    const int k0 = full ? 0 : s0;                           // first column the block holds
+    const int rows = min(MT * 16, S - s0), w = S - k0;
+    const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S + k0;
     double* out = Afrag + (size_t)g * group_stride;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)rows * w;
          idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / w), k = (int)(idx - (long long)r * w);
         const double v = Cl[(size_t)r * S + k];
-        out[afrag_off(r, s0 + k, MT)] = k < MT * 16 ? v : 2.0 * v;
+        out[afrag_off(r, k0 + k, MT)] = (full || k < MT * 16) ? v : 2.0 * v;
     }
 }
 
-// usq[j][l0 + l] += sum over the gpl groups of l of part[(l * gpl + g)][j], l < nl
+// usq[j][l0 + l] += sum over the gpl row blocks g of part[g * nl + l][j], l < nl
 __global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp, int B, int nl, int L, int l0,
                               double* __restrict__ usq)
 {
@@ -3034,7 +3040,7 @@ __global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp,
     if (i >= (long long)B * nl) return;
     const int j = (int)(i / nl), l = (int)(i - (long long)j * nl);
     double s = 0.0;
-    for (int g = 0; g < gpl; ++g) s += part[(size_t)(l * gpl + g) * ldp + j];
+    for (int g = 0; g < gpl; ++g) s += part[(size_t)(g * nl + l) * ldp + j];
     usq[(size_t)j * L + l0 + l] += s;
 }
 

@@ -2616,8 +2616,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.Zt = w;
     a.pctvar = pctvar; a.yload = yload; a.cvec = cvec;
     if (scatter && Vd) {
-        HIPCHK(hipMemsetAsync(Vd, 0, (size_t)nres * k * S * 8, st));
-        a.Vd = Vd;
+        a.Vd = Vd;                                     // (k_sd_final writes every entry)
     } else if (scatter) {
         // the solver batch may span several cross-product batches: its own span of A operands
         if (int e = ensure(ctx, ctx->Afrag, (size_t)groups * ctx->group_stride * 8 + 4096)) return e;
@@ -2665,7 +2664,9 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     {
         a.Qs = align_signs ? ptr<double>(ctx->Qs) : nullptr;
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_final, grid, block, (size_t)wpb * k * 8, st, a);
+        const size_t lds_f = (size_t)wpb * (k + (a.Vd ? S : 0)) * 8;
+        HIPCHK(set_lds(k_sd_final, lds_f));
+        hipLaunchKernelGGL(k_sd_final, grid, block, lds_f, st, a);
         LAUNCHCHK();
     }
 #ifdef PLSX_SD_PROBE

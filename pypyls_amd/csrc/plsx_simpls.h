@@ -218,6 +218,76 @@ __device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, doubl
     }
 }
 
+// C[m][n] = sum_{p < S} A[m][p] B[n][p] on ONE wavefront with the fp64 matrix instruction: MTL x NTL tiles of 16 x 16.
+// The contraction index may meet the four k-slots of an instruction in any order as long as both operands agree, so
+// lane (row = l & 15, q = l >> 4) fetches the FOUR consecutive positions p0 + 4 q .. + 3 of its row per 16-position
+// chunk and feeds them to four successive instructions (slot q of instruction j <-> position p0 + 4 q + j).
+// fa(row, p, v) / fb(row, p, v) fill v[0..3] with the operand's values at (row, p .. p + 3), zeros beyond their
+// extents.  acc[mt][nt][i] <-> C[mt 16 + (l >> 4) + 4 i][nt 16 + (l & 15)].  The dot-product loops these replace
+// (T x T / 4 passes over S for H0, T x k / 4 for the y-loadings) re-read their operands T / 4 times from memory.
+template <int MTL, int NTL, class FA, class FB>
+__device__ __forceinline__ void wave_mfma_nt(d4 (&acc)[MTL][NTL], int S, int lane, FA fa, FB fb)
+{
+    const int row = lane & 15, q = lane >> 4;
+    double a[MTL][4], b[NTL][4], an[MTL][4], bn[NTL][4];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, 4 * q, a[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, 4 * q, b[nt]);
+    for (int p0 = 0; p0 < S; p0 += 16) {
+        const int pn = min(p0 + 16, max(S - 1, 0) & ~15) + 4 * q;      // next chunk (the last one is fetched twice)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, pn, an[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, pn, bn[nt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma_f64(a[mt][j], b[nt][j], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[mt][j] = an[mt][j];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nt][j] = bn[nt][j];
+    }
+}
+
+// H = H0 = Y0^T Z0 (T x T; Y0, Z0 T-major [t][p]) of one resample by its wave.
+template <int TT>
+__device__ __forceinline__ void sd_gram_h(const double* Y0, const double* Z0, int S, int T, int lane, double* H, double* H0)
+{
+    d4 acc[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    auto rows = [&](const double* M) {
+        return [=](int t, int p, double (&v)[4]) {
+            const double* src = M + (size_t)min(t, T - 1) * S;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double x = src[min(p + j, S - 1)];
+                v[j] = (t < T && p + j < S) ? x : 0.0;
+            }
+        };
+    };
+    wave_mfma_nt<TT, TT>(acc, S, lane, rows(Y0), rows(Z0));
+#pragma unroll
+    for (int mt = 0; mt < TT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t1 = mt * 16 + (lane >> 4) + 4 * i, t2 = nt * 16 + (lane & 15);
+                if (t1 < T && t2 < T) { H[t1 * T + t2] = acc[mt][nt][i]; H0[t1 * T + t2] = acc[mt][nt][i]; }
+            }
+}
+
 // After GEMM 0: Z0 = Jc gather(K scatter(Y0)), kcpos, H = H0 = Y0^T Z0.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_post0(SdArgs a)
@@ -265,28 +335,37 @@ void k_sd_post0(SdArgs a)
             }
         }
     }
-    // H[t1][t2] = sum_p Y0[p][t1] Z0[p][t2]: four columns of Z0 per pass over a column of Y0
+    // H[t1][t2] = sum_p Y0[p][t1] Z0[p][t2] on the matrix pipe (Z0 as this wave just wrote it: same lanes' stores are
+    // visible to the wave after the fence)
     double* H = a.H + (size_t)r * T * T;
     double* H0 = a.H0 + (size_t)r * T * T;
-    for (int t1 = 0; t1 < T; ++t1)
-        for (int t2 = 0; t2 < T; t2 += 4) {
-            const double* y1 = Y0 + (size_t)t1 * S;
-            const double* z0 = Z0 + (size_t)min(t2, T - 1) * S;
-            const double* z1 = Z0 + (size_t)min(t2 + 1, T - 1) * S;
-            const double* z2 = Z0 + (size_t)min(t2 + 2, T - 1) * S;
-            const double* z3 = Z0 + (size_t)min(t2 + 3, T - 1) * S;
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
-                SD_TILE_PC(pc, p0);
-                SD_OWN(i) {
-                    const double yv = y1[pc[i]], y = SD_IN(p0, i) ? yv : 0.0;
-                    s4[0] += y * z0[pc[i]]; s4[1] += y * z1[pc[i]]; s4[2] += y * z2[pc[i]]; s4[3] += y * z3[pc[i]];
+    wave_sync();
+    __threadfence_block();
+    if (T <= 16) sd_gram_h<1>(Y0, Z0, S, T, lane, H, H0);
+    else if (T <= 32) sd_gram_h<2>(Y0, Z0, S, T, lane, H, H0);
+    else if (T <= 48) sd_gram_h<3>(Y0, Z0, S, T, lane, H, H0);
+    else if (T <= 64) sd_gram_h<4>(Y0, Z0, S, T, lane, H, H0);
+    else {
+        for (int t1 = 0; t1 < T; ++t1)
+            for (int t2 = 0; t2 < T; t2 += 4) {
+                const double* y1 = Y0 + (size_t)t1 * S;
+                const double* z0 = Z0 + (size_t)min(t2, T - 1) * S;
+                const double* z1 = Z0 + (size_t)min(t2 + 1, T - 1) * S;
+                const double* z2 = Z0 + (size_t)min(t2 + 2, T - 1) * S;
+                const double* z3 = Z0 + (size_t)min(t2 + 3, T - 1) * S;
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                    SD_TILE_PC(pc, p0);
+                    SD_OWN(i) {
+                        const double yv = y1[pc[i]], y = SD_IN(p0, i) ? yv : 0.0;
+                        s4[0] += y * z0[pc[i]]; s4[1] += y * z1[pc[i]]; s4[2] += y * z2[pc[i]]; s4[3] += y * z3[pc[i]];
+                    }
                 }
+                wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+                if (lane == 0)
+                    for (int u = 0; u < 4 && t2 + u < T; ++u) { H[t1 * T + t2 + u] = s4[u]; H0[t1 * T + t2 + u] = s4[u]; }
             }
-            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
-            if (lane == 0)
-                for (int u = 0; u < 4 && t2 + u < T; ++u) { H[t1 * T + t2 + u] = s4[u]; H0[t1 * T + t2 + u] = s4[u]; }
-        }
+    }
 }
 
 // One-sided Jacobi on the columns of A (m x n, column pitch ld, in the wave's LDS) by ONE
@@ -908,7 +987,7 @@ void k_sd_step(SdArgs a)
 // (w0c centred over the features, wd_c centred over the positions), so the feature pass can
 // accumulate the aligned weights directly (k_xprod EPI = 2) instead of writing them, forming
 // their cross-Gram with the original and reading them back for the sign and the sums.
-// dynamic LDS: k doubles per wave.
+// dynamic LDS: k (+ S with a.Vd) doubles per wave.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_final(SdArgs a)
 {
@@ -916,7 +995,7 @@ void k_sd_final(SdArgs a)
     const int S = a.S, T = a.T, k = a.k, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
     const int r = blockIdx.x * (blockDim.x >> 6) + wave;
     if (r >= a.nres) return;
-    double* flip = sm_sd + (size_t)wave * k;
+    double* flip = sm_sd + (size_t)wave * (k + (a.Vd ? S : 0));      // [k] signs (+ [S] scatter buffer with Vd)
     const int* xs = a.xs + (size_t)r * S;
     const int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
@@ -948,25 +1027,64 @@ void k_sd_final(SdArgs a)
                 flip[c0 + u] = (s4[u] > 0.0) ? 1.0 : ((s4[u] < 0.0) ? -1.0 : 0.0);
     }
     wave_sync();
-    for (int t = 0; t < T; ++t)
-        for (int c0 = 0; c0 < k; c0 += 4) {
-            const double *w0 = XW + (size_t)min(c0, k - 1) * S, *w1 = XW + (size_t)min(c0 + 1, k - 1) * S,
-                         *w2 = XW + (size_t)min(c0 + 2, k - 1) * S, *w3 = XW + (size_t)min(c0 + 3, k - 1) * S;
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
-                SD_TILE_PC(pc, p0);
-                SD_OWN(i) {
-                    const int x = xs[pc[i]], yy = ys[pc[i]];
-                    const double yv = Ysrc[(size_t)yy * T + t];
-                    const double y = (SD_IN(p0, i) && x >= 0) ? yv : 0.0;
-                    s4[0] += y * w0[pc[i]]; s4[1] += y * w1[pc[i]]; s4[2] += y * w2[pc[i]]; s4[3] += y * w3[pc[i]];
-                }
-            }
-            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
-            if (lane == 0)
-                for (int u = 0; u < 4 && c0 + u < k; ++u)
-                    a.yload[((size_t)r * T + t) * k + c0 + u] = s4[u] * flip[c0 + u];
+    // y_loadings[t][c] = flip_c sum_p Y[ys_p][t] XW[c][p] over the included positions: on the matrix pipe (M = t, N = c)
+    auto fy = [&](int t, int p, double (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pp = min(p + j, S - 1);
+            const int x = xs[pp], yy = ys[pp];
+            const double yv = Ysrc[(size_t)yy * T + min(t, T - 1)];
+            v[j] = (t < T && p + j < S && x >= 0) ? yv : 0.0;
         }
+    };
+    auto fw = [&](int c, int p, double (&v)[4]) {
+        const double* src = XW + (size_t)min(c, k - 1) * S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double w = src[min(p + j, S - 1)];
+            v[j] = (c < k && p + j < S) ? w : 0.0;
+        }
+    };
+    const int tt = (T + 15) >> 4, kt = (k + 15) >> 4;
+#define SD_YL(MTL, NTL) {                                                                                          \
+        d4 acc[MTL][NTL];                                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < MTL; ++i_)                                                         \
+            _Pragma("unroll") for (int j_ = 0; j_ < NTL; ++j_) acc[i_][j_] = (d4){0.0, 0.0, 0.0, 0.0};            \
+        wave_mfma_nt<MTL, NTL>(acc, S, lane, fy, fw);                                                              \
+        _Pragma("unroll") for (int mt = 0; mt < MTL; ++mt)                                                         \
+            _Pragma("unroll") for (int nt = 0; nt < NTL; ++nt)                                                     \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+                    const int t = mt * 16 + (lane >> 4) + 4 * i, c = nt * 16 + (lane & 15);                        \
+                    if (t < T && c < k) a.yload[((size_t)r * T + t) * k + c] = acc[mt][nt][i] * flip[c];          \
+                }                                                                                                  \
+    }
+    if (tt == 1 && kt == 1) SD_YL(1, 1)
+    else if (tt == 2 && kt == 1) SD_YL(2, 1)
+    else if (tt <= 4 && kt == 1) SD_YL(4, 1)
+    else if (tt <= 2 && kt <= 2) SD_YL(2, 2)
+    else if (tt <= 4 && kt <= 4) SD_YL(4, 4)
+    else {
+        for (int t = 0; t < T; ++t)
+            for (int c0 = 0; c0 < k; c0 += 4) {
+                const double *w0 = XW + (size_t)min(c0, k - 1) * S, *w1 = XW + (size_t)min(c0 + 1, k - 1) * S,
+                             *w2 = XW + (size_t)min(c0 + 2, k - 1) * S, *w3 = XW + (size_t)min(c0 + 3, k - 1) * S;
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                    SD_TILE_PC(pc, p0);
+                    SD_OWN(i) {
+                        const int x = xs[pc[i]], yy = ys[pc[i]];
+                        const double yv = Ysrc[(size_t)yy * T + t];
+                        const double y = (SD_IN(p0, i) && x >= 0) ? yv : 0.0;
+                        s4[0] += y * w0[pc[i]]; s4[1] += y * w1[pc[i]]; s4[2] += y * w2[pc[i]]; s4[3] += y * w3[pc[i]];
+                    }
+                }
+                wave_sum4(s4[0], s4[1], s4[2], s4[3]);
+                if (lane == 0)
+                    for (int u = 0; u < 4 && c0 + u < k; ++u)
+                        a.yload[((size_t)r * T + t) * k + c0 + u] = s4[u] * flip[c0 + u];
+            }
+    }
+#undef SD_YL
     if (a.Afrag) {
         const int g = r / a.lay.n, rr = r % a.lay.n;
         double* A = a.Afrag + (size_t)g * a.group_stride;
@@ -976,10 +1094,14 @@ void k_sd_final(SdArgs a)
         }
     }
     if (a.Vd) {
+        // dense, one row per component: scattered through the wave's LDS buffer (every entry written: no memset, no
+        // global atomics)
         double* V = a.Vd + (size_t)r * k * S;
-        for (int idx = lane; idx < S * k; idx += 64) {
-            const int c = idx / S, p = idx - c * S;
-            if (xs[p] >= 0) atomicAdd(V + (size_t)c * S + xs[p], flip[c] * WD[(size_t)c * S + p]);
+        double* buf = flip + k;
+        for (int c = 0; c < k; ++c) {
+            const double f = flip[c];
+            const double* wdc = WD + (size_t)c * S;
+            sd_scatter(buf, xs, S, lane, V + (size_t)c * S, [&](int p) { return f * wdc[p]; });
         }
     }
 }

@@ -2584,6 +2584,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     SdArgs a;
     memset(&a, 0, sizeof(a));
     a.jacobi_eig = ctx->opt[OPT_SIMPLS_JACOBI] ? 1 : 0;
+    a.weights = scatter ? 1 : 0;
     a.S = S; a.T = T; a.k = k; a.nres = nres;
     a.Yc = ystack ? ystack : ptr<double>(ctx->Y);
     a.y_stride = ystack ? (long long)S * T : 0;
@@ -2661,7 +2662,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
                                nullptr, 0, 0, st))
                 return e;
     }
-    {
+    if (scatter) {          // (permutations: pctvar is all that leaves the solver -- no y-loadings, no weights)
         a.Qs = align_signs ? ptr<double>(ctx->Qs) : nullptr;
         KTimer tm(ctx, KC_SIMPLS, st);
         const size_t lds_f = (size_t)wpb * (k + (a.Vd ? S : 0)) * 8;

@@ -101,6 +101,8 @@ struct SdArgs {
     size_t group_stride;
     GroupLayout lay;
     int jacobi_eig;             // 1: full one-sided Jacobi for the leading eigenpair (round 3) instead of wave_top_eig
+    int weights;                // 1: the dual weights / scores are wanted (bootstraps, decomposition); 0: permutations --
+                                // only pctvar leaves the solver, the Yd c pass and what hangs on it are skipped
 };
 
 // doubles of LDS one wave of k_sd_step needs
@@ -845,25 +847,44 @@ void k_sd_step(SdArgs a)
     double n2 = 0.0, asum = 0.0;
     const __amdgpu_buffer_rsrc_t rsY = sd_rsrc(Y0), rsZ = sd_rsrc(Z0), rsB = sd_rsrc(BT), rsK = sd_rsrc(KB);
     const int rowb = S * 8;
+    const bool wts = a.weights != 0;
     for (int p0 = 0; p0 < S; p0 += SD_TILE) {
         SD_TILE_PC(pc, p0);
         int vo[SD_RC];
         SD_OWN(i) vo[i] = pc[i] * 8;
         double ya[SD_RC], za[SD_RC];
         SD_OWN(i) { ya[i] = 0.0; za[i] = 0.0; }
-        for (int t = 0; t < T; ++t) {
-            const double cvt = cv[t];
-            const int so = t * rowb;
-            double yv[SD_RC], zv[SD_RC];
-            SD_OWN(i) { yv[i] = sd_ld(rsY, vo[i], so); zv[i] = sd_ld(rsZ, vo[i], so); }
-            SD_OWN(i) { ya[i] += yv[i] * cvt; za[i] += zv[i] * cvt; }
-        }
-        for (int j = 0; j < c; ++j) {
-            const double g = gc[j];
-            const int so = j * rowb;
-            double bv[SD_RC], kv[SD_RC];
-            SD_OWN(i) { bv[i] = sd_ld(rsB, vo[i], so); kv[i] = sd_ld(rsK, vo[i], so); }
-            SD_OWN(i) { ya[i] -= bv[i] * g; za[i] -= kv[i] * g; }
+        if (wts) {
+            for (int t = 0; t < T; ++t) {
+                const double cvt = cv[t];
+                const int so = t * rowb;
+                double yv[SD_RC], zv[SD_RC];
+                SD_OWN(i) { yv[i] = sd_ld(rsY, vo[i], so); zv[i] = sd_ld(rsZ, vo[i], so); }
+                SD_OWN(i) { ya[i] += yv[i] * cvt; za[i] += zv[i] * cvt; }
+            }
+            for (int j = 0; j < c; ++j) {
+                const double g = gc[j];
+                const int so = j * rowb;
+                double bv[SD_RC], kv[SD_RC];
+                SD_OWN(i) { bv[i] = sd_ld(rsB, vo[i], so); kv[i] = sd_ld(rsK, vo[i], so); }
+                SD_OWN(i) { ya[i] -= bv[i] * g; za[i] -= kv[i] * g; }
+            }
+        } else {
+            // permutations: t = Z c / s alone (a = Yd c / s only feeds the weights and the scores)
+            for (int t = 0; t < T; ++t) {
+                const double cvt = cv[t];
+                const int so = t * rowb;
+                double zv[SD_RC];
+                SD_OWN(i) zv[i] = sd_ld(rsZ, vo[i], so);
+                SD_OWN(i) za[i] += zv[i] * cvt;
+            }
+            for (int j = 0; j < c; ++j) {
+                const double g = gc[j];
+                const int so = j * rowb;
+                double kv[SD_RC];
+                SD_OWN(i) kv[i] = sd_ld(rsK, vo[i], so);
+                SD_OWN(i) za[i] -= kv[i] * g;
+            }
         }
         int xv[SD_RC];
         SD_OWN(i) xv[i] = xs[pc[i]];
@@ -874,13 +895,14 @@ void k_sd_step(SdArgs a)
                 if (xv[i] >= 0) asum += ya[i];
             }
         }
-        SD_OWN(i) if (SD_IN(p0, i)) { wd[pc[i]] = ya[i]; vt[pc[i]] = za[i]; }
+        if (wts) { SD_OWN(i) if (SD_IN(p0, i)) wd[pc[i]] = ya[i]; }
+        SD_OWN(i) if (SD_IN(p0, i)) vt[pc[i]] = za[i];
     }
     SD_MARK(7);
     const double normt = sqrt(wave_sum(n2));
     const double amean = wave_sum(asum) / ninc;
     double mu = 0.0;
-    for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+    for (int p0 = 0; wts && p0 < S; p0 += SD_TILE) {
         SD_TILE_PC(pc, p0);
         double an[SD_RC];
         SD_OWN(i) {

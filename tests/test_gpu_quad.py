@@ -203,3 +203,70 @@ def test_regression_goldens_on_the_route(which, forced_route):
     assert forced_route.boot_begin(10) == 1
     forced_route.boot_finish(forced_route._zeros((forced_route.B, forced_route.k)),
                              forced_route._zeros((forced_route.B, forced_route.k)))
+
+
+def test_full_size_c3_route_vs_oracle_and_per_bootstrap_pass():
+    """c3 shape (200 x 50 000, 8 cells): 10 bootstraps on the forced route against the oracle, then the series the
+    front-end would run (2000 here) on the route the library picks against the per-bootstrap pass."""
+    from pypyls_amd import resampling as rsmp
+    groups, n_cond = [25, 25, 25, 25], 2
+    S, B = 200, 50000
+    rs = np.random.RandomState(0)
+    cells = rsmp.cell_of_row(groups, n_cond)
+    X = rs.randn(S, B) + 0.25 * rs.randn(8, B)[cells]
+    spec = ref.Spec('meancentered', groups, n_cond, False, 0)
+    Y = spec.dummy.astype(float)
+    U, d, V = ref.decompose(spec, X, Y)
+    live = ref.live_lvs(d)
+    eng = _engine(quad_sums=1)
+    eng.set_data(X, None, cells, len(groups), n_cond, 1, mean_centering=0)
+    eng.set_original(U, np.diag(d), V)
+    n = 10
+    boots = rsmp.gen_bootsamp(groups, n_cond, n, seed=1235)
+    usum, usq, dist = eng.boot(boots)
+    ws, wq = np.zeros_like(U), np.zeros_like(U)
+    for i in range(n):
+        _, ub = ref.single_boot(spec, X, Y, boots[:, i], U, d)
+        ws += ub
+        wq += ub ** 2
+    assert_close_per_lv(usum.cpu().numpy(), ws, 1, 1e-7, what='c3 sum U on the route vs oracle', keep=live)
+    assert_close_per_lv(usq.cpu().numpy(), wq, 1, 1e-7, what='c3 sum U^2 on the route vs oracle', keep=live)
+    many = rsmp.gen_bootsamp(groups, n_cond, 2000, seed=99)
+    out = {}
+    for route, opt in (('auto', 0), ('direct', -1)):
+        eng.set_option('quad_sums', opt)
+        assert eng.boot_begin(2000) == (1 if route == 'auto' else 0)
+        eng.boot_finish(usum, usq)
+        u, q, _ = eng.boot(many)
+        out[route] = (u.cpu().numpy(), q.cpu().numpy())
+    for a, b, what in zip(out['auto'], out['direct'], ('sum U', 'sum U^2')):
+        assert_close_per_lv(a, b, 1, 1e-10, what='c3, 2000 bootstraps, ' + what, keep=live)
+
+
+def test_full_size_c5_route_vs_per_bootstrap_pass():
+    """c5 shape (1000 x 100 000, k = 15): 1200 bootstraps, the route the library picks for that series against the
+    per-bootstrap pass (which test_config_c5_regression_1000x100000 pins on the oracle): sums and standard errors."""
+    from pypyls_amd import resampling as rsmp
+    S, B, T, k = 1000, 100000, 20, 15
+    rs = np.random.RandomState(2)
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.3 * X[:, :T]
+    Xc, Yc = X - X.mean(0), Y - Y.mean(0)
+    boots = rsmp.gen_bootsamp([S], 1, 1200, seed=7, verbose=False)
+    out = {}
+    for route, opt in (('auto', 0), ('direct', -1)):
+        eng = _engine(quad_sums=opt)
+        eng.set_data_regression(Xc, Yc, k)
+        W, pct, cvec, _ = eng.simpls_decompose()
+        W = W * np.sign(W[np.argmax(np.abs(W), axis=0), np.arange(k)])
+        eng.simpls_set_original(W)
+        assert eng.boot_begin(1200) == (1 if route == 'auto' else 0)
+        u, q, yl = eng.simpls_boot(boots)
+        out[route] = (u.cpu().numpy(), q.cpu().numpy(), yl)
+        del eng
+    assert_close_per_lv(out['auto'][0], out['direct'][0], 1, 1e-10, what='c5 sum of weights')
+    assert_close_per_lv(out['auto'][1], out['direct'][1], 1, 1e-10, what='c5 sum of squared weights')
+    assert_close(out['auto'][2], out['direct'][2], 1e-12, what='c5 y_loadings')
+    n = 1200
+    se = [np.sqrt(np.abs(q - u ** 2 / n) / (n - 1)) for u, q, _ in (out['auto'], out['direct'])]
+    np.testing.assert_allclose(se[0], se[1], rtol=1e-8)

@@ -8,8 +8,8 @@ run c4_strong --mode strong --steps 3 --warmup 1
 run c4_strong_emulation --mode strong --steps 2 --warmup 1 --emulate-world 1,2,4,8 --cpu-sample 0
 run c2 --config c2 --steps 10 --warmup 2
 run c3 --config c3 --steps 5 --warmup 2
-run c5 --config c5 --steps 5 --warmup 2
-run c5_full --config c5 --perms 5000 --boots 5000 --steps 2 --warmup 1 --cpu-sample 0
+run c5 --config c5 --steps 3 --warmup 1
+run c5_1000 --config c5 --perms 1000 --boots 1000 --steps 5 --warmup 2 --cpu-sample 0
 run c4split --config c4split --steps 3 --warmup 1
 run analysis_c4_emulation --mode analysis --steps 3 --emulate-world 1,2,4,8
 run analysis_c2 --mode analysis --config c2 --steps 5

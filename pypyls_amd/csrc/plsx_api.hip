@@ -920,7 +920,9 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
     nchunk = std::min(nchunk, std::max(1, K / 256));
     a.kchunk = round_up(ceil_div(K, nchunk), NT_KB);
     nchunk = ceil_div(K, a.kchunk);
-    const size_t bytes = (size_t)nchunk * batch * 2 * tiles * 4096 * 8;
+    const bool direct = nchunk == 1 && !B2 && !a.sym && !accumulate;
+    a.Cd = direct ? C1 : nullptr; a.strideCd = strideC1; a.ldcd = ldc1;
+    const size_t bytes = direct ? 0 : (size_t)nchunk * batch * 2 * tiles * 4096 * 8;
     if (int e = ensure(ctx, ctx->part, bytes)) return e;
     a.part = ptr<double>(ctx->part);
     if (ctx->timing) ctx->nt_flops += 2.0 * Ma * (double)(N1 + (B2 ? N2 : 0)) * K * batch * (a.sym ? 0.5 : 1.0);
@@ -932,6 +934,7 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
         hipLaunchKernelGGL(k_nt_gemm<1>, dim3(nchunk, tiles, batch), dim3(256), 0, st, a);
     }
     LAUNCHCHK();
+    if (direct) return 0;
     {
         dim3 g(ceil_div(Ma * N1, 256), batch);
         hipLaunchKernelGGL(k_reduce_part, g, dim3(256), 0, st, a.part, nchunk, batch, a.mtiles,

@@ -1304,6 +1304,11 @@ struct NtArgs {
     double* part;     // [nchunk][batch][2][mtiles*ntiles][64*64]
     int batch;
     int sym;          // 1: A == B1 (C symmetric): blocks wholly below the diagonal are skipped, k_reduce_part mirrors
+    // single contraction chunk, one product, not symmetric: the block owns its output tile and stores it itself
+    // (no partial tiles, no k_reduce_part pass: W = A K of the dual routes is 164 MB of partials at c3)
+    double* Cd;       // or nullptr
+    long long strideCd;
+    int ldcd;
 };
 
 // RM = 64-row output tiles per block (1 or 2).  With RM = 2 a wave owns 32 rows x 64 columns: two
@@ -1400,6 +1405,17 @@ void k_nt_gemm(NtArgs a)
         const int rowb = (wave * RW + r) * 16;                 // row of the block
         const int tm = tmb * RM + rowb / 64;                     // 64-row output tile
         if (tm >= a.mtiles) continue;
+        if (a.Cd) {
+            double* Cb = a.Cd + (size_t)b * a.strideCd;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = tm * 64 + (rowb & 63) + (lane >> 4) + 4 * i, n = tn * 64 + nt * 16 + (lane & 15);
+                    if (m < a.Ma && n < a.N1) Cb[(size_t)m * a.ldcd + n] = acc1[r][nt][i];
+                }
+            continue;
+        }
         const int tile = tm * a.ntiles + tn;
         double* out = a.part + ((((size_t)chunk * a.batch + b) * 2) * tiles + tile) * 4096;
 #pragma unroll

@@ -952,14 +952,14 @@ int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
 
 // G_r = W_r A_r^T (T' x T') and, with ScT, P_r = A_r Sc (T' x L) of the dual-space routes.  Small T' (mean-centred
 // PLS: T' = cells, a handful): the batched 64 x 64-tile GEMM would multiply (64 / T')^2 x padding -- at c3 (T' = 8)
-// 16 of every 16.3 GFLOP -- so one block per resample takes the T'^2 + T' L dot products over the S positions.
+// 16 of every 16.3 GFLOP -- so one WAVE per resample takes each product as one 16 x 16 tile over the S positions.
 int run_dual_gp(plsx_ctx* ctx, int m, int Sd, const double* ScT, int L, hipStream_t st)
 {
     const int S = ctx->S, Tp = ctx->Tp;
     if (Tp <= 16 && L <= 16) {
         KTimer tm(ctx, KC_NT, st);
-        hipLaunchKernelGGL(k_dual_gp, dim3(m), dim3(256), 0, st, ptr<double>(ctx->Wd), ptr<double>(ctx->Ad), Sd, S, Tp,
-                           ScT, L, ptr<double>(ctx->Gm), ScT ? ptr<double>(ctx->Pm) : nullptr);
+        hipLaunchKernelGGL(k_dual_gp, dim3(ceil_div(m, 4)), dim3(256), 0, st, ptr<double>(ctx->Wd), ptr<double>(ctx->Ad), Sd, S, Tp,
+                           ScT, L, ptr<double>(ctx->Gm), ScT ? ptr<double>(ctx->Pm) : nullptr, m);
         LAUNCHCHK();
         return 0;
     }

@@ -2981,27 +2981,82 @@ __global__ void k_add_splits(const double* __restrict__ psum, const double* __re
 // small helpers
 // ---------------------------------------------------------------------------
 
-// G_r = W_r A_r^T (T' x T'), P_r = A_r ScT^T (T' x L) for T', L <= 16: block = resample, every wave takes output
-// entries in turn, its lanes stride over the S positions (rows of W_r / A_r / ScT of pitch ld; L1 holds the 2 T' rows).
+// C[m][n] = sum_{p < S} A[m][p] B[n][p] on ONE wavefront with the fp64 matrix instruction: MTL x NTL tiles of 16 x 16.
+// The contraction index may meet the four k-slots of an instruction in any order as long as both operands agree, so
+// lane (row = l & 15, q = l >> 4) fetches the FOUR consecutive positions p0 + 4 q .. + 3 of its row per 16-position
+// chunk and feeds them to four successive instructions (slot q of instruction j <-> position p0 + 4 q + j).
+// fa(row, p, v) / fb(row, p, v) fill v[0..3] with the operand's values at (row, p .. p + 3), zeros beyond their
+// extents.  acc[mt][nt][i] <-> C[mt 16 + (l >> 4) + 4 i][nt 16 + (l & 15)].  The dot-product loops these replace
+// (T x T / 4 passes over S for H0, T x k / 4 for the y-loadings) re-read their operands T / 4 times from memory.
+template <int MTL, int NTL, class FA, class FB>
+__device__ __forceinline__ void wave_mfma_nt(d4 (&acc)[MTL][NTL], int S, int lane, FA fa, FB fb)
+{
+    const int row = lane & 15, q = lane >> 4;
+    double a[MTL][4], b[NTL][4], an[MTL][4], bn[NTL][4];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, 4 * q, a[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, 4 * q, b[nt]);
+    for (int p0 = 0; p0 < S; p0 += 16) {
+        const int pn = min(p0 + 16, max(S - 1, 0) & ~15) + 4 * q;      // next chunk (the last one is fetched twice)
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, pn, an[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, pn, bn[nt]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma_f64(a[mt][j], b[nt][j], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[mt][j] = an[mt][j];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[nt][j] = bn[nt][j];
+    }
+}
+
+// G_r = W_r A_r^T (T' x T'), P_r = A_r ScT^T (T' x L) for T', L <= 16: ONE wave per resample, each product one
+// 16 x 16 tile of the matrix pipe over the S positions (rows of W_r / A_r / ScT of pitch ld).  (Round 4, first form:
+// a dot product per output entry and wave -- 0.26 ms per 10 000 resamples at c3, latency bound.)
 __global__ __launch_bounds__(256)
 void k_dual_gp(const double* __restrict__ W, const double* __restrict__ A, int ld, int S, int Tp,
-               const double* __restrict__ ScT, int L, double* __restrict__ G, double* __restrict__ P)
+               const double* __restrict__ ScT, int L, double* __restrict__ G, double* __restrict__ P, int nres)
 {
-    const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nres) return;
     const double* Wr = W + (size_t)r * Tp * ld;
     const double* Ar = A + (size_t)r * Tp * ld;
-    const int nG = Tp * Tp, nP = P ? Tp * L : 0;
-    for (int o = wave; o < nG + nP; o += 4) {
-        const double *x, *y;
-        if (o < nG) { x = Wr + (size_t)(o / Tp) * ld; y = Ar + (size_t)(o % Tp) * ld; }
-        else { const int q = o - nG; x = Ar + (size_t)(q / L) * ld; y = ScT + (size_t)(q % L) * ld; }
-        double s = 0.0;
-        for (int i = lane; i < S; i += 64) s += x[i] * y[i];
+    auto rows = [&](const double* M, int nrows) {
+        return [=](int t, int p, double (&v)[4]) {
+            const double* src = M + (size_t)min(t, nrows - 1) * ld;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) {
-            if (o < nG) G[(size_t)r * nG + o] = s;
-            else P[(size_t)r * nP + (o - nG)] = s;
+            for (int j = 0; j < 4; ++j) {
+                const double x = src[min(p + j, S - 1)];
+                v[j] = (t < nrows && p + j < S) ? x : 0.0;
+            }
+        };
+    };
+    {
+        d4 acc[1][1] = {{(d4){0.0, 0.0, 0.0, 0.0}}};
+        wave_mfma_nt<1, 1>(acc, S, lane, rows(Wr, Tp), rows(Ar, Tp));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t1 = (lane >> 4) + 4 * i, t2 = lane & 15;
+            if (t1 < Tp && t2 < Tp) G[(size_t)r * Tp * Tp + t1 * Tp + t2] = acc[0][0][i];
+        }
+    }
+    if (P) {
+        d4 acc[1][1] = {{(d4){0.0, 0.0, 0.0, 0.0}}};
+        wave_mfma_nt<1, 1>(acc, S, lane, rows(Ar, Tp), rows(ScT, L));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = (lane >> 4) + 4 * i, l = lane & 15;
+            if (t < Tp && l < L) P[(size_t)r * Tp * L + t * L + l] = acc[0][0][i];
         }
     }
 }

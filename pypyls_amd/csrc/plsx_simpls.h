@@ -220,45 +220,6 @@ __device__ __forceinline__ void wave_sum4(double& a, double& b, double& c, doubl
     }
 }
 
-// C[m][n] = sum_{p < S} A[m][p] B[n][p] on ONE wavefront with the fp64 matrix instruction: MTL x NTL tiles of 16 x 16.
-// The contraction index may meet the four k-slots of an instruction in any order as long as both operands agree, so
-// lane (row = l & 15, q = l >> 4) fetches the FOUR consecutive positions p0 + 4 q .. + 3 of its row per 16-position
-// chunk and feeds them to four successive instructions (slot q of instruction j <-> position p0 + 4 q + j).
-// fa(row, p, v) / fb(row, p, v) fill v[0..3] with the operand's values at (row, p .. p + 3), zeros beyond their
-// extents.  acc[mt][nt][i] <-> C[mt 16 + (l >> 4) + 4 i][nt 16 + (l & 15)].  The dot-product loops these replace
-// (T x T / 4 passes over S for H0, T x k / 4 for the y-loadings) re-read their operands T / 4 times from memory.
-template <int MTL, int NTL, class FA, class FB>
-__device__ __forceinline__ void wave_mfma_nt(d4 (&acc)[MTL][NTL], int S, int lane, FA fa, FB fb)
-{
-    const int row = lane & 15, q = lane >> 4;
-    double a[MTL][4], b[NTL][4], an[MTL][4], bn[NTL][4];
-#pragma unroll
-    for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, 4 * q, a[mt]);
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, 4 * q, b[nt]);
-    for (int p0 = 0; p0 < S; p0 += 16) {
-        const int pn = min(p0 + 16, max(S - 1, 0) & ~15) + 4 * q;      // next chunk (the last one is fetched twice)
-#pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) fa(mt * 16 + row, pn, an[mt]);
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt) fb(nt * 16 + row, pn, bn[nt]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) acc[mt][nt] = mfma_f64(a[mt][j], b[nt][j], acc[mt][nt]);
-#pragma unroll
-        for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[mt][j] = an[mt][j];
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[nt][j] = bn[nt][j];
-    }
-}
-
 // H = H0 = Y0^T Z0 (T x T; Y0, Z0 T-major [t][p]) of one resample by its wave.
 template <int TT>
 __device__ __forceinline__ void sd_gram_h(const double* Y0, const double* Z0, int S, int T, int lane, double* H, double* H0)

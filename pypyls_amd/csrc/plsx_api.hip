@@ -1962,6 +1962,8 @@ int quad_accumulate(plsx_ctx* ctx, int m, hipStream_t st)
     return 0;
 }
 
+inline int quad_blocks(int tiles) { return std::max(ceil_div(tiles, 24), tiles >= 8 ? 2 : 1); }
+
 // The closing pass of a series: usum += Xc^T Vsum, usq[j][l] += x_j^T C_l x_j.
 template <int MT>
 int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
@@ -2027,8 +2029,10 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
         LAUNCHCHK();
     }
     // the S rows of a C_l in gpl blocks of MT tiles, as evenly as the instantiated block heights allow
-    const int tiles = ceil_div(S, 16), gpl = ceil_div(tiles, 24);
+    // (at least two blocks once there are 8 tiles: the second one starts its contraction half way down)
+    const int tiles = ceil_div(S, 16), gpl = quad_blocks(tiles);
     const int need = ctx->opt[OPT_QUAD_MT] > 0 ? std::min(24, ctx->opt[OPT_QUAD_MT]) : ceil_div(tiles, gpl);
+    if (need <= 8) return quad_finish_t<8>(ctx, d_usq, ceil_div(tiles, 8), st);
     if (need <= 12) return quad_finish_t<12>(ctx, d_usq, ceil_div(tiles, 12), st);
     if (need <= 16) return quad_finish_t<16>(ctx, d_usq, ceil_div(tiles, 16), st);
     if (need <= 20) return quad_finish_t<20>(ctx, d_usq, ceil_div(tiles, 20), st);
@@ -2885,7 +2889,7 @@ try {
     // per-bootstrap pass: 2 S L B n flop; closing pass 2 S^2 L B (rows of C_l in blocks of 384) + 2 S^2 L n for C
     // on the slower tiled GEMM + its transposes: worth it from n ~ 1.25 x the rows the closing pass multiplies
     // (the closing pass contracts a row block of C_l from its own first row on: ~(1 + 1/blocks) / 2 of S^2)
-    const int tiles_q = ceil_div(S, 16), gpl_q = ceil_div(tiles_q, 24);
+    const int tiles_q = ceil_div(S, 16), gpl_q = quad_blocks(tiles_q);
     const double rows_closing = (double)ceil_div(tiles_q, gpl_q) * gpl_q * 16.0 * 0.5 * (1.0 + 1.0 / gpl_q);
     if (force == 0 && (double)n_total < 1.25 * rows_closing + 64.0) return PLSX_OK;
     const size_t cbytes = (size_t)L * S * S * 8;

@@ -905,7 +905,11 @@ void k_sd_step(SdArgs a)
     // Gram-Schmidt against the previous basis pairs (v_j^T v = (K beta_j)^T beta), twice: the
     // coefficients of four basis vectors are taken together (block Gram-Schmidt: classical
     // inside a block of four, modified across blocks), so a pass is c / 4 reductions deep
-    for (int rep = 0; rep < 2; ++rep)
+    // The second pass is only run when the first one removed more than half of the squared norm (va enters with norm
+    // one): otherwise what the first pass left of the earlier directions is below eps sqrt(2) already (the
+    // re-orthogonalisation criterion of Daniel, Gragg, Kaufman and Stewart).
+    double left = 1.0;
+    for (int rep = 0; rep < 2 && (rep == 0 || left < 0.5); ++rep)
         for (int j0 = 0; j0 < c; j0 += 4) {
             const int j1 = min(j0 + 1, c - 1), j2 = min(j0 + 2, c - 1), j3 = min(j0 + 3, c - 1);
             const double *k0 = KB + (size_t)j0 * S, *k1 = KB + (size_t)j1 * S, *k2 = KB + (size_t)j2 * S,
@@ -924,6 +928,7 @@ void k_sd_step(SdArgs a)
             if (j0 + 1 >= c) cf[1] = 0.0;
             if (j0 + 2 >= c) cf[2] = 0.0;
             if (j0 + 3 >= c) cf[3] = 0.0;
+            double nn = 0.0;
             for (int p0 = 0; p0 < S; p0 += SD_TILE) {
                 SD_TILE_PC(pc, p0);
                 double bb[SD_RC];
@@ -931,9 +936,11 @@ void k_sd_step(SdArgs a)
                     double b = va[pc[i]];
                     b -= cf[0] * b0[pc[i]]; b -= cf[1] * b1[pc[i]]; b -= cf[2] * b2[pc[i]]; b -= cf[3] * b3[pc[i]];
                     bb[i] = b;
+                    nn += SD_IN(p0, i) ? b * b : 0.0;
                 }
                 SD_OWN(i) if (SD_IN(p0, i)) va[pc[i]] = bb[i];
             }
+            if (rep == 0 && j0 + 4 >= c) left = wave_sum(nn);
         }
     SD_MARK(10);
     double bs = 0.0;

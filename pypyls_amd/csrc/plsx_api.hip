@@ -2601,7 +2601,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     // per-resample state, carved out of one scratch buffer (doubles)
     const size_t n = (size_t)nres;
     const size_t per = (size_t)S /* xs, ys as ints share one S-double slot */ + 2 * (size_t)S * T + 4 * (size_t)k * S +
-                       2 * (size_t)S + 2 * (size_t)T * T + 2 * (size_t)k * T + 4;
+                       2 * (size_t)S + 2 * (size_t)T * T + 2 * (size_t)k * T + 4 + (size_t)T;
     const size_t gemm_rows = n * (T + 1);
     if (int e = ensure(ctx, ctx->swork, (n * per + 2 * gemm_rows * S + 64) * 8)) return e;
     double* w = ptr<double>(ctx->swork);
@@ -2619,6 +2619,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     a.H0 = w; w += n * T * T;
     a.G = w; w += n * k * T;
     a.gY0 = w; w += n * k * T;
+    a.ymean = w; w += n * T;
     a.scal = w; w += n * 4;
     a.Wt = w; w += gemm_rows * S;
     a.Zt = w;

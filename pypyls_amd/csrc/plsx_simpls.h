@@ -90,6 +90,7 @@ struct SdArgs {
     double* G;                  // [nres][k][T]  deflation coefficients g_j
     double* gY0;                // [nres][k][T]  (K beta_j)^T Y0
     double* scal;               // [nres][4]: n included, sum Y0^2
+    double* ymean;              // [nres][T]: column means of Y[ys] over the included positions (Y0 = Y[ys] - ymean there)
     double* Wt;                 // GEMM operand rows (vectors in subject space), S doubles each
     double* Zt;                 // GEMM result rows
     double* pctvar;             // [nres][k]   sum(y_loadings^2) / sum(Y0^2)
@@ -159,6 +160,7 @@ void k_sd_init(SdArgs a)
         double part = 0.0;
         for (int p = lane; p < S; p += 64) if (xs[p] >= 0) part += Ysrc[(size_t)ys[p] * T + t];
         const double mean = wave_sum(part) / ninc;
+        if (lane == 0) a.ymean[(size_t)r * T + t] = mean;
         for (int p = lane; p < S; p += 64) {
             const double y = xs[p] >= 0 ? Ysrc[(size_t)ys[p] * T + t] - mean : 0.0;
             Y0[(size_t)t * S + p] = y;
@@ -660,6 +662,9 @@ void k_sd_step(SdArgs a)
     double* G = a.G + (size_t)r * k * T;
     double* gY0 = a.gY0 + (size_t)r * k * T;
     const double ninc = a.scal[(size_t)r * 4], ssY = a.scal[(size_t)r * 4 + 1];
+    const int* ys = a.ys + (size_t)r * S;
+    const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
+    const double* ym = a.ymean + (size_t)r * T;
 
     SD_MARK(0);
     if (c > 0) {
@@ -700,23 +705,30 @@ void k_sd_step(SdArgs a)
             SD_OWN(i) if (SD_IN(p0, i)) { btc[pc[i]] = vv[i]; kbc[pc[i]] = zv[i]; }
         }
         SD_MARK(1);
-        // gY0_cc[t] = sum_p KB_cc[p] Y0[p][t];  m_j = KB_cc . BT_j   (four dot products per pass)
-        for (int t0 = 0; t0 < T; t0 += 4) {
-            const double* y0 = Y0 + (size_t)min(t0, T - 1) * S;
-            const double* y1 = Y0 + (size_t)min(t0 + 1, T - 1) * S;
-            const double* y2 = Y0 + (size_t)min(t0 + 2, T - 1) * S;
-            const double* y3 = Y0 + (size_t)min(t0 + 3, T - 1) * S;
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int p0 = 0; p0 < S; p0 += SD_TILE) {
-                SD_TILE_PC(pc, p0);
-                SD_OWN(i) {
-                    const double kv = kbc[pc[i]], kb = SD_IN(p0, i) ? kv : 0.0;
-                    s4[0] += kb * y0[pc[i]]; s4[1] += kb * y1[pc[i]]; s4[2] += kb * y2[pc[i]]; s4[3] += kb * y3[pc[i]];
+        // gY0_cc[t] = sum_p KB_cc[p] Y0[p][t];  m_j = KB_cc . BT_j.  Y0[p][t] = Y[ys_p][t] - ymean[t] on the included
+        // positions and KB is zero on the others, so the sum is taken over ROWS of the shared Y (S x T, row-major: 8 T
+        // contiguous bytes per position, resident in L2 for every resample of the launch) instead of streaming the
+        // resample's own copy of Y0 from HBM: sum_p KB[p] Y[ys_p][t] - ymean[t] sum_p KB[p]
+        {
+            double ksum = 0.0;
+            for (int t0 = 0; t0 < T; t0 += 8) {
+                double g8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int p0 = 0; p0 < S; p0 += SD_TILE) {
+                    SD_TILE_PC(pc, p0);
+                    SD_OWN(i) {
+                        const double kv = kbc[pc[i]], kb = SD_IN(p0, i) ? kv : 0.0;
+                        const double* yr = Ysrc + (size_t)ys[pc[i]] * T + t0;
+                        if (t0 == 0) ksum += kb;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) g8[u] += kb * yr[min(u, T - 1 - t0)];
+                    }
                 }
+                wave_sum4(g8[0], g8[1], g8[2], g8[3]);
+                wave_sum4(g8[4], g8[5], g8[6], g8[7]);
+                if (t0 == 0) ksum = wave_sum(ksum);
+                if (lane == 0)
+                    for (int u = 0; u < 8 && t0 + u < T; ++u) gv[t0 + u] = g8[u] - ym[t0 + u] * ksum;
             }
-            wave_sum4(s4[0], s4[1], s4[2], s4[3]);
-            if (lane == 0)
-                for (int u = 0; u < 4 && t0 + u < T; ++u) gv[t0 + u] = s4[u];
         }
         for (int j0 = 0; j0 < cc; j0 += 4) {
             const double* b0 = BT + (size_t)min(j0, cc - 1) * S;
@@ -809,6 +821,8 @@ void k_sd_step(SdArgs a)
     const __amdgpu_buffer_rsrc_t rsY = sd_rsrc(Y0), rsZ = sd_rsrc(Z0), rsB = sd_rsrc(BT), rsK = sd_rsrc(KB);
     const int rowb = S * 8;
     const bool wts = a.weights != 0;
+    double ymcv = 0.0;                         // ymean . c (every lane: T reads of the wave's LDS / its own means)
+    for (int t = 0; t < T; ++t) ymcv += ym[t] * cv[t];
     for (int p0 = 0; p0 < S; p0 += SD_TILE) {
         SD_TILE_PC(pc, p0);
         int vo[SD_RC];
@@ -816,12 +830,20 @@ void k_sd_step(SdArgs a)
         double ya[SD_RC], za[SD_RC];
         SD_OWN(i) { ya[i] = 0.0; za[i] = 0.0; }
         if (wts) {
+            // Yd c: rows of the shared Y again (see the closing half), Z c: the resample's own Z0, T-major
+            int yo[SD_RC];
+            SD_OWN(i) yo[i] = ys[pc[i]] * T;
             for (int t = 0; t < T; ++t) {
                 const double cvt = cv[t];
                 const int so = t * rowb;
                 double yv[SD_RC], zv[SD_RC];
-                SD_OWN(i) { yv[i] = sd_ld(rsY, vo[i], so); zv[i] = sd_ld(rsZ, vo[i], so); }
+                SD_OWN(i) { yv[i] = Ysrc[(size_t)yo[i] + t]; zv[i] = sd_ld(rsZ, vo[i], so); }
                 SD_OWN(i) { ya[i] += yv[i] * cvt; za[i] += zv[i] * cvt; }
+            }
+            {
+                int xq[SD_RC];
+                SD_OWN(i) xq[i] = xs[pc[i]];
+                SD_OWN(i) ya[i] = xq[i] >= 0 ? ya[i] - ymcv : 0.0;
             }
             for (int j = 0; j < c; ++j) {
                 const double g = gc[j];

@@ -19,7 +19,7 @@ rs = np.random.RandomState(0)
 S, B, T, k = 1000, 100000, 20, 15
 X = rs.randn(S, B)
 Y = rs.randn(S, T) + 0.3 * X[:, :T]
-pls.pls_regression(X, Y, n_components=k, n_perm=32, n_boot=32, seed=1, verbose=False)
+pls.pls_regression(X, Y, n_components=k, n_perm=n_perm, n_boot=n_boot, seed=1, verbose=False)      # (same sizes: scratch mapped)
 acc = {}
 
 

@@ -1346,19 +1346,22 @@ void k_nt_gemm(NtArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc1[r][i] = (d4){0, 0, 0, 0}; acc2[r][i] = (d4){0, 0, 0, 0}; }
 
-    for (int kk = k0; kk < k1; kk += NT_KB) {
+    // The next stage's operands are fetched into registers while the current one is multiplied (the stage loop was
+    // load -> barrier -> multiply -> barrier: a block's loads only overlapped OTHER blocks' products).
+    d2 ra[4 * RM], rb1[4], rb2[4];
+    auto fetch = [&](int kk) {
         const int c = kk + seg * 2;
 #pragma unroll
         for (int i = 0; i < 4 * RM; ++i) {
             const int rl = rbase + 16 * i;
             d2 va = (d2){0, 0};
-            const int ra = tmb * (RM * 64) + rl;
-            if (ra < a.Ma) {
-                const double* p = Ab + (size_t)ra * a.lda + c;
+            const int ra_ = tmb * (RM * 64) + rl;
+            if (ra_ < a.Ma) {
+                const double* p = Ab + (size_t)ra_ * a.lda + c;
                 if (c + 1 < k1) va = *reinterpret_cast<const d2*>(p);
                 else if (c < k1) va = (d2){p[0], 0.0};
             }
-            *reinterpret_cast<d2*>(&sA[rl * NT_LD + seg * 2]) = va;
+            ra[i] = va;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1375,10 +1378,21 @@ void k_nt_gemm(NtArgs a)
                 if (c + 1 < k1) v2 = *reinterpret_cast<const d2*>(p);
                 else if (c < k1) v2 = (d2){p[0], 0.0};
             }
-            *reinterpret_cast<d2*>(&sB1[rl * NT_LD + seg * 2]) = v1;
-            if (two) *reinterpret_cast<d2*>(&sB2[rl * NT_LD + seg * 2]) = v2;
+            rb1[i] = v1;
+            rb2[i] = v2;
+        }
+    };
+    if (k0 < k1) fetch(k0);
+    for (int kk = k0; kk < k1; kk += NT_KB) {
+#pragma unroll
+        for (int i = 0; i < 4 * RM; ++i) *reinterpret_cast<d2*>(&sA[(rbase + 16 * i) * NT_LD + seg * 2]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<d2*>(&sB1[(rbase + 16 * i) * NT_LD + seg * 2]) = rb1[i];
+            if (two) *reinterpret_cast<d2*>(&sB2[(rbase + 16 * i) * NT_LD + seg * 2]) = rb2[i];
         }
         __syncthreads();
+        if (kk + NT_KB < k1) fetch(kk + NT_KB);
 #pragma unroll
         for (int ks = 0; ks < NT_KB / 4; ++ks) {
             const int off = (lane & 15) * NT_LD + ks * 4 + (lane >> 4);

@@ -2894,8 +2894,9 @@ try {
     const double rows_closing = (double)ceil_div(tiles_q, gpl_q) * gpl_q * 16.0 * 0.5 * (1.0 + 1.0 / gpl_q);
     if (force == 0 && (double)n_total < 1.25 * rows_closing + 64.0) return PLSX_OK;
     const size_t cbytes = (size_t)L * S * S * 8;
-    // (S > 4096: the partial tiles of the batched S x S products alone would take > 2 GB)
-    if (S > 4096 || cbytes > (size_t)(0.25 * ctx->scratch_gb * 1073741824.0)) return PLSX_OK;
+    // (C_l itself and the partial tiles of the batched S x S products, 2 x 64 x 64 doubles per tile and LV)
+    const size_t pbytes = (size_t)L * round_up(S, 64) * round_up(S, 64) * 16;
+    if (cbytes + pbytes > (size_t)(0.25 * ctx->scratch_gb * 1073741824.0)) return PLSX_OK;
     if (int e = ensure(ctx, ctx->Cq, cbytes)) return e;
     if (int e = ensure(ctx, ctx->Vsumq, (size_t)L * S * 8)) return e;
     HIPCHK(hipMemsetAsync(ctx->Cq.p, 0, cbytes, st));

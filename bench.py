@@ -656,7 +656,7 @@ class SplitHalf(object):
 
 def run_analysis(args, real_stdout):
     """--mode analysis: END-TO-END wall time of the PUBLIC front-end call (the counterpart of BasePLS.run_pls,
-    pyls/base.py:341-399 + behavioral.py:197-227) at --config c4 / c2 / c3 with --perms + --boots resamples
+    pyls/base.py:341-399 + behavioral.py:197-227) at --config c4 / c2 / c3 / c5 with --perms + --boots resamples
     (default: the literal 10 000 + 10 000; --splits S adds split-half with n_split = S): index generation,
     H2D of X, binding, original decomposition, resampling, THE collective, percentile intervals, bootstrap
     ratios and the D2H of what PLSResults holds -- everything the resampling-step modes leave out.  A fresh
@@ -685,10 +685,16 @@ def run_analysis(args, real_stdout):
         X = rs.randn(200, 50000)
         call = lambda **kw: pls.meancentered_pls(X, groups=groups, n_cond=n_cond, verbose=False, **kw)
         desc = 'meancentered_pls X(200x50000) groups=[25]*4 n_cond=2 fp64'
+    elif cfg == 'c5':
+        X, Y = synth(1000, 100000, 20)
+        call = lambda **kw: pls.pls_regression(X, Y, n_components=15, verbose=False, **kw)
+        desc = 'pls_regression (SIMPLS) X(1000x100000) Y(1000x20) n_components=15 fp64'
+        if args.emulate_world or args.splits:
+            raise SystemExit('--mode analysis --config c5: no --emulate-world / --splits (the regression front-end has neither)')
     else:
-        raise SystemExit('--mode analysis supports --config c4 | c2 | c3')
-    n_perm = args.perms or (5000 if cfg == 'c2' else 10000)
-    n_boot = args.boots or (5000 if cfg == 'c2' else 10000)
+        raise SystemExit('--mode analysis supports --config c4 | c2 | c3 | c5')
+    n_perm = args.perms or (5000 if cfg in ('c2', 'c5') else 10000)
+    n_boot = args.boots or (5000 if cfg in ('c2', 'c5') else 10000)
     extra = {'n_split': args.splits} if args.splits else {}
     call(n_perm=64, n_boot=64, seed=1)                      # warm-up
     worlds = sorted({1} | {int(v) for v in args.emulate_world.split(',') if v.strip()}) if args.emulate_world else [1]

@@ -164,16 +164,27 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     draws = resampling.DrawThread(rs, jobs).start()
     try:
         return _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
-                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'))
+                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'), kwargs.get('_phases'))
     finally:
         draws.thread.join()
 
 
 def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,
-                bootsamples_out, k, ci, engine):
+                bootsamples_out, k, ci, engine, phases=None):
+    import time
     import torch
     from .engine import default_engine
     S = len(X)
+    t_last = [time.perf_counter()]
+
+    def tick(name):                                     # per-phase wall times (bench.py --mode analysis)
+        if phases is None:
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        phases[name] = phases.get(name, 0.0) + 1e3 * (now - t_last[0])
+        t_last[0] = now
+
     # regression.py:395-397 (on copies: the reference centres the caller's X in place)
     Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
     B, T = X.shape[1], Yc.shape[1]
@@ -198,6 +209,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         if masked:
             eng.simpls_set_row_masks(okx, oky)
     res = PLSResults(inputs=inputs)
+    tick('h2d_and_bind')
 
     W, pctvar, cvec, _ = eng.simpls_decompose()
     # sign rule of compute.svd: on r (prop. to the x_weights column) when B > T,
@@ -213,6 +225,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     x_scores[~okx] = np.nan                                        # NaN rows stay NaN (X @ W)
     res['x_scores'] = x_scores
     rank, world = parallel.rank_world()
+    tick('decompose')
 
     # this rank's shards (permutations contiguous, bootstraps chunk-cyclic), launched chunk by chunk as the index rows arrive; the
     # results stay on the device until the one collective
@@ -224,6 +237,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         d_perm = eng._zeros((hi - lo, k))
         for a, b in pstream.chunks(lo, hi):
             eng.simpls_perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - lo:b - lo])
+    tick('permutations')
     if bstream is not None:
         bchunks = parallel.shard_chunks(n_boot_tot, rank, world)     # chunk-cyclic share of the bootstraps
         usum, usq = eng._zeros((B, k)), eng._zeros((B, k))
@@ -245,6 +259,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
                                      d_yl[off + a - lo:off + b - lo], ystack=ystack)
             off += hi - lo
         eng.boot_finish(usum, usq)
+    tick('bootstraps')
     permsamp = bootsamp = None
     if pstream is not None:
         permsamp = np.asarray(permsamples) if permsamples is not None else pstream.samples
@@ -261,6 +276,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
                                            cyclic=[len(slices) - 1] if d_yl is not None else [])
     if usum is not None:
         usum, usq = summed
+    tick('collective')
     i = 0
     d_perm = distrib = None
     if pstream is not None:
@@ -286,4 +302,5 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
             y_loadings_ci=np.stack(eng.percentile_ci(distrib, ci=ci), -1),
             bootsamples=bootsamples_out if third is not None else bootsamp))
     res['varexp'] = pctvar                                          # regression.py:425-426
+    tick('host_finish')
     return res

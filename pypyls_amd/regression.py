@@ -235,7 +235,9 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     if pstream is not None:
         lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
         d_perm = eng._zeros((hi - lo, k))
-        for a, b in pstream.chunks(lo, hi):
+        # (a solver batch is a latency chain of ~3 k launches whatever its size: few, large chunks -- the first 2048 rows
+        # are drawn in 5 ms)
+        for a, b in pstream.chunks(lo, hi, first=2048):
             eng.simpls_perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - lo:b - lo])
     tick('permutations')
     if bstream is not None:
@@ -245,7 +247,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         off = 0
         eng.boot_begin(sum(hi - lo for lo, hi in bchunks))     # (plsx_boot_begin: the feature pass may move to boot_finish)
         for lo, hi in bchunks:
-            for a, b in bstream.chunks(lo, hi, first=256, grow=4 if third is None else 1,
+            for a, b in bstream.chunks(lo, hi, first=2048 if third is None else 256, grow=4 if third is None else 1,
                                        limit=None if third is None else 256):
                 ystack = None
                 if third is not None:

@@ -2892,7 +2892,10 @@ try {
     // (the closing pass contracts a row block of C_l from its own first row on: ~(1 + 1/blocks) / 2 of S^2)
     const int tiles_q = ceil_div(S, 16), gpl_q = quad_blocks(tiles_q);
     const double rows_closing = (double)ceil_div(tiles_q, gpl_q) * gpl_q * 16.0 * 0.5 * (1.0 + 1.0 / gpl_q);
-    if (force == 0 && (double)n_total < 1.25 * rows_closing + 64.0) return PLSX_OK;
+    // ... and S^2 L n for the C_l on the tiled GEMM (symmetric half, at about half the matrix rate): S n / B in the same
+    // units (rows of a pass over the B features) -- with few features the per-bootstrap pass is the cheaper one
+    const double per_boot = 1.0 - 1.25 * (double)S / std::max(ctx->B, 1);
+    if (force == 0 && (per_boot <= 0.0 || (double)n_total * per_boot < 1.25 * rows_closing + 64.0)) return PLSX_OK;
     const size_t cbytes = (size_t)L * S * S * 8;
     // (C_l itself and the partial tiles of the batched S x S products, 2 x 64 x 64 doubles per tile and LV)
     const size_t pbytes = (size_t)L * round_up(S, 64) * round_up(S, 64) * 16;

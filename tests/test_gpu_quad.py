@@ -97,9 +97,14 @@ def test_route_choice():
     eng = _engine()
     eng.set_data(X, None, cells, len(groups), n_cond, 1, mean_centering=0)
     eng.set_original(U, np.diag(d), V)
-    assert eng.boot_begin(100) == 0 and eng.boot_begin(203) == 0 and eng.boot_begin(204) == 1          # S = 111: 7 tiles, one block
+    assert eng.boot_begin(100) == 0 and eng.boot_begin(222) == 0 and eng.boot_begin(223) == 1          # S = 111 (7 tiles, one block), B = 1700
     eng.set_original(U, np.diag(d), V)                                    # ends the open series
     assert eng.lib.plsx_boot_route(eng.ctx) == 0
+    few = _engine()                                                       # few features: the S x S moments cost more than they save
+    few.set_data(X[:, :120], None, cells, len(groups), n_cond, 1, mean_centering=0)
+    Uf, df, Vf = ref.decompose(spec, X[:, :120], spec.dummy.astype(float))
+    few.set_original(Uf, np.diag(df), Vf)
+    assert few.boot_begin(100000) == 0
     Xb = rs.randn(40, 500)
     Yb = rs.randn(40, 4)
     specb = ref.Spec('behavioral', [40], 1, False, 0)

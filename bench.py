@@ -689,8 +689,8 @@ def run_analysis(args, real_stdout):
         X, Y = synth(1000, 100000, 20)
         call = lambda **kw: pls.pls_regression(X, Y, n_components=15, verbose=False, **kw)
         desc = 'pls_regression (SIMPLS) X(1000x100000) Y(1000x20) n_components=15 fp64'
-        if args.emulate_world or args.splits:
-            raise SystemExit('--mode analysis --config c5: no --emulate-world / --splits (the regression front-end has neither)')
+        if args.splits:
+            raise SystemExit('--mode analysis --config c5: no --splits (pls_regression has no split-half)')
     else:
         raise SystemExit('--mode analysis supports --config c4 | c2 | c3 | c5')
     n_perm = args.perms or (5000 if cfg in ('c2', 'c5') else 10000)

@@ -164,13 +164,14 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     draws = resampling.DrawThread(rs, jobs).start()
     try:
         return _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
-                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'), kwargs.get('_phases'))
+                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'), kwargs.get('_phases'),
+                           kwargs.get('_emulate'))
     finally:
         draws.thread.join()
 
 
 def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,
-                bootsamples_out, k, ci, engine, phases=None):
+                bootsamples_out, k, ci, engine, phases=None, emulate=None):
     import time
     import torch
     from .engine import default_engine
@@ -224,7 +225,9 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     x_scores = eng.project(W)                                      # X already centred
     x_scores[~okx] = np.nan                                        # NaN rows stay NaN (X @ W)
     res['x_scores'] = x_scores
-    rank, world = parallel.rank_world()
+    # emulate = (rank, world) of an emulated run on one GPU (bench.py --mode analysis --emulate-world): own shard, the
+    # all-gather replaced by a surrogate of the same volume (parallel._surrogate_gather)
+    rank, world = emulate if emulate is not None else parallel.rank_world()
     tick('decompose')
 
     # this rank's shards (permutations contiguous, bootstraps chunk-cyclic), launched chunk by chunk as the index rows arrive; the
@@ -274,8 +277,9 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     eng.sync()                     # numerical status of the launches above is raised here
     slices = [t for t in (d_perm, d_yl) if t is not None]
     totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
-    full, summed = parallel.collect_slices(slices, totals, [usum, usq] if usum is not None else [],
+    full, summed = parallel.collect_device(slices, totals, [usum, usq] if usum is not None else [], emulate=emulate,
                                            cyclic=[len(slices) - 1] if d_yl is not None else [])
+    full = [t.detach().cpu().numpy() for t in full]
     if usum is not None:
         usum, usq = summed
     tick('collective')

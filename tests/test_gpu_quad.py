@@ -94,13 +94,13 @@ def test_route_choice():
     X, Y, groups, n_cond, mc, method, spec = _case('mc0', rs)
     cells = rsmp.cell_of_row(groups, n_cond)
     U, d, V = ref.decompose(spec, X, spec.dummy.astype(float))
-    eng = _engine()
+    eng = _engine(quad_sums=0)                                            # (the library's own choice, whatever the environment says)
     eng.set_data(X, None, cells, len(groups), n_cond, 1, mean_centering=0)
     eng.set_original(U, np.diag(d), V)
     assert eng.boot_begin(100) == 0 and eng.boot_begin(222) == 0 and eng.boot_begin(223) == 1          # S = 111 (7 tiles, one block), B = 1700
     eng.set_original(U, np.diag(d), V)                                    # ends the open series
     assert eng.lib.plsx_boot_route(eng.ctx) == 0
-    few = _engine()                                                       # few features: the S x S moments cost more than they save
+    few = _engine(quad_sums=0)                                            # few features: the S x S moments cost more than they save
     few.set_data(X[:, :120], None, cells, len(groups), n_cond, 1, mean_centering=0)
     Uf, df, Vf = ref.decompose(spec, X[:, :120], spec.dummy.astype(float))
     few.set_original(Uf, np.diag(df), Vf)

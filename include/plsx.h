@@ -177,7 +177,8 @@ int plsx_boot_batch(plsx_ctx* ctx, const int32_t* d_boot_idx, int n,
  * Where the rotated bootstrap weights are linear in the bound, unscaled feature matrix -- U_b = Xc^T V_b with V_b
  * (S x L) known in dual space: mean-centred PLS and covariance-mode behavioral PLS (single-pass route), SIMPLS --
  *   sum_b U_b = Xc^T (sum_b V_b),     sum_b U_b[j,l]^2 = x_j^T C_l x_j,     C_l = sum_b v_bl v_bl^T   (S x S)
- * so a series of n_total >~ 1.25 S bootstraps (and B well above S features) accumulates C_l (a batched S x S product per batch) and passes the
+ * so a series of n_total >~ 0.85 S .. 1.25 S bootstraps (the closing pass uses the symmetry of C_l in row blocks;
+ * B well above S features) accumulates C_l (a batched S x S product per batch) and passes the
  * features ONCE, in plsx_boot_finish (2 S^2 L B flop), instead of once per bootstrap (2 S L B n_total): the same
  * sums to rounding.  Between begin and finish of such a series the batches do NOT touch d_usum / d_usq
  * (plsx_boot_route() = 1); d_distrib / d_yload are written per batch as ever.  Without plsx_boot_begin, for short

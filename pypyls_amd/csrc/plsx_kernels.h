@@ -92,7 +92,7 @@ __device__ __forceinline__ double sd_rsqrt(double x)
 
 // Column means of X (S x B, ld = B) -> mean[B]; one thread per column, rows
 // summed in order (deterministic).
-__global__ void k_colmean(const double* __restrict__ X, int S, int B, double* __restrict__ mean)
+static __global__ void k_colmean(const double* __restrict__ X, int S, int B, double* __restrict__ mean)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -103,7 +103,7 @@ __global__ void k_colmean(const double* __restrict__ X, int S, int B, double* __
 
 // Xc[i][b] = X[i][b] - mean[b]  into the padded buffer (Kpad x ldx); padding
 // rows / columns are zeroed by a memset beforehand.
-__global__ void k_center_pad(const double* __restrict__ X, const double* __restrict__ mean,
+static __global__ void k_center_pad(const double* __restrict__ X, const double* __restrict__ mean,
                              int S, int B, double* __restrict__ Xc, int ldx)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,7 +116,7 @@ __global__ void k_center_pad(const double* __restrict__ X, const double* __restr
 // un-resampled X enters every per-cell z-score.  Permutations leave X fixed
 // (pyls/base.py:599), so their cross-products can use Xn and skip the moment
 // tiles.  One thread per column, rows visited in order.
-__global__ void k_cell_scale(const double* __restrict__ Xc, int ldx, int B, int J,
+static __global__ void k_cell_scale(const double* __restrict__ Xc, int ldx, int B, int J,
                              const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                              double* __restrict__ Xn)
 {
@@ -166,7 +166,7 @@ struct GroupLayout {
 // z-scoring is over the positions of cell j that the resample keeps
 // (pyls/compute.py:83-87 applied per cell, behavioral.py:49-52).
 // grid (n_resamples, J), block 256.  dynamic LDS: 2*Tn doubles.
-__global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_stride, int T, int S,
+static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_stride, int T, int S,
                                 const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                                 const int* __restrict__ xsrc, const int* __restrict__ ysrc,
                                 GroupLayout lay, int covariance, int scaled,
@@ -291,7 +291,7 @@ __global__ void k_build_A_behav(const double* __restrict__ Y0, long long y_strid
 // Mean-centred PLS: A = (cell-averaging - reference-averaging) weights, so
 // that A . X = cell means minus the mean_centering reference mean
 // (pyls/compute.py:267-357 with means=True).  grid (n_resamples), block 256.
-__global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
+static __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
                              const int* __restrict__ cell_of_pos,
                              const int* __restrict__ xsrc, GroupLayout lay,
                              double* __restrict__ Afrag, size_t group_stride, int dense_ld = 0)
@@ -345,7 +345,7 @@ __device__ __forceinline__ size_t mfrag_index(int t, int l, int nks_t, int LT)
     return (size_t)chunk * PLSX_LT_CHUNK * nks_t * 64 + ((size_t)(t >> 2) * ltc + lt) * 64 + (t & 3) * 16 + (l & 15);
 }
 
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_build_W(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
                const double* __restrict__ Mfrag, int nks_t, int LT, int npg_w, int MT,
                double* __restrict__ Afrag, size_t group_stride)
@@ -376,7 +376,7 @@ void k_build_W(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
 }
 
 // The same W_r = A_r^T M_r, dense: Vd[r][l * S + i] (the quadratic-form route of the bootstrap sums, k_quad_* below).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_build_Vd(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
                 const double* __restrict__ Mfrag, int nks_t, int LT, double* __restrict__ Vd)
 {
@@ -406,7 +406,7 @@ void k_build_Vd(const double* __restrict__ Adense, int ld, int S, int Tp, int L,
 
 // Column sums of Xc and Xc^2 per cell: S1[j][b], S2[j][b] (full-sample moments
 // the fused split-half epilogue subtracts the first half's from).
-__global__ void k_cell_moments(const double* __restrict__ Xc, int ldx, int B, int J,
+static __global__ void k_cell_moments(const double* __restrict__ Xc, int ldx, int B, int J,
                                const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                                double* __restrict__ S1, double* __restrict__ S2)
 {
@@ -460,7 +460,7 @@ struct SplitEpi {
 };
 
 // grid (n_splits, J), block 256 = 64 behaviours x 4 quarters of the cell's rows.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_build_A_split(const double* __restrict__ Y, int T, int S,
                      const int* __restrict__ cell_start, const int* __restrict__ cell_len,
                      const int* __restrict__ perm, const uint8_t* __restrict__ masks,
@@ -566,7 +566,7 @@ void k_build_A_split(const double* __restrict__ Y, int T, int S,
 
 // Compact bootstraps: mask[r][s] = 1 when resample r draws source row s (mask zeroed by the caller).
 // grid (ceil(S / 256), n_resamples).
-__global__ void k_drawn_mask(const int* __restrict__ xsrc, int S, uint8_t* __restrict__ mask)
+static __global__ void k_drawn_mask(const int* __restrict__ xsrc, int S, uint8_t* __restrict__ mask)
 {
     const int r = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= S) return;
@@ -578,7 +578,7 @@ __global__ void k_drawn_mask(const int* __restrict__ xsrc, int S, uint8_t* __res
 // index of position p in the split's own cross-product block), row_tab[split][k] = the position of
 // rank k (the X row that block loads at contraction index k; padding entries -> row 0, whose A
 // column is zero).  grid (n_splits), block 64.
-__global__ void k_split_rank(const uint8_t* __restrict__ masks, int S, int ktot,
+static __global__ void k_split_rank(const uint8_t* __restrict__ masks, int S, int ktot,
                              int* __restrict__ rank, int* __restrict__ row_tab, int* __restrict__ row_cnt)
 {
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -1918,7 +1918,7 @@ void k_gram4(const double* __restrict__ R, long long strideR, int ldr, int Tp,
 }
 
 // C[b][m][n] = sum_chunk part[...]; which = 0/1 selects the first / second product.
-__global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
+static __global__ void k_reduce_part(const double* __restrict__ part, int nchunk, int batch,
                               int mtiles, int ntiles, int which,
                               double* __restrict__ C, long long strideC, int ldc, int M, int N, int sym,
                               int accumulate = 0)
@@ -2574,7 +2574,7 @@ void k_small(SmallArgs a)
 // Only graded data ever gets here (blocks of resamples that are not parked return at once): plain fp64
 // VALU code, 64 columns per step -- stage 1: wave w forms rows [16 w, 16 w + 16) of Y for one column per
 // lane (V broadcast from LDS); stage 2 / 3: 4 x 4 register tiles of G' and Y U0 over the 64 columns in LDS.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int B, int n,
                    const double* __restrict__ refV, const int* __restrict__ refK0,
                    const double* __restrict__ U0T, int ldu, int L,
@@ -2667,7 +2667,7 @@ void k_refine_gram(const double* __restrict__ R, long long strideR, int ldr, int
 // x_weights of the original decomposition (plsx_decompose) after a refinement: column kc (small) minus its
 // components along the large columns, coefficients H (L x L, zero outside large -> small) from k_small phase 2.
 // One thread per feature row.  No-op when the decomposition was not parked.
-__global__ void k_fix_small_cols(double* __restrict__ xw, int B, int L, const double* __restrict__ H,
+static __global__ void k_fix_small_cols(double* __restrict__ xw, int B, int L, const double* __restrict__ H,
                                  const int* __restrict__ refK0)
 {
     if (!refK0[0]) return;
@@ -2980,7 +2980,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
 }
 
 // usum += sum_s psum[s], usq += sum_s psq[s] in split order.
-__global__ void k_add_splits(const double* __restrict__ psum, const double* __restrict__ psq, int nsplit,
+static __global__ void k_add_splits(const double* __restrict__ psum, const double* __restrict__ psq, int nsplit,
                              long long count, double* __restrict__ usum, double* __restrict__ usq)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3037,7 +3037,7 @@ __device__ __forceinline__ void wave_mfma_nt(d4 (&acc)[MTL][NTL], int S, int lan
 // G_r = W_r A_r^T (T' x T'), P_r = A_r ScT^T (T' x L) for T', L <= 16: ONE wave per resample, each product one
 // 16 x 16 tile of the matrix pipe over the S positions (rows of W_r / A_r / ScT of pitch ld).  (Round 4, first form:
 // a dot product per output entry and wave -- 0.26 ms per 10 000 resamples at c3, latency bound.)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_dual_gp(const double* __restrict__ W, const double* __restrict__ A, int ld, int S, int Tp,
                const double* __restrict__ ScT, int L, double* __restrict__ G, double* __restrict__ P, int nres)
 {
@@ -3083,7 +3083,7 @@ void k_dual_gp(const double* __restrict__ W, const double* __restrict__ A, int l
 // bootstrap: 2 S^2 L B flop against 2 S L B n_boot.
 // ---------------------------------------------------------------------------
 // Vsum[row] += sum_b Vt[row][b]: one wave per row, fixed order.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, double* __restrict__ Vsum)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -3099,7 +3099,7 @@ void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, doub
 // Rows s0 .. of C_l (S x S, row-major, symmetric) into the fragment-ordered A operand of group g = block * nl + l:
 // x^T C x = sum over the row blocks of x_blk^T (C[blk, blk] x_blk + 2 C[blk, right of blk] x_right), so a block
 // only holds the columns from its own first row on, the ones right of the diagonal block doubled.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride,
                   int full)
 {
@@ -3118,7 +3118,7 @@ void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* 
 }
 
 // usq[j][l0 + l] += sum over the gpl row blocks g of part[g * nl + l][j], l < nl
-__global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp, int B, int nl, int L, int l0,
+static __global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp, int B, int nl, int L, int l0,
                               double* __restrict__ usq)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3130,7 +3130,7 @@ __global__ void k_quad_finish(const double* __restrict__ part, int gpl, int ldp,
 }
 
 // usum[j][l] += sum_s X[s][j] Vsum[l][s]; thread = feature j, blockIdx.y = chunk of 8 l's.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_xt_vsum(const double* __restrict__ X, int ldx, int S, int B, const double* __restrict__ Vsum, int L,
                double* __restrict__ usum)
 {
@@ -3160,7 +3160,7 @@ void k_xt_vsum(const double* __restrict__ X, int ldx, int S, int B, const double
 }
 
 // dst (C x Rr) = src (Rr x C)^T ; tiled through LDS.
-__global__ void k_transpose(const double* __restrict__ src, int rows, int cols, int lds_,
+static __global__ void k_transpose(const double* __restrict__ src, int rows, int cols, int lds_,
                             double* __restrict__ dst, int ldd)
 {
     __shared__ double tile[32][33];
@@ -3180,7 +3180,7 @@ __global__ void k_transpose(const double* __restrict__ src, int rows, int cols, 
 // of largest magnitude in every column of `lead` (rows x L, row-major) becomes positive; ties go to the lowest
 // row, as numpy.argmax.  Pass 1: column maxima of |lead| (positive doubles order like their bit patterns);
 // pass 2: lowest row that attains it; pass 3 (k_flip_signs): the sign there (0 -> +1).
-__global__ void k_absmax_cols(const double* __restrict__ lead, long long rows, int L, unsigned long long* __restrict__ gmax)
+static __global__ void k_absmax_cols(const double* __restrict__ lead, long long rows, int L, unsigned long long* __restrict__ gmax)
 {
     extern __shared__ unsigned long long sm_mx[];
     for (int k = threadIdx.x; k < L; k += blockDim.x) sm_mx[k] = 0ull;
@@ -3195,7 +3195,7 @@ __global__ void k_absmax_cols(const double* __restrict__ lead, long long rows, i
     for (int k = threadIdx.x; k < L; k += blockDim.x) atomicMax(&gmax[k], sm_mx[k]);
 }
 
-__global__ void k_argmax_rows(const double* __restrict__ lead, long long rows, int L,
+static __global__ void k_argmax_rows(const double* __restrict__ lead, long long rows, int L,
                               const unsigned long long* __restrict__ gmax, unsigned long long* __restrict__ grow)
 {
     const long long total = rows * L, per = 4096LL * L;
@@ -3207,7 +3207,7 @@ __global__ void k_argmax_rows(const double* __restrict__ lead, long long rows, i
     }
 }
 
-__global__ void k_flip_signs(const double* __restrict__ lead, int L, const unsigned long long* __restrict__ grow,
+static __global__ void k_flip_signs(const double* __restrict__ lead, int L, const unsigned long long* __restrict__ grow,
                              double* __restrict__ signs)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3217,7 +3217,7 @@ __global__ void k_flip_signs(const double* __restrict__ lead, int L, const unsig
 }
 
 // out[i][k] = in[i][k] * scale[k]   (rows x cols, row-major; in == out allowed)
-__global__ void k_scale_cols(const double* __restrict__ in, long long count, int cols, const double* __restrict__ scale,
+static __global__ void k_scale_cols(const double* __restrict__ in, long long count, int cols, const double* __restrict__ scale,
                              double* __restrict__ out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3225,7 +3225,7 @@ __global__ void k_scale_cols(const double* __restrict__ in, long long count, int
 }
 
 // out[a][c] = mean_b in[a][b][c], terms added in order of b (NaN propagates, as numpy's mean: base.py:770)
-__global__ void k_mean_axis1(const double* __restrict__ in, int na, int nb, int nc, double* __restrict__ out)
+static __global__ void k_mean_axis1(const double* __restrict__ in, int na, int nb, int nc, double* __restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na * nc) return;
@@ -3236,7 +3236,7 @@ __global__ void k_mean_axis1(const double* __restrict__ in, int na, int nb, int 
 }
 
 // out[r][t][l] = R[r][t][col0 + l]  (bootstrap distrib columns / crosscov copy-out)
-__global__ void k_gather_cols(const double* __restrict__ R, long long strideR, int ldr, int col0,
+static __global__ void k_gather_cols(const double* __restrict__ R, long long strideR, int ldr, int col0,
                               int Tp, int ncol, double* __restrict__ out)
 {
     const int r = blockIdx.y;
@@ -3247,7 +3247,7 @@ __global__ void k_gather_cols(const double* __restrict__ R, long long strideR, i
 }
 
 // compute.boot_rel (pyls/compute.py:212-237)
-__global__ void k_boot_rel(const double* __restrict__ orig, const double* __restrict__ usum,
+static __global__ void k_boot_rel(const double* __restrict__ orig, const double* __restrict__ usum,
                            const double* __restrict__ usq, double n, int add_orig, long long count,
                            double* __restrict__ bsr, double* __restrict__ se)
 {
@@ -3261,7 +3261,7 @@ __global__ void k_boot_rel(const double* __restrict__ orig, const double* __rest
     bsr[i] = o / e;
 }
 
-__global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
+static __global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n * S) dst[i] = i % S;
@@ -3274,7 +3274,7 @@ __global__ void k_iota_rows(int* __restrict__ dst, int n, int S)
 // Source-row tables of the 2*ns half samples of ONE arrangement:
 // slot 2*i + h keeps the positions whose mask equals (h == 0); behavioral PLS
 // permutes Y (ysrc = perm), mean-centred PLS permutes X (xsrc = perm).
-__global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restrict__ masks,
+static __global__ void k_split_src(const int* __restrict__ perm, const uint8_t* __restrict__ masks,
                             int ns, int S, int permute_x, int* __restrict__ xsrc, int* __restrict__ ysrc)
 {
     const int slot = blockIdx.y;
@@ -3462,7 +3462,7 @@ void k_ucorr_partial(const double* __restrict__ R, long long strideR, int ldr, i
 // Final split-half correlations of one split (block = pair):
 //   ucorr[l] from the feature-axis sums; vcorr[l] = Pearson over the T' rows of
 //   F_h = C_h . (V d^-2) with C_h = D_h . R_full^T  (= D_h @ ud, base.py:767).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int lpad,
                    const double* __restrict__ C /* [2*npairs][n][n] */,
                    const double* __restrict__ V /* n x L */, const double* __restrict__ d,
@@ -3523,7 +3523,7 @@ void k_split_final(const double* __restrict__ part, int nchunk, int npairs, int 
 // ---------------------------------------------------------------------------
 
 // Training masks -> source tables (train rows keep their position, test rows -1).
-__global__ void k_cv_src(const uint8_t* __restrict__ masks, int S, int* __restrict__ xsrc)
+static __global__ void k_cv_src(const uint8_t* __restrict__ masks, int S, int* __restrict__ xsrc)
 {
     const int slot = blockIdx.y;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < S; p += gridDim.x * blockDim.x)
@@ -3533,7 +3533,7 @@ __global__ void k_cv_src(const uint8_t* __restrict__ masks, int S, int* __restri
 // Rs[(i*J + j)][t][b] = invstd_{i,j}[b] * R_i[t][b]  and  c[(i*J+j)][t] = sum_b mean_{i,j}[b] * Rs[..][t][b]
 // so that zmap(X_test; X_train_cell_j) @ R_i^T = X_test @ Rs^T - c   (compute.rescale_test,
 // pyls/compute.py:148-149).  grid (T', m*J), one block per output row.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_cv_rescale(const double* __restrict__ R, long long strideR, int ldr, int B, int J, int npg,
                   int nmom_pad, const double* __restrict__ mom_out,
                   double* __restrict__ R2, double* __restrict__ cvec, int Tp, int gps,
@@ -3566,7 +3566,7 @@ void k_cv_rescale(const double* __restrict__ R, long long strideR, int ldr, int 
 // Predictions and scores of one train/test split (block = split).
 //   q = Q[(i*J+j)][:, p] - c ;  z = q^T V / d ;  y_pred = z V_j^T + mean_train_j(Y)
 //   pearson r and r^2 (sklearn r2_score, raw values) per behaviour over the test rows.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_cv_final(const double* __restrict__ Q /* [m*J][Tp][S] */, const double* __restrict__ cvec,
                 const double* __restrict__ V /* [m][Tp][L] */, const double* __restrict__ d /* [m][L] */,
                 const double* __restrict__ Y, const uint8_t* __restrict__ masks,
@@ -3628,7 +3628,7 @@ void k_cv_final(const double* __restrict__ Q /* [m*J][Tp][S] */, const double* _
 // lerp = a + (b - a) g for g < 0.5 and b - (b - a)(1 - g) otherwise (numpy
 // lib/_function_base_impl._lerp).  The virtual indices (i, g) of the two
 // quantiles are computed on the host exactly as numpy does.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_percentile2(const double* __restrict__ data, int n, int npow2,
                    int i_lo, double g_lo, int i_hi, double g_hi,
                    double* __restrict__ out_lo, double* __restrict__ out_hi, const int* __restrict__ only = nullptr)
@@ -3704,7 +3704,7 @@ __device__ __forceinline__ void lds_bitonic(double* v, int P, int tid)
 // Interpolation exactly as k_percentile2 (numpy's _lerp).  One block per series.
 #define PSEL_CAP 2048
 #define PSEL_SAMPLE 1024
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_percentile_sel(const double* __restrict__ data, int n, int i_lo, double g_lo, int i_hi, double g_hi,
                       double* __restrict__ out_lo, double* __restrict__ out_hi, int* __restrict__ need_full)
 {
@@ -3787,7 +3787,7 @@ void k_percentile_sel(const double* __restrict__ data, int n, int i_lo, double g
 // fp64 MFMA issue-rate microbenchmark: 8 independent accumulators per wave
 // with distinct operands (identical chains would be merged by the compiler),
 // 4 waves per block; used to confirm the fp64 matrix peak on the box.
-__global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ out, int iters)
+static __global__ __launch_bounds__(256) void k_mfma_peak(double* __restrict__ out, int iters)
 {
     d4 acc[8];
     double a[8], b[8];

@@ -133,7 +133,7 @@ __device__ __forceinline__ void sd_scatter(double* buf, const int* xs, int S, in
 // Resample setup: sources, masks, Y0 = Jc Y[ys], sum of squares, and the T + 1
 // subject-space vectors scatter(Y0[:, t]), cnt for GEMM 0.
 // dynamic LDS: S doubles per wave.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void k_sd_init(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
@@ -254,7 +254,7 @@ __device__ __forceinline__ void sd_gram_h(const double* Y0, const double* Z0, in
 }
 
 // After GEMM 0: Z0 = Jc gather(K scatter(Y0)), kcpos, H = H0 = Y0^T Z0.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_post0(SdArgs a)
 {
     const int S = a.S, T = a.T, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
@@ -632,7 +632,7 @@ __device__ double wave_top_eig(double* A, int n, int ld, int lane, double* ws, d
 
 // Component step c (see the header): closes component c - 1 when c > 0, opens component c
 // unless c == k.  dynamic LDS: sd_step_lds(S, T, k) doubles per wave.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_step(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
@@ -1000,7 +1000,7 @@ void k_sd_step(SdArgs a)
 // accumulate the aligned weights directly (k_xprod EPI = 2) instead of writing them, forming
 // their cross-Gram with the original and reading them back for the sign and the sums.
 // dynamic LDS: k (+ S with a.Vd) doubles per wave.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void k_sd_final(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
@@ -1121,7 +1121,7 @@ void k_sd_final(SdArgs a)
 // Bootstrap sign alignment (regression.py:317-320): flip_c = sign(corr(w_c, w0_c))
 // = sign(sum_b w_c[b] * (w0_c[b] - mean w0_c)); P[r][c][c'] = W_r[c] . W0c[c'].
 // Writes M = diag(flip) in k_urot's fragment order and flips the y_loadings.
-__global__ void k_simpls_signs(const double* __restrict__ P, int k, int T, int nks_t, int LT,
+static __global__ void k_simpls_signs(const double* __restrict__ P, int k, int T, int nks_t, int LT,
                                double* __restrict__ Mfrag, double* __restrict__ yload)
 {
     const int r = blockIdx.x;

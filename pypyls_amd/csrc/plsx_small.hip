@@ -1,0 +1,93 @@
+// plsx_small.hip -- launches of the small dense solvers (k_small, k_small_ql) and the refinement of graded spectra
+// Part of libplsx.so (plsx_internal.h has the map of translation units).  gfx950 only.
+#include "plsx_internal.h"
+
+using namespace plsxi;
+
+namespace plsxi {
+
+// Rref: the cross-covariance matrices the Gram matrices a.G were formed from (slot r at r * strideR, pitch Bpad,
+// B live columns), or nullptr on the dual-space routes that never form them.  With them a graded spectrum is
+// refined on R itself (SmallArgs::phase, k_refine_gram); without, such resamples are only counted.
+int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double* Rref)
+{
+    const int n = a.n;
+    const int ld = n | 1;
+    KTimer tm(ctx, KC_SMALL, st);
+    a.nres = nres;
+    a.ld = ld;
+    a.jtol = 1e-15;
+    a.phase = 0;
+    if (n > PLSX_JACOBI_TP) {
+        // Householder + implicit QL (plsx_symeig.h): persistent blocks, a global workspace of 4 n ld
+        // doubles per block, and whatever LDS is left behind the bookkeeping vectors for the leading
+        // block of the matrix being reduced (the whole matrix up to T' ~ 135)
+        const size_t ws = (size_t)4 * n * ld * 8;
+        const size_t lds_vec = (size_t)(7 * n + PLSX_SE_THREADS + 18) * 8 + (size_t)(2 * n + 2) * 4 + 64;
+        const size_t lds = std::min((size_t)160 * 1024 - 256, lds_vec + (size_t)n * n * 8);
+        a.lds_cap = (int)((lds - lds_vec) / 8);
+        int nblk = 0;
+#define SMALL_QL_LAUNCH(RPT, CH) { HIPCHK(set_lds(k_small_ql<RPT, CH>, lds)); int per = 1; \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_small_ql<RPT, CH>, PLSX_SE_THREADS, lds); \
+        nblk = std::min(nres, 256 * std::max(1, per)); \
+        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e; \
+        a.gws = ptr<double>(ctx->gws); \
+        hipLaunchKernelGGL((k_small_ql<RPT, CH>), dim3(nblk), dim3(PLSX_SE_THREADS), lds, st, a); }
+        if (n <= 192) SMALL_QL_LAUNCH(1, 16)          // rows of the eigenvector matrix per rotating thread, prefetch depth
+        else if (n <= 384) SMALL_QL_LAUNCH(2, 8)
+        else if (n <= 576) SMALL_QL_LAUNCH(3, 8)
+        else SMALL_QL_LAUNCH(7, 4)
+#undef SMALL_QL_LAUNCH
+        LAUNCHCHK();
+        return 0;
+    }
+    // one-sided Jacobi out of LDS, one block per resample, 8 lanes per column pair
+    const size_t lds = ((size_t)2 * n * ld + 2 * n) * 8 + (size_t)2 * n * 4 + 64;
+#define SMALL_LDS_LAUNCH(ITL, THREADS, BYTES) { HIPCHK(set_lds(k_small<ITL>, BYTES)); \
+        hipLaunchKernelGGL((k_small<ITL>), dim3(nres), dim3(THREADS), BYTES, st, a); }
+#define SMALL_LDS_DISPATCH(BYTES) \
+    if (n <= 16) SMALL_LDS_LAUNCH(2, 64, BYTES)          /* one wave per resample: the step barriers cost nothing */ \
+    else if (n <= 32) SMALL_LDS_LAUNCH(4, 128, BYTES) \
+    else if (n <= 56) SMALL_LDS_LAUNCH(7, 256, BYTES) \
+    else SMALL_LDS_LAUNCH(8, 256, BYTES)
+    int nchunk = 0;
+    const bool boot = a.mode == SMALL_BOOT;
+    if (Rref && n > 1 && !ctx->opt[OPT_NO_REFINE]) {
+        // partial G' (and Y U0): one (n x n) (+ (n x L)) tile per (resample, column chunk), 256 MB at most
+        const long long per = (long long)n * (n + (boot ? a.L : 0)) * 8;
+        nchunk = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(32, ceil_div(ctx->B, 1024)),
+                                                                  (256LL << 20) / ((long long)nres * per)));
+        if (int e = ensure(ctx, ctx->refV, (size_t)nres * n * n * 8)) return e;
+        if (int e = ensure(ctx, ctx->refLam, (size_t)nres * n * 8)) return e;
+        if (int e = ensure(ctx, ctx->refK0, (size_t)nres * sizeof(int))) return e;
+        if (int e = ensure(ctx, ctx->refPart, (size_t)nres * nchunk * n * n * 8)) return e;
+        if (boot) if (int e = ensure(ctx, ctx->refPartP, (size_t)nres * nchunk * n * a.L * 8)) return e;
+        a.phase = 1;
+        a.refV = ptr<double>(ctx->refV); a.refLam = ptr<double>(ctx->refLam); a.refK0 = ptr<int>(ctx->refK0);
+        a.refPart = ptr<double>(ctx->refPart); a.refPartP = boot ? ptr<double>(ctx->refPartP) : nullptr;
+        a.ref_nchunk = nchunk;
+    }
+    SMALL_LDS_DISPATCH(lds)
+    LAUNCHCHK();
+    if (a.phase == 1) {
+        // blocks of resamples that are not parked return at once: two short launches when nothing is graded
+        const size_t rlds = ((size_t)n * 64 + 2 * 64 * 66) * 8;
+        HIPCHK(set_lds(k_refine_gram, rlds));
+        hipLaunchKernelGGL(k_refine_gram, dim3(nchunk, nres), dim3(256), rlds, st, Rref, ctx->strideR, ctx->Bpad,
+                           ctx->B, n, ptr<double>(ctx->refV), ptr<int>(ctx->refK0),
+                           boot ? ptr<double>(ctx->U0T) : (const double*)nullptr, ctx->Bpad, a.L,
+                           ptr<double>(ctx->refPart), a.refPartP, nchunk);
+        LAUNCHCHK();
+        a.phase = 2;
+        // (two more work matrices in LDS: W of the small block and the large -> small coefficients)
+        const size_t lds2 = lds + (size_t)2 * n * ld * 8 + 16;
+        SMALL_LDS_DISPATCH(lds2)
+        LAUNCHCHK();
+    }
+#undef SMALL_LDS_DISPATCH
+#undef SMALL_LDS_LAUNCH
+    return 0;
+}
+
+}  // namespace plsxi
+

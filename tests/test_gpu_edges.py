@@ -308,7 +308,7 @@ def test_randomised_parity_sweep():
 def test_single_pass_bootstrap_equals_two_pass(case, monkeypatch):
     """Unscaled modes (mean-centred PLS, covariance-mode behavioral PLS): the bootstrap takes ONE
     pass over the features per resample (G, P from the S x S kernel, U = X^T (A^T M) accumulated in the
-    cross-product epilogue; plsx_api.hip boot_single_pass).  Same sum U, sum U^2, distrib as the
+    cross-product epilogue; plsx_core.hip boot_single_pass).  Same sum U, sum U^2, distrib as the
     two-pass route (R written, Gram pass, rotation pass) and as the oracle."""
     from pypyls_amd import resampling as rsmp
     rs = np.random.RandomState(17)

@@ -238,12 +238,15 @@ def test_shared_seed_multiprocess_gloo(tmp_path):
 
 def test_every_c_abi_entry_is_guarded_and_reads_no_environment():
     """no C++ exception crosses the ABI, and the route switches are an interface
-    (plsx_set_option), not ambient environment.  Every ``extern "C"`` definition in plsx_api.hip is either
+    (plsx_set_option), not ambient environment.  Every ``extern "C"`` definition in csrc/*.hip is either
     a function-try-block closed by PLSX_CATCH or a one-line accessor that cannot throw; nothing under
     csrc/ calls getenv."""
     import re
-    src = open(os.path.join(ROOT, 'pypyls_amd', 'csrc', 'plsx_api.hip')).read()
-    lines = src.split('\n')
+    csrc = os.path.join(ROOT, 'pypyls_amd', 'csrc')
+    lines = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith('.hip'):
+            lines += open(os.path.join(csrc, f)).read().split('\n') + ['']
     header = open(os.path.join(ROOT, 'include', 'plsx.h')).read()
     declared = set(re.findall(r'\b(plsx_\w+)\s*\(', header))
     trivial = {'plsx_version', 'plsx_max_tprime', 'plsx_last_error', 'plsx_num_lv', 'plsx_tprime',
@@ -272,8 +275,9 @@ def test_every_c_abi_entry_is_guarded_and_reads_no_environment():
         assert lines[k].startswith('} PLSX_CATCH('), (name, lines[k])
     assert not unguarded, unguarded
     assert declared <= defined, declared - defined
-    for f in os.listdir(os.path.join(ROOT, 'pypyls_amd', 'csrc')):
-        assert 'getenv' not in open(os.path.join(ROOT, 'pypyls_amd', 'csrc', f)).read(), f
+    for f in os.listdir(csrc):
+        if os.path.isfile(os.path.join(csrc, f)):
+            assert 'getenv' not in open(os.path.join(csrc, f)).read(), f
     # ... and the product's Python does not select routes from the environment either
     for f in ('engine.py', 'plsc.py', 'regression.py', 'parallel.py', 'resampling.py'):
         text = open(os.path.join(ROOT, 'pypyls_amd', f)).read()

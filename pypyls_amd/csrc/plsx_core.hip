@@ -206,24 +206,8 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     // x (T'/200)^3 for Householder + QL (T' > PLSX_JACOBI_TP; one block per resample, latency
     // bound: only a large batch keeps the chip busy)
     const double tn = ctx->Tp / 200.0;
-    // what mapping a GB costs HERE is measured once per context (2 GB: hipMalloc + first touch + free) instead of
-    // assumed: ~1 ms per GB on a device with clean pages (the model then launches 2 - 3 x larger super-batches:
-    // a 1250-bootstrap shard of c4 ran 56 per launch under the fixed 40 ms per GB and paid one 2.5 ms wave of the
-    // small solver per 10 ms of cross-product), 25+ ms per GB when the driver has to clear recycled VRAM first.
-    // Floor 1.5 ms per GB (the zero fill of R and a margin for the pool running dry beyond the probe), cap 40.
-    if (ctx->map_ms_per_gb <= 0.0) {
-        ctx->map_ms_per_gb = 40.0;
-        void* probe = nullptr;
-        const size_t pb = (size_t)2 << 30;
-        auto t0 = std::chrono::steady_clock::now();
-        if (hipMalloc(&probe, pb) == hipSuccess) {
-            (void)hipMemset(probe, 0, pb);
-            (void)hipDeviceSynchronize();
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            (void)hipFree(probe);
-            ctx->map_ms_per_gb = std::min(40.0, std::max(1.5, 2.0 * (ms / 2.0)));   // (safety factor 2 on the per-GB time)
-        } else (void)hipGetLastError();
-    }
+    // what mapping a GB costs HERE was measured when the data were bound (probe_map_cost, plsx_set_data), in classes
+    if (ctx->map_ms_per_gb <= 0.0) ctx->map_ms_per_gb = 40.0;
     const double c_group = ctx->map_ms_per_gb * gb_per_group, c_launch = ctx->Tp > PLSX_JACOBI_TP ? std::max(2.5, 25.0 * tn * tn * tn) : 2.5;
     int g = round_up((int)std::ceil(std::sqrt(c_launch * (double)need / std::max(c_group, 1e-3))), 8);
     g = std::max(g, ctx->Galloc);
@@ -232,6 +216,30 @@ int launch_groups(plsx_ctx* ctx, long long units, int per_group)
     if (ctx->R.bytes > 0 && gb_per_group > 0.0)
         g = std::max(g, (int)std::min<double>(cap, std::floor((double)ctx->R.bytes / (gb_per_group * 1073741824.0))));
     return std::max(1, std::min(g, cap));
+}
+
+// What mapping a GB of device memory costs on THIS device right now: ~1 ms per GB on clean pages (the model of
+// launch_groups then launches 2 - 3 x larger super-batches), 25+ ms per GB when the driver has to clear recycled VRAM
+// first.  Measured once per context at bind time -- outside the launch path: the probe ends in a device-wide sync --
+// on 1 GB (a smaller request is served from the pool of clean pages and sees nothing), and QUANTISED to four classes so that the super-batch sizes (and with them the summation order of the
+// bootstrap sums) do not follow measurement noise from run to run.  A failed probe (full device) keeps the
+// conservative 40 ms per GB.
+void probe_map_cost(plsx_ctx* ctx)
+{
+    if (ctx->map_ms_per_gb > 0.0 || ctx->scratch_fixed) return;
+    ctx->map_ms_per_gb = 40.0;
+    void* probe = nullptr;
+    const size_t pb = (size_t)1 << 30;
+    (void)hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    if (hipMalloc(&probe, pb) == hipSuccess) {
+        (void)hipMemset(probe, 0, pb);
+        (void)hipDeviceSynchronize();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        (void)hipFree(probe);
+        const double per_gb = 2.0 * ms;                    // (safety factor 2 on the per-GB time)
+        ctx->map_ms_per_gb = per_gb < 3.0 ? 1.5 : (per_gb < 10.0 ? 5.0 : (per_gb < 25.0 ? 15.0 : 40.0));
+    } else (void)hipGetLastError();
 }
 
 // Super-batches of a call of n resamples with at most `cap` per launch (cap a multiple of `per_group`): the same
@@ -423,6 +431,9 @@ try {
         return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
     }
     ctx->has_data = ctx->has_orig = false;
+    // a new binding starts a new analysis: numerical status and graded-spectrum counters of the last one are dropped
+    ctx->n_refined = ctx->n_unrefined = 0;
+    HIPCHK(hipMemsetAsync(ctx->status.p, 0, 4 * sizeof(int), st));
     ctx->has_Kd = 0;
     ctx->npg_w = 0;                                    // the row -> LV map of the accumulating epilogue follows L
     ctx->has_compact_maps = 0;
@@ -433,11 +444,13 @@ try {
         // front-ends re-binding data of the same shape: a 26 GB fill is 8 ms per call)
         const int Tp_n = (method == PLSX_BEHAVIORAL) ? J * T : (method == PLSX_REGRESSION ? ncomp : J);
         const int L_n = std::min(Tp_n, B);
-        const long long geom[3] = {Tp_n, round_up(Tp_n, 4), round_up(B + L_n, 128)};
-        const bool same = ctx->R.p && ctx->R_geom[0] == geom[0] && ctx->R_geom[1] == geom[1] && ctx->R_geom[2] == geom[2] &&
-                          ctx->R_zeroed_bytes == ctx->R.bytes;
+        // (the key holds everything a slot's padding depends on: rows T'..T'pp, columns B + L..Bpad, and the method --
+        // a route of another method may have left other rows / columns of a slot untouched)
+        const long long geom[6] = {Tp_n, round_up(Tp_n, 4), round_up(B + L_n, 128), B, L_n, method * 2 + ((flags & PLSX_FLAG_COVARIANCE) ? 1 : 0)};
+        bool same = ctx->R.p && ctx->R_zeroed_bytes == ctx->R.bytes;
+        for (int i = 0; i < 6; ++i) same = same && ctx->R_geom[i] == geom[i];
         if (ctx->R.p && !same) HIPCHK(hipMemsetAsync(ctx->R.p, 0, ctx->R.bytes, st));
-        ctx->R_geom[0] = geom[0]; ctx->R_geom[1] = geom[1]; ctx->R_geom[2] = geom[2];
+        for (int i = 0; i < 6; ++i) ctx->R_geom[i] = geom[i];
         ctx->R_zeroed_bytes = ctx->R.bytes;
     }
     ctx->has_okx = ctx->has_oky = false;
@@ -489,6 +502,7 @@ try {
         if (int e = ensure(ctx, ctx->Y, (size_t)S * T * 8)) return e;
         HIPCHK(hipMemcpyAsync(ctx->Y.p, d_Y, (size_t)S * T * 8, hipMemcpyDeviceToDevice, st));
     }
+    probe_map_cost(ctx);
     if (plan_groups(ctx) != 0)
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
                     "cannot lay out the rows of a resample (with their per-cell moment rows) over cross-product blocks");

@@ -118,7 +118,7 @@ struct plsx_ctx {
     int quad_MT = 0, quad_gpl = 0, quad_series = 0;     // block height / blocks per LV of the last closing pass; series closed on that route while timing
     int last_compact_n = 0, last_compact_ktot = 0;   // compact launch behind the last run_xprod (0: none)
     double scratch_gb = 48.0;                           // super-batch scratch budget
-    long long R_geom[3] = {0, 0, 0};                    // (T', T'pp, Bpad) the R scratch was last zeroed under
+    long long R_geom[6] = {0, 0, 0, 0, 0, 0};           // (T', T'pp, Bpad, B, L, method) the R scratch was last zeroed under
     size_t R_zeroed_bytes = 0;
     double map_ms_per_gb = 0.0;                         // measured cost of mapping device memory (launch_groups), 0 = not yet
     int scratch_fixed = 0;                              // 1: always launch budget-sized super-batches
@@ -259,6 +259,7 @@ int plan_sepmom(plsx_ctx* ctx);
 int ensure_scratch(plsx_ctx* ctx, int groups);
 int launch_groups(plsx_ctx* ctx, long long units, int per_group);
 int balanced_batch(int n, int cap, int per_group);
+void probe_map_cost(plsx_ctx* ctx);
 int chip_slots(const void* kernel);
 int pick_parts(long long units, int slots, int lo, int hi);
 SmallArgs small_args(plsx_ctx* ctx, int mode);

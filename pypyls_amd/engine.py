@@ -8,6 +8,7 @@ There is NO CPU fallback: without the built library or without a GPU every
 entry point raises.
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -204,6 +205,10 @@ class Engine(object):
         if rc != 0:
             raise PlsxError('plsx_ctx_create failed with status {}'.format(rc))
         self.ctx = ctx
+        # one analysis at a time per context: the context is not shared across host threads (include/plsx.h);
+        # the front-ends hold this lock for the whole call, so two threads that call behavioral_pls /
+        # pls_regression concurrently (they share the cached default engine) run one after the other
+        self.lock = threading.RLock()
         self.S = self.B = self.L = self.Tp = 0
         self.refined = self.unrefined = 0
         if scratch_gb is not None:
@@ -266,6 +271,19 @@ class Engine(object):
                           'SVD of R by more than 1e-5 relative'.format(b.value), GradedSpectrumWarning,
                           stacklevel=2)
         return a.value, b.value
+
+    def end_analysis(self, warn=True):
+        """Close an analysis on this context, on the success AND on the error path of a front-end: forget the
+        announced shard size (``expect_resamples``) and drain the refined / unrefined counters so that neither
+        leaks into the next call.  ``warn``: raise the GradedSpectrumWarning of this analysis (success path);
+        after an exception the counters are dropped silently and a failing device is not allowed to mask the
+        exception that is already propagating."""
+        try:
+            self.set_option('expect_resamples', 0)
+            self.numeric_report(warn=warn)
+        except PlsxError:
+            if warn:
+                raise
 
     # -- data -------------------------------------------------------------
     def set_data(self, X, Y, cell_of_row, n_groups, n_cond, method, mean_centering=0,
@@ -725,6 +743,7 @@ class Engine(object):
 # the front-ends' default engine
 # ---------------------------------------------------------------------------
 _DEFAULT = {}
+_DEFAULT_LOCK = threading.Lock()
 
 
 def default_engine(device=None):
@@ -735,23 +754,31 @@ def default_engine(device=None):
     driver clears recycled VRAM lazily, so a call that maps the tens of GB its predecessor just released waits
     for the clear (25 ms per GB: 1 - 5 s measured for the c4 shape, ten times the analysis' own fixed cost),
     while a context that is re-bound (plsx_set_data) reuses what it holds.  ``release_default_engine()`` gives
-    the memory back."""
+    the memory back.
+
+    **What stays mapped after a call returns**: the resident copy of X (0.8 GB at 500 x 200 000) and the
+    super-batch scratch the call sized for itself (up to 48 GB) -- on purpose, see above, but it IS device memory
+    that later work on the same GPU (torch or otherwise) cannot use until ``pypyls_amd.release_default_engine()``
+    is called.  Thread safety: creation is guarded here, use is serialised by ``Engine.lock`` in the front-ends."""
     torch = _torch()
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     key = int(device)
-    eng = _DEFAULT.get(key)
-    if eng is None or not getattr(eng, 'ctx', None):
-        if not _DEFAULT:
-            import atexit
-            atexit.register(release_default_engine)     # free the device memory before the runtime goes away
-        eng = _DEFAULT[key] = Engine(device=key)
+    with _DEFAULT_LOCK:
+        eng = _DEFAULT.get(key)
+        if eng is None or not getattr(eng, 'ctx', None):
+            if not _DEFAULT:
+                import atexit
+                atexit.register(release_default_engine)     # free the device memory before the runtime goes away
+            eng = _DEFAULT[key] = Engine(device=key)
     return eng
 
 
 def release_default_engine(device=None):
     """Destroy the cached default engine(s) and free their device memory."""
-    for key in ([int(device)] if device is not None else list(_DEFAULT)):
-        eng = _DEFAULT.pop(key, None)
+    with _DEFAULT_LOCK:
+        engines = [_DEFAULT.pop(key, None) for key in ([int(device)] if device is not None else list(_DEFAULT))]
+    for eng in engines:
         if eng is not None:
-            eng.close()
+            with eng.lock:                                  # (a call in flight on another thread finishes first)
+                eng.close()

@@ -152,16 +152,29 @@ class _PLSCRun(object):
         Y = None if self.method == 'meancentered' else _as_float_array(inp.Y, 'Y')
         Tp = self.n_cells * Y.shape[1] if Y is not None else self.n_cells
         self.perm_given = self.boot_given = None
+        from .engine import default_engine
+        eng = self.engine or default_engine()
         draws = self._plan_draws(min(Tp, X.shape[1])).start()
         self._mstream = None
+        ok = False
         try:
-            return self._run_device(X, Y, draws)
+            with eng.lock:                             # one analysis at a time per context (shared default engine)
+                try:
+                    res = self._run_device(X, Y, draws, eng)
+                    ok = True
+                finally:
+                    # state that must not leak into the next analysis on this context, whatever happened:
+                    # the announced shard size and the refined / unrefined counters (a stale count would raise
+                    # a spurious GradedSpectrumWarning -- and stale scratch sizing -- in an unrelated call)
+                    if getattr(eng, 'ctx', None):
+                        eng.end_analysis(warn=ok)
+            return res
         finally:
             draws.thread.join()                        # never leave the generators running on an error
             if self._mstream is not None:
                 self._mstream.close()
 
-    def _run_device(self, X, Y, draws):
+    def _run_device(self, X, Y, draws, eng):
         """The analysis after the draws started.  Everything B- or n_boot-sized stays on the device from the
         H2D copy of X to the finished statistics: the sign convention, the original's scores, the resampling,
         THE one collective, percentile intervals, bootstrap ratios and the (T', L, n_boot) layout of the
@@ -170,9 +183,7 @@ class _PLSCRun(object):
         transposed the 200 MB distributions on the host: 0.26 - 0.30 s of fixed cost per call at c4.)"""
         import time
         import torch
-        from .engine import default_engine
         inp = self.inputs
-        eng = self.engine or default_engine()
         phases = self.phases                           # dict: per-phase wall times (bench.py --mode analysis)
 
         t_last = [time.perf_counter()]
@@ -425,8 +436,6 @@ class _PLSCRun(object):
 
         res['varexp'] = hostmath.varexp(sv)
         res['singvals'] = sv
-        eng.set_option('expect_resamples', 0)
-        eng.numeric_report()       # warns when graded decompositions could not be refined (T' > 64)
         tick('host_finish')
         self.engine_used = eng
         return res

@@ -161,11 +161,21 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
             if bs.ndim != 2 or bs.shape[0] != S:
                 raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'.format(S, bs.shape))
             bstream = resampling.IndexStream.of_array(check_index_array(bs, S))
+    from .engine import default_engine
+    eng = kwargs.get('_engine') or default_engine()
     draws = resampling.DrawThread(rs, jobs).start()
+    ok = False
     try:
-        return _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
-                           bootsamples, bootsamples_out, k, ci, kwargs.get('_engine'), kwargs.get('_phases'),
-                           kwargs.get('_emulate'))
+        with eng.lock:                                 # one analysis at a time per context (shared default engine)
+            try:
+                res = _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
+                                  bootsamples, bootsamples_out, k, ci, eng, kwargs.get('_phases'),
+                                  kwargs.get('_emulate'))
+                ok = True
+            finally:
+                if getattr(eng, 'ctx', None):
+                    eng.end_analysis(warn=ok)          # nothing of this call leaks into the next one on the context
+        return res
     finally:
         draws.thread.join()
 
@@ -174,7 +184,6 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
                 bootsamples_out, k, ci, engine, phases=None, emulate=None):
     import time
     import torch
-    from .engine import default_engine
     S = len(X)
     t_last = [time.perf_counter()]
 
@@ -189,7 +198,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     # regression.py:395-397 (on copies: the reference centres the caller's X in place)
     Yc = Y_agg.astype(np.float64) - np.nanmean(Y_agg, axis=0, keepdims=True)
     B, T = X.shape[1], Yc.shape[1]
-    eng = engine or default_engine()
+    eng = engine
     clean = bool(np.isfinite(Yc).all())
     if clean:
         # no missing data in Y: bind X as it is -- the device centres it itself (plsx_set_data) -- and let the

@@ -269,11 +269,17 @@ def gen_splits_seeded(groups, n_cond, n_split, seeds, test_size=0.5, rows=False,
     S = int(sum(groups)) * int(n_cond)
     lib = _native()
     if lib is None or seeds.size == 0 or seeds.min() < 0 or seeds.max() >= 2 ** 32:
+        dup = [False]
         if seeds.size == 0:
             res = np.zeros((0, S, int(n_split)), dtype=bool)
         else:
-            res = np.stack([_py_gen_splits(groups, n_cond, n_split, int(sd), test_size) for sd in seeds])
-        return np.ascontiguousarray(res.transpose(0, 2, 1), dtype=np.uint8) if rows else res
+            res = np.stack([_py_gen_splits(groups, n_cond, n_split, int(sd), test_size, dup_flag=dup) for sd in seeds])
+        res = np.ascontiguousarray(res.transpose(0, 2, 1), dtype=np.uint8) if rows else res
+        if not warn:                                    # (thread use: the caller warns) -- same shape as the native path
+            return res, dup[0]
+        if dup[0]:
+            warnings.warn('WARNING: Duplicate split halves used.')
+        return res
     out = np.zeros((seeds.size, int(n_split), S), dtype=np.uint8)
     g = np.ascontiguousarray(groups, dtype=np.int32)
     sd = np.ascontiguousarray(seeds, dtype=np.uint32)
@@ -289,7 +295,9 @@ def gen_splits_seeded(groups, n_cond, n_split, seeds, test_size=0.5, rows=False,
     return res
 
 
-def _py_gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5):
+def _py_gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5, dup_flag=None):
+    # dup_flag: a one-element list that receives the "duplicate limit hit" bit instead of a warning (the caller
+    # warns from ITS thread: warnings raised on a producer thread are lost under filters or attributed wrongly)
     des = _Design(groups, n_cond)
     rs = check_random_state(seed)
     out = np.zeros((des.n_rows, n_split), dtype=bool)
@@ -310,7 +318,10 @@ def _py_gen_splits(groups, n_cond, n_split, seed=None, test_size=0.5):
             if key in seen:
                 duplicated = True
         if count == 500 and not warned:
-            warnings.warn('WARNING: Duplicate split halves used.')
+            if dup_flag is not None:
+                dup_flag[0] = True
+            else:
+                warnings.warn('WARNING: Duplicate split halves used.')
             warned = True
         seen.add(key)
         out[:, i] = half
@@ -497,11 +508,9 @@ class MaskStream(object):
                 if self.given is not None:
                     m = np.ascontiguousarray(np.asarray(self.given)[a:b].transpose(0, 2, 1), dtype=np.uint8)
                 else:
-                    m = gen_splits_seeded(groups, n_cond, n_split, np.arange(a, b), test_size=test_size,
-                                          rows=True, warn=False)
-                    if isinstance(m, tuple):                  # native generator: (masks, duplicate limit hit)
-                        m, dup = m
-                        self.duplicates = self.duplicates or dup
+                    m, dup = gen_splits_seeded(groups, n_cond, n_split, np.arange(a, b), test_size=test_size,
+                                               rows=True, warn=False)      # (masks, duplicate limit hit)
+                    self.duplicates = self.duplicates or dup
                 self.q.put((a, b, m))
             self.q.put(None)
         except BaseException as exc:

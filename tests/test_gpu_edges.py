@@ -357,3 +357,82 @@ def test_single_pass_bootstrap_equals_two_pass(case, monkeypatch):
     assert_close(usum.cpu().numpy()[:, live], ws[:, live], 1e-8, what='single-pass sum U vs oracle')
     assert_close(usq.cpu().numpy()[:, live], wq[:, live], 1e-8, what='single-pass sum U^2 vs oracle')
     assert_close(dist[:, live], np.stack(wd, -1)[:, live], 1e-8, what='single-pass distrib vs oracle')
+
+
+def test_rebinding_a_context_equals_a_fresh_one():
+    """a re-bound context skips the zero fill of its R scratch when the slot geometry is unchanged.
+    The geometry key holds (T', T'pp, Bpad, B, L, method); bindings that differ only in what the key must tell
+    apart -- another B inside the same Bpad, another method with the same T' -- give the results of a fresh
+    engine."""
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(3)
+    S, T = 60, 6
+    X1, X2 = rs.randn(S, 1010), rs.randn(S, 1000)          # B + L = 1016 / 1006: both pad to 1024
+    Y = rs.randn(S, T) + 0.4 * X1[:, :T]
+    boots = rsmp.gen_bootsamp([S], 1, 12, seed=5)
+    perms = rsmp.gen_permsamp([S], 1, 12, seed=6)
+
+    def behavioral(eng, X):
+        _bind(eng, X, Y, [S], 1)
+        xw, sv, yw = eng.decompose()
+        eng.set_original(xw, sv, yw)
+        return (sv, eng.perm(perms)) + tuple(eng.boot(boots))
+
+    def regression(eng, X):
+        Xc, Yc = X - X.mean(0), Y - Y.mean(0)
+        eng.set_data_regression(Xc, Yc, T)                  # n_components = T: the same T' = 6 rows per resample
+        W, pct, cvec, yl = eng.simpls_decompose()
+        eng.simpls_set_original(W)
+        return (pct, eng.simpls_perm(perms)) + tuple(eng.simpls_boot(boots))
+
+    shared = _engine()
+    seq = [behavioral(shared, X1), behavioral(shared, X2), regression(shared, X2), behavioral(shared, X1)]
+    fresh = [behavioral(_engine(), X1), behavioral(_engine(), X2), regression(_engine(), X2), behavioral(_engine(), X1)]
+    for k, (a, b) in enumerate(zip(seq, fresh)):
+        for x, y in zip(a, b):
+            x, y = [t.cpu().numpy() if hasattr(t, 'cpu') else np.asarray(t) for t in (x, y)]
+            assert_close(x, y, 1e-12, what='binding {}'.format(k))
+
+
+def test_a_failed_analysis_leaves_no_state_on_the_shared_engine(monkeypatch):
+    """the front-ends share one cached engine.  An analysis that dies half way must not leave its
+    announced shard size or its graded-spectrum counters behind (they would size the scratch of, and raise a
+    spurious GradedSpectrumWarning in, the next unrelated call), and concurrent callers are serialised."""
+    import threading
+    import warnings
+    import pypyls_amd as pls
+    from pypyls_amd import hostmath
+    from pypyls_amd.engine import default_engine, GradedSpectrumWarning
+    from test_gpu_graded import graded_behaviours
+    rs = np.random.RandomState(11)
+    S, B, T = 80, 2000, 8
+    X = rs.randn(S, B)
+    Yg = graded_behaviours(rs, S, T, 3e5, 'mix')
+    eng = default_engine()
+    eng.set_option('no_refine', 1)                         # graded decompositions are counted, not repaired
+    try:
+        def boom(*a, **k):
+            raise RuntimeError('injected failure after the resampling')
+        monkeypatch.setattr(hostmath, 'varexp', boom)
+        with pytest.raises(RuntimeError, match='injected'):
+            pls.behavioral_pls(X, Yg, n_perm=16, n_boot=16, test_split=0, seed=1, verbose=False)
+        monkeypatch.undo()
+        assert eng.numeric_report(warn=False) == (0, 0)    # drained on the error path
+    finally:
+        eng.set_option('no_refine', 0)
+    Y = rs.randn(S, T) + 0.4 * X[:, :T]
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', GradedSpectrumWarning)
+        a = pls.behavioral_pls(X, Y, n_perm=16, n_boot=16, test_split=0, seed=2, verbose=False)
+    # two threads on the shared engine: serialised by Engine.lock, both get the single-threaded answer
+    out = {}
+
+    def work(name):
+        out[name] = pls.behavioral_pls(X, Y, n_perm=16, n_boot=16, test_split=0, seed=2, verbose=False)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for i in range(2):
+        assert np.array_equal(out[i].singvals, a.singvals)
+        assert np.array_equal(out[i].bootres.x_weights_normed, a.bootres.x_weights_normed)
+        assert np.array_equal(out[i].permres.perm_singval, a.permres.perm_singval)

@@ -164,7 +164,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     line = [l for l in proc.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
-    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['value_primal'] > 0
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['value_dual'] > 0
     assert out['roofline']['bound'] in ('mfma', 'hbm') and out['config']['perms_per_step'] == 56
     # strong mode: one analysis split over the two ranks, index generation inside the clock
     proc = subprocess.run(cmd + ['--mode', 'strong', '--perms', '120', '--boots', '112', '--no-primal'], env=env,
@@ -172,6 +172,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     out = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{')][-1])
     assert out['n_gpus'] == 2 and out['scaling'] == 'strong'
+    # the END-TO-END public call under two real ranks (the front-end shards and gathers over the process group)
+    proc = subprocess.run(cmd[:3] + ['2', '--mode', 'analysis', '--config', 'c2', '--perms', '200', '--boots', '200',
+                                     '--steps', '1'], env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['config']['mode'] == 'analysis' and out['value'] > 0
+    assert 'over 2 ranks' in out['config']['collective']
     # more ranks than GPUs without the dry-run switch: refused loudly
     env2 = dict(env)
     env2.pop('PLSX_BENCH_SHARE_GPU')
@@ -198,7 +205,9 @@ def test_bench_config_lines(config):
         assert key in out, key
     assert out['dtype'] == 'f64' and out['roofline']['bound'] in ('hbm', 'mfma')
     assert 0 < out['roofline']['frac'] <= 1.0 and out['cpu_baseline']['kind'] == 'port'
-    assert out['value_primal'] > 0 and 'k_xprod' in out['config']['kernel_ms_per_step']
+    # `value` is the north-star pipeline (every permutation passes over X), the S x S route rides beside it
+    assert out['value_dual'] >= out['value'] > 0 and 'k_xprod' in out['config']['kernel_ms_per_step']
+    assert 'feature pass' in out['config']['perm_path']
 
 
 def test_bench_analysis_mode_line():
@@ -221,3 +230,28 @@ def test_bench_analysis_mode_line():
         assert key in w['1']['rank0_phases_ms'], key
     assert w['2']['critical_path_ms'] > 0 and 0 < w['2']['efficiency'] <= 1.5
     assert out['fixed_cost_ms']['everything_else_ms'] >= 0
+
+
+def test_bench_default_line_embeds_every_config():
+    """The driver's command (`bench.py --gpus 1 --steps K --warmup W`) ends in ONE line that carries the headline
+    (value = feature-pass pipeline, value_dual beside it) AND a sub-record per other BASELINE config plus the
+    end-to-end call, each with value / ms_per_step / roofline.frac / cpu_baseline."""
+    import json
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1'],
+                          env=env, capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['value_dual'] > out['value'] > 0 and out['hbm_algorithmic_TBps'] <= 8.0
+    assert 0 < out['roofline']['frac'] <= 1.0 and out['cpu_baseline']['kind'] == 'port'
+    cfgs = out['configs']
+    for c in ('c2', 'c3', 'c4split', 'c5'):
+        assert 'error' not in cfgs[c], cfgs[c]
+        assert cfgs[c]['value'] > 0 and cfgs[c]['ms_per_step'] > 0 and cfgs[c]['cpu_baseline']['value'] > 0
+        assert 0 < cfgs[c]['roofline']['frac'] <= 1.0, (c, cfgs[c]['roofline'])
+    assert 'unpinned' in cfgs['c5']['parity_note']
+    assert 'error' not in cfgs['c4_analysis'] and cfgs['c4_analysis']['value'] > 0
+    assert cfgs['wall_s'] < 300

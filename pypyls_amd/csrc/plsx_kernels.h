@@ -1082,7 +1082,7 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
                      const int* __restrict__ out_row, const int* __restrict__ mom_idx,
                      const double* __restrict__ mom_n, int n_groups, int ncolblk, SplitEpi se)
 {
-    static_assert(EPI == 3 || EPI == 5, "compact blocks: bootstrap (3) or fused split-half (5) epilogue");
+    static_assert(EPI == 3 || EPI == 5 || EPI == 8, "compact blocks: bootstrap (3), fused split-half (5) or raw first-half sums (8)");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = 4, NT = NW * 64, BC = NW * 32;       // threads, columns of a block
     constexpr int STAGE = KT * MT * 64;
@@ -1161,7 +1161,26 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
     auto val0 = [&](int m, int i) -> double { return (TAIL && m == MT - 1) ? tl0 : acc0[m < MF ? m : 0][i]; };
     auto val1 = [&](int m, int i) -> double { return (TAIL && m == MT - 1) ? tl1 : acc1[m < MF ? m : 0][i]; };
 
-    if constexpr (EPI == 3) {
+    if constexpr (EPI == 8) {
+        // raw first-half sums C_1 = A_1 . X of ONE split per block, stored once (slot = split): the fused reader
+        // (k_split_fused) rebuilds both z-scored halves from them and the arrangement's full-sample cross-product,
+        // so this leg writes half the bytes of epilogue 5 and spends no arithmetic on them
+        int* s_out = reinterpret_cast<int*>(smem);
+        for (int i = tid; i < MT * 16; i += NT) s_out[i] = out_row[i];
+        __syncthreads();
+        if (!live) return;
+        double* Rg = R + (size_t)grp * rows_per_group * ldr + col;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (TAIL && m == MT - 1 && i > 0) break;
+                const int orow = s_out[m * 16 + kq + 4 * i];
+                if (orow < 0) continue;
+                __builtin_nontemporal_store((d2){val0(m, i), val1(m, i)}, reinterpret_cast<d2*>(&Rg[(size_t)orow * ldr]));
+            }
+        return;
+    } else if constexpr (EPI == 3) {
         const int nmu = se.npairs;
         double* sS3 = smem;                                  // [nmu][BC]
         int* s_out = reinterpret_cast<int*>(smem + (size_t)nmu * BC);

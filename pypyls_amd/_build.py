@@ -14,7 +14,7 @@ OBJDIR = os.path.join(CSRC, 'build')
 UNITS = ['plsx_xprod', 'plsx_compact', 'plsx_gram', 'plsx_urot', 'plsx_small', 'plsx_simpls_api', 'plsx_split',
          'plsx_core']                                   # (longest compile first)
 COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_symeig.h']
-EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_simpls_api': ['plsx_simpls.h']}
+EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_simpls_api': ['plsx_simpls.h'], 'plsx_split': ['plsx_splitfused.h']}
 PUBLIC = os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')
 LIB = os.path.join(HERE, 'libplsx.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-function']

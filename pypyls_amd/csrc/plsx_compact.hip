@@ -56,28 +56,38 @@ int launch_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st
 // through a per-split row table (k_xprod IDX), first-half feature moments from moment-only blocks over all
 // (split, cell) pairs of the pass (full K: 16 tile-steps per split).  432 -> 272 tile-steps per split at
 // the headline shape; the price is one pass over half of X per split (0.4 GB): the leg turns HBM bound.
-template <int MT, int KT, bool TAIL = false>
+template <int MT, int KT, bool TAIL = false, int EPI = 5>
 int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st)
 {
     const int J = ctx->J;
     const size_t stage = (size_t)2 * (((size_t)KT * MT * 64 + 127) / 128) * 128 * 8 + (size_t)nks_c * 4 * sizeof(int);
-    const size_t epi = (size_t)5 * J * 128 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
+    // EPI 8 (raw first-half sums, one R slot per split): the epilogue needs the row map only
+    const size_t epi = EPI == 8 ? (size_t)MT * 16 * 4 : (size_t)5 * J * 128 * 8 + (size_t)2 * MT * 16 * 4 + (size_t)MT * 16 * 5 * 8;
     const size_t lds = std::max(stage, epi);
     se.off_pre = 0;
-    HIPCHK(set_lds(k_xprod_compact<MT, KT, 5, TAIL>, lds));
+    HIPCHK(set_lds(k_xprod_compact<MT, KT, EPI, TAIL>, lds));
     const int ncolblk = ceil_div(ctx->Bpad, 128);
     KTimer tm(ctx, KC_XPROD, st);
-    hipLaunchKernelGGL((k_xprod_compact<MT, KT, 5, TAIL>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(256), lds, st,
+    hipLaunchKernelGGL((k_xprod_compact<MT, KT, EPI, TAIL>), dim3(round_up(ncolblk, 8) * round_up(m, 8)), dim3(256), lds, st,
                        ptr<double>(ctx->Afrag_c), (size_t)nks_c * MT * 64, ptr<double>(ctx->Xc), ctx->Bpad, nks_c,
-                       ptr<double>(ctx->R), ctx->Bpad, 2 * ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
+                       ptr<double>(ctx->R), ctx->Bpad, (EPI == 8 ? 1 : 2) * ctx->Tpp, ptr<int>(ctx->out_row_c), ptr<int>(ctx->mom_idx_c),
                        ptr<double>(ctx->momn_m), m, ncolblk, se);
     LAUNCHCHK();
     return 0;
 }
 
-int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st)
+int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, bool raw)
 {
     const int MTc = ceil_div(ctx->Tp, 16);
+    if (raw) {
+        // (the one-pass reader exists for ceil(T'/4) = 5, 9, 13: the last tile always holds <= 4 live rows)
+        switch (MTc) {
+            case 2: return launch_xprod_compact<2, 6, true, 8>(ctx, m, nks_c, se, st);
+            case 3: return launch_xprod_compact<3, 4, true, 8>(ctx, m, nks_c, se, st);
+            case 4: return launch_xprod_compact<4, 3, true, 8>(ctx, m, nks_c, se, st);
+            default: return fail(ctx, PLSX_ERR_STATE, "raw compact split blocks: T' outside 17..52");
+        }
+    }
     // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
     const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !ctx->opt[OPT_SPLIT_NO_TAIL4];
     switch (MTc) {

@@ -360,7 +360,7 @@ try {
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
                    &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws, &ctx->pflags,
-                   &ctx->Cq, &ctx->Vsumq, &ctx->Vdq, &ctx->Vtq, &ctx->Afrag_q, &ctx->qpart})
+                   &ctx->Cq, &ctx->Vsumq, &ctx->Vdq, &ctx->Vtq, &ctx->Afrag_q, &ctx->qpart, &ctx->ccon, &ctx->sFt})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -508,7 +508,7 @@ try {
                     "cannot lay out the rows of a resample (with their per-cell moment rows) over cross-product blocks");
     if (int e = upload_rowmaps(ctx)) return e;
     if (int e = plan_sepmom(ctx)) return e;
-    ctx->fix = 0; ctx->has_Xn = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0;
+    ctx->fix = 0; ctx->has_Xn = 0; ctx->npgf = 0; ctx->group_stride_f = 0; ctx->has_cellS = 0; ctx->has_sFt = 0;
     {
         if (method == PLSX_BEHAVIORAL && !ctx->cov && !ctx->opt[OPT_NO_FIXED_X]) {
             // fixed-X fast path for permutations

@@ -39,13 +39,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
     OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
     OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_QUAD_MT, OPT_QUAD_FULL_ROWS, OPT_QUAD_LAUNCH_PER_BLOCK, OPT_COUNT
+    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_QUAD_MT, OPT_QUAD_FULL_ROWS, OPT_QUAD_LAUNCH_PER_BLOCK, OPT_SPLIT_TWO_READERS, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
     "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
     "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort", "quad_sums", "quad_mt", "quad_full_rows", "quad_launch_per_block"};
+    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort", "quad_sums", "quad_mt", "quad_full_rows", "quad_launch_per_block", "split_two_readers"};
 
 struct plsx_ctx {
     int device = 0;
@@ -97,6 +97,8 @@ struct plsx_ctx {
     int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
     long long n_refined = 0, n_unrefined = 0;           // host copies of status[1], status[2] since the last plsx_numeric_report
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
+    Buf ccon, sFt;                                      // one-pass split reader: column constants [pair][4][Bpad], cell std [J][Bpad]
+    int has_sFt = 0, split_raw = 0;                     // split_raw: the last compact split pass left raw first-half sums (one slot per split)
     int has_cellS = 0;
     int dual = 0, dual_ok = 0, has_Kd = 0;              // has_Kd: the S x S kernel of the bound data is current
     Buf okx, oky;                                       // regression: usable-row masks (NaN rows)
@@ -281,7 +283,7 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st);
 inline int quad_blocks(int tiles) { return std::max(ceil_div(tiles, 24), tiles >= 8 ? 2 : 1); }
 // ---- plsx_compact.hip ----
 int launch_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st);
-int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st);
+int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, bool raw = false);
 // ---- plsx_gram.hip ----
 int run_nt(plsx_ctx* ctx, const double* A, long long strideA, int lda, int Ma,
            const double* B1, long long strideB1, int ldb1, int N1,

@@ -1,14 +1,26 @@
 // plsx_split.hip -- split-half resampling (BasePLS.split_half) and cross-validation (BehavioralPLS.crossval)
 // Part of libplsx.so (plsx_internal.h has the map of translation units).  gfx950 only.
 #include "plsx_internal.h"
+#include "plsx_splitfused.h"
 
 using namespace plsxi;
 
 namespace plsxi {
 
+// The one-pass reader (plsx_splitfused.h) is instantiated for ceil(T'/4) = 5, 9, 13 row blocks (T' = 17..20, 33..36,
+// 49..52 -- the headline shape is 50): there the last tile of T' and of L always holds <= 4 live rows / LVs.
+bool split_reader_ok(const plsx_ctx* ctx)
+{
+    const int nb = ctx->nks_t;
+    return (nb == 5 || nb == 9 || nb == 13) && ctx->L == ctx->Tp && ctx->J <= SF_MAXJ && !ctx->opt[OPT_SPLIT_TWO_READERS] &&
+           (long long)ctx->Tpp * ctx->Bpad * 8 < (1LL << 31);
+}
+
 int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
                       hipStream_t st, const double* Yarr)
 {
+    const bool raw = split_reader_ok(ctx);
+    ctx->split_raw = raw ? 1 : 0;
     const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = 12 / MTc, rows = MTc * 16;
     ctx->last_compact_n = 0;                            // (the row tables are about to hold this pass's splits)
     if (!ctx->has_cellS) {
@@ -27,8 +39,9 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     const MomLayout ml = moment_layout(ctx, npairs);
     const int groups_m = ml.groups;
     const size_t mstride = ml.stride;
-    if (int e = ensure_scratch(ctx, std::min(ctx->Gcap, ceil_div(2 * m, ctx->npg)))) return e;
-    if ((size_t)2 * m * ctx->strideR * 8 > ctx->R.bytes) return fail(ctx, PLSX_ERR_STATE, "compact split: R scratch too small");
+    const int slots = raw ? m : 2 * m;                  // R slots of the pass: raw sums of a split / its two halves
+    if (int e = ensure_scratch(ctx, std::min(ctx->Gcap, ceil_div(slots, ctx->npg)))) return e;
+    if ((size_t)slots * ctx->strideR * 8 > ctx->R.bytes) return fail(ctx, PLSX_ERR_STATE, "compact split: R scratch too small");
     if (int e = ensure(ctx, ctx->Afrag_c, (size_t)m * astride * 8 + 4096)) return e;
     if (int e = ensure(ctx, ctx->rank_c, (size_t)m * S * sizeof(int))) return e;
     if (int e = ensure(ctx, ctx->rowtab_c, ((size_t)m * nks_c * 4 + m) * sizeof(int))) return e;
@@ -58,6 +71,23 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     se.scale = ptr<double>(ctx->m1_c); se.scale2 = ptr<double>(ctx->m2_c);
     se.npairs = npairs;
     if (int e = launch_moment_blocks_raw(ctx, ml, se, st)) return e;
+    if (raw) {
+        // column constants of every (split, cell) pair for the reader; the cells' full-sample std once per binding
+        if (int e = ensure(ctx, ctx->ccon, (size_t)npairs * 4 * ctx->Bpad * 8)) return e;
+        if (!ctx->has_sFt) {
+            if (int e = ensure(ctx, ctx->sFt, (size_t)J * ctx->Bpad * 8)) return e;
+            hipLaunchKernelGGL(k_cell_sd, dim3(ceil_div(ctx->Bpad, 256), J), dim3(256), 0, st, ptr<double>(ctx->cellS),
+                               ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad, ptr<int>(ctx->cell_len), ctx->Bpad,
+                               ptr<double>(ctx->sFt));
+            LAUNCHCHK();
+            ctx->has_sFt = 1;
+        }
+        KTimer tm(ctx, KC_MOM, st);
+        hipLaunchKernelGGL(k_split_colconst, dim3(ceil_div(ctx->Bpad, 256), npairs), dim3(256), 0, st, ptr<double>(ctx->m1_c),
+                           ptr<double>(ctx->m2_c), ptr<double>(ctx->momn_m), ptr<int>(ctx->cell_len), ptr<double>(ctx->cellS),
+                           ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad, J, ctx->Bpad, ptr<double>(ctx->ccon));
+        LAUNCHCHK();
+    }
     se.Rfull = Rfull;
     se.cellS1 = ptr<double>(ctx->cellS);
     se.cellS2 = ptr<double>(ctx->cellS) + (size_t)J * ctx->Bpad;
@@ -66,7 +96,72 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
     se.J = J; se.Tpp = ctx->Tpp;
     se.row_tab = ptr<int>(ctx->rowtab_c);
     se.row_cnt = ptr<int>(ctx->rowtab_c) + (size_t)m * nks_c * 4;
-    return launch_csplit(ctx, m, nks_c, se, st);
+    return launch_csplit(ctx, m, nks_c, se, st, raw);
+}
+
+// One pass over the raw first-half sums of the m splits run_split_compact just left in the R scratch (one slot per
+// split): cross-Gram partials of both halves (reduced into Cm, [2 m][T'][T']) and the feature-axis sums of the
+// projections (part2, [nchunk_u][m][5][lpad]).  Returns the number of partial "chunks" of part2 in *nchunk_u.
+template <int NB>
+int launch_split_fused(plsx_ctx* ctx, const SplitFusedArgs& a, int blocks, size_t lds, hipStream_t st)
+{
+    HIPCHK(set_lds(k_split_fused<NB>, lds));
+    hipLaunchKernelGGL((k_split_fused<NB>), dim3(blocks), dim3(512), lds, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
+int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mvd, hipStream_t st, int* nchunk_u)
+{
+    const int NB = ctx->nks_t, LT = ctx->LT, J = ctx->J, Tp = ctx->Tp, rows = ceil_div(Tp, 16) * 16;
+    const int nstage = ceil_div(ctx->B, SF_COLS), npb = ceil_div(m, 2);
+    // column chunks: a multiple of 8 (a chunk's blocks run on one XCD), enough blocks for whole rounds of the 256 CUs
+    // (one 8-wave block per CU), chunks of >= 64 stages
+    int nchunk = 8;
+    {
+        double best = 2.0;
+        for (int c = 8; c <= std::max(8, std::min(128, (nstage / 64) & ~7)); c += 8) {
+            const double rounds = (double)npb * c / 256.0;
+            const double waste = rounds < 1.0 ? 1.0 - rounds : (std::ceil(rounds) - rounds) / std::ceil(rounds);
+            if (waste < best - 1e-9) { best = waste; nchunk = c; }
+        }
+    }
+    int spc = ceil_div(nstage, nchunk);
+    nchunk = ceil_div(nstage, spc);
+    const int lpad = LT * 16;
+    if (int e = ensure(ctx, ctx->part, (size_t)nchunk * 2 * m * 2 * 4096 * 8)) return e;
+    if (int e = ensure(ctx, ctx->part2, (size_t)2 * nchunk * m * 5 * lpad * 8)) return e;
+    if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
+    SplitFusedArgs a;
+    a.C1 = ptr<double>(ctx->R); a.strideR = ctx->strideR; a.ldr = ctx->Bpad;
+    a.Rp = Rfull; a.Mfrag = Mvd;
+    a.rowc = ptr<double>(ctx->rowc); a.rows_rc = rows;
+    a.cc = ptr<double>(ctx->ccon); a.sFt = ptr<double>(ctx->sFt);
+    a.J = J; a.T = ctx->T; a.Tp = Tp; a.B = ctx->B;
+    a.stages_per_chunk = spc; a.nchunk = nchunk; a.nsplits = m;
+    a.gpart = ptr<double>(ctx->part); a.upart = ptr<double>(ctx->part2); a.lpad = lpad;
+    const size_t lds = ((size_t)2 * 5 * (4 * NB * SF_PITCH + SF_TILE_PAD) + (size_t)2 * 9 * J * 16 +
+                        (size_t)NB * ((LT + 1) / 2) * 128 + (size_t)4 * NB * 10) * 8;
+    const int blocks = 8 * ceil_div(nchunk, 8) * npb;
+    {
+        KTimer tm(ctx, KC_UCORR, st);
+        int rc;
+        switch (NB) {
+            case 5: rc = launch_split_fused<5>(ctx, a, blocks, lds, st); break;
+            case 9: rc = launch_split_fused<9>(ctx, a, blocks, lds, st); break;
+            case 13: rc = launch_split_fused<13>(ctx, a, blocks, lds, st); break;
+            default: return fail(ctx, PLSX_ERR_STATE, "split reader: unsupported T'");
+        }
+        if (rc) return rc;
+    }
+    {
+        KTimer tm(ctx, KC_GRAM, st);
+        hipLaunchKernelGGL(k_reduce_part, dim3(ceil_div(Tp * Tp, 256), 2 * m), dim3(256), 0, st, ptr<double>(ctx->part),
+                           nchunk, 2 * m, 1, 1, 1, ptr<double>(ctx->Cm), (long long)Tp * Tp, Tp, Tp, Tp, 0);
+        LAUNCHCHK();
+    }
+    *nchunk_u = 2 * nchunk;
+    return 0;
 }
 
 int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m, const double* Rfull,
@@ -117,6 +212,8 @@ int run_split_fused(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int m,
 }  // namespace plsxi
 
 extern "C" {
+
+int plsx_split_route(const plsx_ctx* ctx) { return ctx ? ctx->split_raw : 0; }
 
 int plsx_split_half_batch(plsx_ctx* ctx, const int32_t* d_perm_idx, int np, const uint8_t* d_masks,
                           int ns, double* d_ucorr, double* d_vcorr, void* stream)
@@ -180,6 +277,7 @@ try {
             const double* Yarr = d_ystack ? d_ystack + (size_t)p * ysz : nullptr;     // this arrangement's Y
             for (int off = 0; off < ns; off += spp) {
                 const int m = std::min(spp, ns - off);               // splits in this pass
+                ctx->split_raw = 0;
                 if (fused) {
                     if (int e = run_split_fused(ctx, perm, d_masks + ((size_t)p * ns + off) * S, m, Rfull, st, Yarr))
                         return e;
@@ -194,25 +292,32 @@ try {
                                           2 * m, st, false, Yarr, 0))
                         return e;
                 }
-                // C_h = D_h . R_p^T  (T' x T')
-                if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
-                if (int e = run_gram_ex(ctx, 2 * m, 2, Rfull, Tp, ptr<double>(ctx->Cm), st)) return e;
-                // feature-axis sums of E_h = D_h^T . vd
-                const int ntile = ceil_div(ctx->B, 16);
-                int nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
-                {
-                    // whole rounds of resident blocks: 100 splits x 21 chunks = 4.1 rounds of 512 left the chip
-                    // nearly empty for a fifth of the kernel
-                    const int slots = ucorr_slots();
-                    nchunk = pick_parts(m, slots, std::max(1, (nchunk * 2) / 3), std::min(std::max(1, ntile / 8), 2 * nchunk));
-                }
-                const int tpc = ceil_div(ntile, nchunk);
-                nchunk = ceil_div(ntile, tpc);
                 const int lpad = ctx->LT * 16;
-                if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
-                dim3 grid(nchunk, m), block(256);
-                if (int e = launch_ucorr(ctx, grid, block, st, Mvd, tpc, ptr<double>(ctx->part2), m)) return e;
-                LAUNCHCHK();
+                int nchunk = 1;
+                if (fused && ctx->split_raw) {
+                    // raw first-half sums in the scratch: ONE reader pass forms the cross-Gram of both halves and the
+                    // feature-axis sums of their projections (plsx_splitfused.h)
+                    if (int e = run_split_reader(ctx, m, Rfull, Mvd, st, &nchunk)) return e;
+                } else {
+                    // C_h = D_h . R_p^T  (T' x T')
+                    if (int e = ensure(ctx, ctx->Cm, (size_t)2 * m * Tp * Tp * 8)) return e;
+                    if (int e = run_gram_ex(ctx, 2 * m, 2, Rfull, Tp, ptr<double>(ctx->Cm), st)) return e;
+                    // feature-axis sums of E_h = D_h^T . vd
+                    const int ntile = ceil_div(ctx->B, 16);
+                    nchunk = std::min(std::max(1, ceil_div(2048, m)), std::max(1, ntile / 8));
+                    {
+                        // whole rounds of resident blocks: 100 splits x 21 chunks = 4.1 rounds of 512 left the chip
+                        // nearly empty for a fifth of the kernel
+                        const int slots = ucorr_slots();
+                        nchunk = pick_parts(m, slots, std::max(1, (nchunk * 2) / 3), std::min(std::max(1, ntile / 8), 2 * nchunk));
+                    }
+                    const int tpc = ceil_div(ntile, nchunk);
+                    nchunk = ceil_div(ntile, tpc);
+                    if (int e = ensure(ctx, ctx->part2, (size_t)nchunk * m * 5 * lpad * 8)) return e;
+                    dim3 grid(nchunk, m), block(256);
+                    if (int e = launch_ucorr(ctx, grid, block, st, Mvd, tpc, ptr<double>(ctx->part2), m)) return e;
+                    LAUNCHCHK();
+                }
                 hipLaunchKernelGGL(k_split_final, dim3(m), dim3(256), (size_t)4 * 256 * 5 * 8, st,
                                    ptr<double>(ctx->part2), nchunk, m,
                                    lpad, ptr<double>(ctx->Cm), Vp, dp, Tp, L, ctx->B,

@@ -63,6 +63,7 @@ def _load():
         'plsx_boot_begin': ([vp, ctypes.c_longlong, vp], i32),
         'plsx_boot_finish': ([vp, vp, vp, vp], i32),
         'plsx_boot_route': ([vp], i32),
+        'plsx_split_route': ([vp], i32),
         'plsx_split_half_batch': ([vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_split_half_batch_y': ([vp, vp, vp, i32, vp, i32, vp, vp, vp], i32),
         'plsx_boot_rel': ([vp, vp, vp, vp, i32, i32, ctypes.c_longlong, vp, vp, vp], i32),
@@ -107,7 +108,7 @@ def exported_symbols():
     names = ['plsx_version', 'plsx_max_tprime', 'plsx_ctx_create', 'plsx_ctx_destroy',
              'plsx_last_error', 'plsx_sync', 'plsx_set_data', 'plsx_num_lv', 'plsx_tprime',
              'plsx_crosscov_batch', 'plsx_decompose', 'plsx_set_original', 'plsx_project',
-             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_boot_begin', 'plsx_boot_finish', 'plsx_boot_route', 'plsx_split_half_batch', 'plsx_split_half_batch_y',
+             'plsx_colmean', 'plsx_perm_batch', 'plsx_perm_batch_y', 'plsx_crossval_batch', 'plsx_boot_batch', 'plsx_boot_begin', 'plsx_boot_finish', 'plsx_boot_route', 'plsx_split_route', 'plsx_split_half_batch', 'plsx_split_half_batch_y',
              'plsx_boot_rel', 'plsx_last_timing', 'plsx_set_timing', 'plsx_kernel_timing',
              'plsx_kernel_class_name', 'plsx_set_perm_path', 'plsx_set_scratch', 'plsx_mfma_f64_peak',
              'plsx_percentile_ci', 'plsx_simpls_decompose', 'plsx_simpls_set_original', 'plsx_simpls_perm_batch',
@@ -520,6 +521,10 @@ class Engine(object):
         self.sync()
         return (np.ascontiguousarray(uc.cpu().numpy().transpose(0, 2, 1)),
                 np.ascontiguousarray(vc.cpu().numpy().transpose(0, 2, 1)))
+
+    def split_route(self):
+        """1 when the last split-half pass took the one-pass reader over raw first-half sums (plsx_split_route)."""
+        return int(self.lib.plsx_split_route(self.ctx))
 
     def crossval(self, splits):
         """splits (S, m) bool, True = training row -> pearson_r, r_squared (T, m)."""

@@ -460,3 +460,51 @@ def test_device_side_finishing_steps():
     lo, hi = eng.percentile_ci_dev(series, ci=95)
     wl, wh = np.percentile(series.cpu().numpy(), [2.5, 97.5], axis=-1)
     assert np.array_equal(lo.cpu().numpy(), wl) and np.array_equal(hi.cpu().numpy(), wh)
+
+
+@pytest.mark.parametrize('shape', [
+    (120, 1235, 50, [120], 1),          # the headline T' = 50 (13 row blocks), B not a multiple of 16
+    (64, 1000, 25, [32, 32], 1),        # T' = 2 cells x 25 = 50: per-cell column constants
+    (90, 700, 18, [90], 1),             # T' = 18 (5 row blocks)
+    (96, 520, 12, [16, 16], 3),         # T' = 6 cells x 12 = 72: outside the reader's shapes -> the two-kernel route (asserted)
+    (108, 900, 12, [36], 3),            # T' = 3 cells x 12 = 36 (9 row blocks)
+    (130, 40000, 52, [130], 1),         # T' = 52: no padding row in the last block; several column chunks
+])
+def test_split_half_one_pass_reader(shape, monkeypatch):
+    """Split-half with ONE reader pass over the raw first-half sums (k_xprod_compact epilogue 8 + k_split_fused) against
+    the two-kernel route over both z-scored halves (option split_two_readers) and against the oracle: original and
+    permuted arrangements, pre-permuted Y stacks, an odd number of splits (the last pair of a block is one split)."""
+    from pypyls_amd import resampling as rsmp
+    S, B, T, groups, n_cond = shape
+    X, Y, rs = _data(S, B, T, seed=31)
+    n_split, n_arr = 7, 2
+    perms = rsmp.gen_permsamp(groups, n_cond, n_arr, seed=5)
+    masks = np.stack([rsmp.gen_splits(groups, n_cond, n_split, seed=40 + i) for i in range(1 + n_arr)])
+    Tp = len(groups) * n_cond * T
+    expect_route = 1 if (-(-Tp // 4)) in (5, 9, 13) and len(groups) * n_cond <= 7 else 0
+    got = {}
+    for key in ('one_pass', 'two_readers'):
+        monkeypatch.delenv('PLSX_SPLIT_TWO_READERS', raising=False)
+        if key == 'two_readers':
+            monkeypatch.setenv('PLSX_SPLIT_TWO_READERS', '1')
+        eng = _engine()
+        spec = _setup(eng, X, Y, groups, n_cond)
+        a = eng.split_half(masks[0])
+        assert eng.split_route() == (expect_route if key == 'one_pass' else 0)
+        b = eng.split_half(masks[1:], perms=perms)
+        c = eng.split_half(masks[1:], ystack=np.stack([Y[perms[:, p]] for p in range(n_arr)]))
+        got[key] = (a, b, c)
+    for a, b in zip(got['one_pass'], got['two_readers']):
+        for x, y in zip(a, b):
+            assert_close(x, y, 1e-9, what='one reader pass vs two readers')
+    for x, y in zip(got['one_pass'][1], got['one_pass'][2]):
+        assert_close(x, y, 1e-12, what='index permutation vs pre-permuted Y')
+    uc, vc = got['one_pass'][1]
+    for p in range(n_arr):
+        Xp, Yp = ref.make_permutation(spec, X, Y, perms[:, p])
+        U, d, V = ref.decompose(spec, Xp, Yp)
+        di = np.linalg.inv(d)
+        for i in (0, n_split - 1):
+            u, v = ref.split_half(spec, Xp, Yp, U @ di, V @ di, masks[1 + p][:, [i]])
+            assert_close(uc[p][:, i], u, 1e-7, what='ucorr vs oracle')
+            assert_close(vc[p][:, i], v, 1e-7, what='vcorr vs oracle')

@@ -21,5 +21,5 @@ with open(sys.argv[2], "w") as f:
     for (k, c), v in sorted(acc.items()):
         if k.startswith("k_"):
             f.write('"%s",%d,%s,%.1f\n' % (k, len(disp[k]), c, v))
-            if any(s in k for s in ("k_xprod", "k_nt_gemm", "k_sd_step", "k_dual_gp")): print(k[:44], len(disp[k]), c, v)
+            if any(s in k for s in ("k_xprod", "k_nt_gemm", "k_sd_step", "k_dual_gp", "k_split_fused", "k_gram4", "k_ucorr", "k_urot")): print(k[:44], len(disp[k]), c, v)
 PY

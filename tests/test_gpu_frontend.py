@@ -306,3 +306,50 @@ def test_calls_without_permutations_or_bootstraps(n_perm, n_boot):
             assert res.permres.perm_singval.shape == (len(res.singvals), n_perm)
         if n_boot:
             assert res.bootres.x_weights_normed.shape == res.x_weights.shape
+
+
+def _flatten(res, prefix=''):
+    out = {}
+    for k, v in dict(res).items():
+        if k == 'inputs':
+            continue
+        if hasattr(v, 'keys'):
+            out.update(_flatten(v, prefix + k + '.'))
+        elif isinstance(v, np.ndarray) and v.dtype != object:
+            out[prefix + k] = v
+    return out
+
+
+@pytest.mark.parametrize('method', ['behavioral', 'behavioral_cov', 'meancentered', 'regression'])
+def test_results_are_bit_reproducible(method, monkeypatch):
+    """the same analysis twice gives the SAME BITS in every result array -- nothing in the
+    resampling path depends on the order in which concurrent threads' floating-point adds land (accumulating
+    cross-product epilogue: fixed-order reduce; A-operand build: duplicates of a source row carry bit-identical
+    addends; super-batch sizes: a function of the shard only).  The per-bootstrap feature pass of the unscaled modes
+    (the route short series and 8-rank shards take) is forced as well as the default route."""
+    import pypyls_amd as pls
+    rs = np.random.RandomState(17)
+    S, B, T = 72, 1500, 6
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.4 * X[:, :T]
+    kw = dict(n_perm=64, n_boot=64, seed=99, verbose=False)
+
+    def call():
+        if method == 'behavioral':
+            return pls.behavioral_pls(X, Y, groups=[36, 36], n_split=5, test_split=10, **kw)
+        if method == 'behavioral_cov':
+            return pls.behavioral_pls(X, Y, groups=[36, 36], covariance=True, test_split=0, **kw)
+        if method == 'meancentered':
+            return pls.meancentered_pls(X, groups=[18, 18], n_cond=2, n_split=5, **kw)
+        return pls.pls_regression(X, Y, n_components=4, **kw)
+    for quad in ('0', '-1'):
+        monkeypatch.setenv('PLSX_QUAD_SUMS', quad)
+        from pypyls_amd import engine
+        engine.release_default_engine()
+        eng = engine.default_engine()
+        eng.set_option('quad_sums', int(quad))
+        a, b = _flatten(call()), _flatten(call())
+        assert set(a) == set(b) and len(a) >= 8
+        for k in sorted(a):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (method, quad, k, np.nanmax(np.abs(a[k] - b[k])))
+    engine.release_default_engine()

@@ -17,7 +17,7 @@ COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_symeig.h']
 EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_simpls_api': ['plsx_simpls.h'], 'plsx_split': ['plsx_splitfused.h']}
 PUBLIC = os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')
 LIB = os.path.join(HERE, 'libplsx.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-function']
 
 
 def lib_path():

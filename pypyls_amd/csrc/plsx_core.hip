@@ -360,7 +360,7 @@ try {
                    &ctx->Xn, &ctx->out_row_f, &ctx->mom_idx_f, &ctx->Kd, &ctx->Ad, &ctx->Wd, &ctx->gws, &ctx->cellS, &ctx->rowc, &ctx->out_row_s, &ctx->okx, &ctx->oky, &ctx->psum, &ctx->psq, &ctx->row_slice, &ctx->row_local, &ctx->slice_cell0, &ctx->cell_momrow, &ctx->status, &ctx->ScT, &ctx->out_row_w, &ctx->Qs, &ctx->out_row_d, &ctx->mom_idx_d, &ctx->Afrag_m, &ctx->momn_m, &ctx->scale,
                    &ctx->Afrag_c, &ctx->rank_c, &ctx->rowtab_c, &ctx->m1_c, &ctx->m2_c, &ctx->out_row_c, &ctx->mom_idx_c, &ctx->mask_c,
                    &ctx->refV, &ctx->refLam, &ctx->refK0, &ctx->refPart, &ctx->refPartP, &ctx->refH, &ctx->flipws, &ctx->pflags,
-                   &ctx->Cq, &ctx->Vsumq, &ctx->Vdq, &ctx->Vtq, &ctx->Afrag_q, &ctx->qpart, &ctx->ccon, &ctx->sFt})
+                   &ctx->Cq, &ctx->Vsumq, &ctx->Vdq, &ctx->Vtq, &ctx->Afrag_q, &ctx->qpart, &ctx->ccon, &ctx->sFt, &ctx->Yrot})
         release(*b);
     for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.e0); (void)hipEventDestroy(ev.e1); }
     delete ctx;
@@ -596,7 +596,7 @@ try {
     if (int e = run_gram(ctx, 1, false, st)) return e;
     SmallArgs a = small_args(ctx, SMALL_DECOMP);
     a.out_V = d_yw; a.out_d = d_sv;
-    const bool fix = ctx->Tp <= PLSX_JACOBI_TP && ctx->Tp > 1 && !ctx->opt[OPT_NO_REFINE];
+    const bool fix = ctx->Tp > 1 && !ctx->opt[OPT_NO_REFINE];
     if (fix) {
         if (int e = ensure(ctx, ctx->refH, (size_t)ctx->L * ctx->L * 8)) return e;
         a.out_H = ptr<double>(ctx->refH);
@@ -743,7 +743,8 @@ int perm_dual(plsx_ctx* ctx, const int32_t* d_perm_idx, const double* d_ystack, 
                                lay, ctx->cov, 0, ptr<double>(ctx->Ad), (size_t)0, (double*)nullptr, 0, Sd);
         } else {
             hipLaunchKernelGGL(k_build_A_mc, dim3(m), dim3(256), 0, st, S, ctx->J, ctx->n_cond, ctx->mc,
-                               ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd);
+                               ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd,
+                               -1);                           // (a permutation repeats no row: plain stores)
         }
         LAUNCHCHK();
         // W = A K  (all permutations stacked: (m T') x S)
@@ -885,14 +886,19 @@ int boot_single_pass(plsx_ctx* ctx, const int32_t* d_boot_idx, int n, double* d_
         const int* idx = d_boot_idx + (size_t)off * S;
         {
             KTimer tm(ctx, KC_BUILD, st);
-            if (ctx->method == PLSX_BEHAVIORAL)
-                hipLaunchKernelGGL(k_build_A_behav, dim3(m, ctx->J), dim3(256), (size_t)2 * ctx->T * 8, st,
+            int cap = 0;
+            if (ctx->method == PLSX_BEHAVIORAL) {
+                const size_t lds = build_lds_behav(ctx, &cap);
+                hipLaunchKernelGGL(k_build_A_behav, dim3(m, ctx->J), dim3(256), lds, st,
                                    ptr<double>(ctx->Y), 0LL, ctx->T, S, ptr<int>(ctx->cell_start),
                                    ptr<int>(ctx->cell_len), idx, idx, lay, ctx->cov, 0, ptr<double>(ctx->Ad),
-                                   (size_t)0, (double*)nullptr, 0, Sd);
-            else
-                hipLaunchKernelGGL(k_build_A_mc, dim3(m), dim3(256), 0, st, S, ctx->J, ctx->n_cond, ctx->mc,
-                                   ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd);
+                                   (size_t)0, (double*)nullptr, 0, Sd, (double*)nullptr, (size_t)0, (const int*)nullptr,
+                                   PLSX_MOM_PAIRS, cap);
+            } else {
+                const size_t lds = build_lds_mc(ctx, &cap);
+                hipLaunchKernelGGL(k_build_A_mc, dim3(m), dim3(256), lds, st, S, ctx->J, ctx->n_cond, ctx->mc,
+                                   ptr<int>(ctx->cell_of_row), idx, lay, ptr<double>(ctx->Ad), (size_t)0, Sd, cap);
+            }
             LAUNCHCHK();
         }
         // W = A K (all resamples stacked), G_r = W_r A_r^T, P_r = A_r Sc

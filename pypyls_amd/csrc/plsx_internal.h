@@ -93,7 +93,7 @@ struct plsx_ctx {
     Buf status;                                         // device words: [0] numerical status bits of the small solvers, [1] refined, [2] graded but unrefined resamples
     Buf pflags;                                         // plsx_percentile_ci: series the selection kernel left to the full sort
     Buf flipws;                                         // plsx_svd_flip: column maxima, their rows, the signs
-    Buf refV, refLam, refK0, refPart, refPartP, refH;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
+    Buf refV, refLam, refK0, refPart, refPartP, refH, Yrot;                   // graded spectra: parked eigenvectors / eigenvalues / first small rank, partial refined Grams
     int graded = 0;                                     // the ORIGINAL spectrum has live LVs below PLSX_REFINE_TAU d_max: no dual-space routes
     long long n_refined = 0, n_unrefined = 0;           // host copies of status[1], status[2] since the last plsx_numeric_report
     Buf cellS, rowc, out_row_s;                         // fused split-half: cell moments of X, row constants, row map
@@ -253,6 +253,26 @@ inline int use_dual(const plsx_ctx* ctx) { return (ctx->dual && !ctx->graded) ? 
     if (!ctx->has_orig) return fail(ctx, PLSX_ERR_STATE, "plsx_set_original has not been called")
 
 struct MomLayout { int pairs, mt, groups; size_t stride; };
+
+// Dynamic LDS of the A-operand builders with room for the occurrence chains of a cell's (k_build_A_behav) / of all S
+// (k_build_A_mc) positions: 2 ints per position behind the 2 T doubles; *cap = ints granted (0: cells too large for
+// the tables -> the kernel falls back to atomic adds).
+inline size_t build_lds_behav(const plsx_ctx* ctx, int* cap)
+{
+    int ml = 0;
+    for (int v : ctx->h_cell_len) ml = std::max(ml, v);
+    const size_t base = (size_t)2 * ctx->T * 8, ints = (size_t)2 * ml;
+    if (base + ints * 4 > 60 * 1024) { *cap = 0; return base; }
+    *cap = (int)ints;
+    return base + ints * 4;
+}
+inline size_t build_lds_mc(const plsx_ctx* ctx, int* cap)
+{
+    const size_t ints = (size_t)2 * ctx->S;
+    if (ints * 4 > 60 * 1024) { *cap = 0; return 0; }
+    *cap = (int)ints;
+    return ints * 4;
+}
 
 // ---- plsx_core.hip ----
 int plan_groups(plsx_ctx* c);

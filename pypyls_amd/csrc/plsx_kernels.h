@@ -173,8 +173,15 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
                                 double* __restrict__ Afrag, size_t group_stride,
                                 double* __restrict__ mom_n, int nmom_pad, int dense_ld = 0,
                                 double* __restrict__ Amom = nullptr, size_t mom_stride = 0,
-                                const int* __restrict__ rank = nullptr, int mom_pairs = PLSX_MOM_PAIRS)
+                                const int* __restrict__ rank = nullptr, int mom_pairs = PLSX_MOM_PAIRS,
+                                int chain_cap = 0)
 {
+    // chain_cap: how duplicates of a source row inside a cell (bootstraps) are added up.  > 0: that many ints of
+    // dynamic LDS behind the 2 T doubles hold, per position of the cell, the NEXT position with the same source row
+    // and a "not the first" flag; the thread of the first occurrence adds the contributions of its chain in
+    // position order and stores once -- a fixed summation order, no atomics (round 5; fp64 atomicAdd before).
+    // -1: the caller guarantees that no source row repeats (permutations): plain stores.  0: atomics (cells too
+    // large for the LDS tables).  xsrc == nullptr never repeats a row.
     // mom_pairs: pairs per moment-only block (192 = 12 + 12 tiles, or 128 = 8 + 8 when that issues fewer tiles)
     // rank != nullptr (compact layout, one resample per group, with Amom): the contraction index of source
     // row xi is its rank among the rows the resample draws (k_split_rank over k_drawn_mask); the weight
@@ -232,21 +239,63 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
     const double inv_nm1 = 1.0 / (double)(cnt - 1);
     const int total = len * T;
     const bool sliced = lay.gps > 0 && !dense_ld;
+    // occurrence chains of the cell's positions (see chain_cap)
+    int* nxt = reinterpret_cast<int*>(sm_b + 2 * T);
+    int* nfirst = nxt + len;
+    const bool unique = !xs || chain_cap < 0;
+    const bool chains = !unique && 2 * len <= chain_cap;
+    if (chains) {
+        for (int pl = tid; pl < len; pl += blockDim.x) nfirst[pl] = 0;
+        __syncthreads();
+        for (int pl = tid; pl < len; pl += blockDim.x) {
+            const int xi = xs[start + pl];
+            int nx = -1;
+            if (xi >= 0)
+                for (int q = pl + 1; q < len; ++q)
+                    if (xs[start + q] == xi) { nx = q; break; }
+            nxt[pl] = nx;
+            if (nx >= 0) nfirst[nx] = 1;                     // (a position has at most one predecessor)
+        }
+        __syncthreads();
+    }
     for (int idx = tid; idx < total; idx += blockDim.x) {
         int pl = idx / T, t = idx - pl * T;
         int p = start + pl;
         int xi = xs ? xs[p] : p;
         if (xi < 0) continue;
-        int yi = ys ? ys[p] : p;
-        double v = (Y[(size_t)yi * T + t] - mean[t]) * rstd[t] * inv_nm1;
+        double v;
+        if (chains) {
+            if (nfirst[pl]) continue;
+            v = 0.0;
+            for (int q = pl; q >= 0; q = nxt[q]) {
+                const int yq = ys ? ys[start + q] : start + q;
+                v += (Y[(size_t)yq * T + t] - mean[t]) * rstd[t] * inv_nm1;
+            }
+        } else {
+            int yi = ys ? ys[p] : p;
+            v = (Y[(size_t)yi * T + t] - mean[t]) * rstd[t] * inv_nm1;
+        }
         int row = rr * lay.Tp + j * T + t;
-        if (dense_ld) atomicAdd(Afrag + ((size_t)r * lay.Tp + j * T + t) * dense_ld + xi, v);
+        double* dst;
+        if (dense_ld) dst = Afrag + ((size_t)r * lay.Tp + j * T + t) * dense_ld + xi;
         else if (sliced) {
             const int grow = j * T + t;
-            atomicAdd(Afrag + ((size_t)r * lay.gps + lay.row_slice[grow]) * group_stride +
-                      afrag_off(lay.row_local[grow], xi, lay.MT), v);
-        } else atomicAdd(A + afrag_off(row, rank ? rank[(size_t)r * S + xi] : xi, lay.MT), v);
+            dst = Afrag + ((size_t)r * lay.gps + lay.row_slice[grow]) * group_stride +
+                  afrag_off(lay.row_local[grow], xi, lay.MT);
+        } else dst = A + afrag_off(row, rank ? rank[(size_t)r * S + xi] : xi, lay.MT);
+        if (chains || unique) *dst = v;                      // (the operand was zeroed by the caller; one writer per entry)
+        else atomicAdd(dst, v);
     }
+    // weight (multiplicity) rows: the chain's length, stored once; without chains exact integer adds (any order)
+    auto put_weight = [&](double* d0, double* d1, int pl) {
+        if (chains) {
+            if (nfirst[pl]) return;
+            double c = 0.0;
+            for (int q = pl; q >= 0; q = nxt[q]) c += 1.0;
+            *d0 = c; *d1 = c;
+        } else if (unique) { *d0 = 1.0; *d1 = 1.0; }
+        else { atomicAdd(d0, 1.0); atomicAdd(d1, 1.0); }
+    };
     if (scaled && sliced) {
         // every slice that holds rows of cell j carries the cell's moment rows
         const int sa = lay.row_slice[j * T], sb = lay.row_slice[j * T + T - 1];
@@ -258,8 +307,7 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
                 int p = start + pl;
                 int xi = xs ? xs[p] : p;
                 if (xi < 0) continue;
-                atomicAdd(As + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), 1.0);
-                atomicAdd(As + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), 1.0);
+                put_weight(As + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), As + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), pl);
             }
             if (tid == 0) mom_n[gg * nmom_pad + mrow] = (double)cnt;
         }
@@ -271,8 +319,7 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
             int p = start + pl;
             int xi = xs ? xs[p] : p;
             if (xi < 0) continue;
-            atomicAdd(Am + afrag_off(mrow, xi, mmt), 1.0);
-            atomicAdd(Am + afrag_off(mom_pairs + mrow, xi, mmt), 1.0);
+            put_weight(Am + afrag_off(mrow, xi, mmt), Am + afrag_off(mom_pairs + mrow, xi, mmt), pl);
         }
         if (tid == 0) mom_n[pair] = (double)cnt;
     } else if (scaled) {
@@ -281,8 +328,7 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
             int xi = xs ? xs[p] : p;
             if (xi < 0) continue;
             int mrow = rr * lay.J + j;
-            atomicAdd(A + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), 1.0);
-            atomicAdd(A + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), 1.0);
+            put_weight(A + afrag_off(lay.w0 * 16 + mrow, xi, lay.MT), A + afrag_off(lay.sq0 * 16 + mrow, xi, lay.MT), pl);
         }
         if (tid == 0) mom_n[(size_t)g * nmom_pad + rr * lay.J + j] = (double)cnt;
     }
@@ -294,8 +340,11 @@ static __global__ void k_build_A_behav(const double* __restrict__ Y0, long long 
 static __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering,
                              const int* __restrict__ cell_of_pos,
                              const int* __restrict__ xsrc, GroupLayout lay,
-                             double* __restrict__ Afrag, size_t group_stride, int dense_ld = 0)
+                             double* __restrict__ Afrag, size_t group_stride, int dense_ld = 0, int chain_cap = 0)
 {
+    // chain_cap as in k_build_A_behav: > 0 ints of dynamic LDS for the occurrence chains of the S positions (a source
+    // row drawn several times gets its coefficients added in position order by ONE thread); -1: no repeats; 0: atomics
+    extern __shared__ int sm_mc[];
     __shared__ int cnt[PLSX_MAX_CELLS];
     const int r = blockIdx.x;
     const int g = r / lay.n, rr = r % lay.n;
@@ -310,26 +359,57 @@ static __global__ void k_build_A_mc(int S, int J, int n_cond, int mean_centering
     int ntot = 0;
     for (int j = 0; j < J; ++j) ntot += cnt[j];
     double* A = Afrag + (size_t)g * group_stride;
+    int* nxt = sm_mc;
+    int* nfirst = sm_mc + S;
+    const bool unique = !xs || chain_cap < 0;
+    const bool chains = !unique && 2 * S <= chain_cap;
+    if (chains) {
+        for (int p = tid; p < S; p += blockDim.x) nfirst[p] = 0;
+        __syncthreads();
+        for (int p = tid; p < S; p += blockDim.x) {
+            const int xi = xs[p];
+            int nx = -1;
+            if (xi >= 0)
+                for (int q = p + 1; q < S; ++q)
+                    if (xs[q] == xi) { nx = q; break; }
+            nxt[p] = nx;
+            if (nx >= 0) nfirst[nx] = 1;
+        }
+        __syncthreads();
+    }
+    auto coef_of = [&](int p, int j2) -> double {
+        const int j = cell_of_pos[p];
+        const int gj = j / n_cond, cj = j % n_cond;
+        const double own = 1.0 / (double)cnt[j];
+        double coef = (j2 == j) ? own : 0.0;
+        if (mean_centering == 0) {
+            if (j2 / n_cond == gj) {
+                int ngrp = 0;
+                for (int c = 0; c < n_cond; ++c) ngrp += cnt[gj * n_cond + c];
+                coef -= 1.0 / (double)ngrp;
+            }
+        } else if (mean_centering == 1) {
+            if (j2 % n_cond == cj) coef -= own / (double)n_groups;
+        } else {
+            coef -= 1.0 / (double)ntot;
+        }
+        return coef;
+    };
     for (int p = tid; p < S; p += blockDim.x) {
         int xi = xs ? xs[p] : p;
         if (xi < 0) continue;
-        int j = cell_of_pos[p];
-        int gj = j / n_cond, cj = j % n_cond;
-        double own = 1.0 / (double)cnt[j];
-        int ngrp = 0;
-        for (int c = 0; c < n_cond; ++c) ngrp += cnt[gj * n_cond + c];
+        if (chains && nfirst[p]) continue;
         for (int j2 = 0; j2 < J; ++j2) {
-            double coef = (j2 == j) ? own : 0.0;
-            if (mean_centering == 0) {
-                if (j2 / n_cond == gj) coef -= 1.0 / (double)ngrp;
-            } else if (mean_centering == 1) {
-                if (j2 % n_cond == cj) coef -= own / (double)n_groups;
-            } else {
-                coef -= 1.0 / (double)ntot;
-            }
+            double coef;
+            if (chains) {
+                coef = 0.0;
+                for (int q = p; q >= 0; q = nxt[q]) coef += coef_of(q, j2);
+            } else coef = coef_of(p, j2);
             if (coef == 0.0) continue;
-            if (dense_ld) atomicAdd(Afrag + ((size_t)r * lay.Tp + j2) * dense_ld + xi, coef);
-            else atomicAdd(A + afrag_off(rr * lay.Tp + j2, xi, lay.MT), coef);
+            double* dst = dense_ld ? Afrag + ((size_t)r * lay.Tp + j2) * dense_ld + xi
+                                   : A + afrag_off(rr * lay.Tp + j2, xi, lay.MT);
+            if (chains || unique) *dst = coef;
+            else atomicAdd(dst, coef);
         }
     }
 }
@@ -873,16 +953,24 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         const int Srows = se.accB;
         const double* Xc = X + col - (size_t)(ks0 * 4) * ldx;   // (X was advanced to the block's first contraction row)
         double part = 0.0;
+        // in batches of four tiles: with the loop fully unrolled hipcc hoists all 4 MT loads above the first
+        // multiply (168 registers at MT = 21: 173 VGPRs spilled next to the accumulators)
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            double xv[4];
+        for (int m0 = 0; m0 < MT; m0 += 4) {
+            asm volatile("" ::: "memory");
+            double xv[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int sr = s0 + m * 16 + kq + 4 * i;
-                xv[i] = sr < Srows ? Xc[(size_t)sr * ldx] : 0.0;
-            }
+            for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) part += xv[i] * acc[m][i];
+                for (int i = 0; i < 4; ++i) {
+                    const int sr = s0 + (m0 + mm) * 16 + kq + 4 * i;
+                    xv[mm][i] = (m0 + mm < MT && sr < Srows) ? Xc[(size_t)sr * ldx] : 0.0;
+                }
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (m0 + mm < MT) part += xv[mm][i] * acc[m0 + mm][i];
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
@@ -890,26 +978,37 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         return;
     }
     if constexpr (EPI == 2) {
-        // accumulate over the resamples of the group: LDS [2][L][ACCP] (the A stages are dead)
+        // accumulate over the resamples of the group, in a FIXED order (round 5; LDS atomics before: the order in which
+        // concurrent adds land is not defined).  The block's (MT * 16 x NW * 16) tile goes through LDS two M tiles at a
+        // time; thread (l, column) -- the only writer of its cell -- adds the rows that carry its LV in increasing row
+        // order.  LDS: [2][L][ACCP] sums, [32][ACCP] staging, the row -> l map (the A stages are dead).
         constexpr int ACCP = NW * 16 + 16;      // LDS pitch of an l-row (PLSX_ACC_PITCH for 4 waves)
+        constexpr int BCW = NW * 16;
         const int L = se.accL;
         double* sU = smem;
         double* sV = smem + (size_t)L * ACCP;
-        int* s_l = reinterpret_cast<int*>(sV + (size_t)L * ACCP);
+        double* sT = sV + (size_t)L * ACCP;                  // [32][ACCP]
+        int* s_l = reinterpret_cast<int*>(sT + 32 * ACCP);
         for (int i = tid; i < 2 * L * ACCP; i += NT) smem[i] = 0.0;
         for (int i = tid; i < MT * 16; i += NT) s_l[i] = out_row[i];
-        __syncthreads();
         const int cw = wave * 16 + (lane & 15);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+            __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int l = s_l[m * 16 + kq + 4 * i];
-                if (l < 0) continue;
-                const double v = acc[m][i];
-                atomicAdd(&sU[l * ACCP + cw], v);
-                atomicAdd(&sV[l * ACCP + cw], v * v);
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (m0 + mm < MT) sT[(mm * 16 + kq + 4 * i) * ACCP + cw] = acc[m0 + mm][i];
+            __syncthreads();
+            for (int idx = tid; idx < L * BCW; idx += NT) {
+                const int l = idx / BCW, c = idx - l * BCW;
+                double u = sU[l * ACCP + c], v2 = sV[l * ACCP + c];
+                for (int rl = 0; rl < 32 && m0 * 16 + rl < MT * 16; ++rl)
+                    if (s_l[m0 * 16 + rl] == l) { const double v = sT[rl * ACCP + c]; u += v; v2 += v * v; }
+                sU[l * ACCP + c] = u; sV[l * ACCP + c] = v2;
             }
+        }
         __syncthreads();
         const int b0 = colblk * (NW * 16);
         double* ps = se.acc_sum + (size_t)grp * se.accB * L;
@@ -2415,7 +2514,9 @@ __device__ void small_solve(const SmallArgs& a, const int r, double* sm_s)
 // (cosines of the principal angles between the original and the resampled weight spaces):
 // directions with sig < 1e-6 sig_max count as dead here (1e-12 in the Jacobi solver).
 // ---------------------------------------------------------------------------
-template <int RPT, int CH>
+// PH2: the launch that finishes PARKED resamples (SmallArgs::phase == 2) -- its own instantiation, so that the code of
+// the refinement stays out of the kernel every other launch runs.
+template <int RPT, int CH, bool PH2 = false>
 __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, double* sm)
 {
     const int n = a.n, L = a.L, ld = a.ld;
@@ -2439,7 +2540,53 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     const int lcap = a.lds_cap;
     __shared__ double s_dmax;
     const double* G = a.G + (size_t)r * n * n;
-
+    __shared__ int s_k0q;
+    int k0 = 0, m = 0;                                // phase 2: first refined rank, size of the small block
+    const double* PVg = nullptr;                      // phase 2 (BOOT): (V^T R) U0, rows in rank order
+    if constexpr (PH2) {
+        // A parked resample (graded spectrum, see small_solve): a.G now holds G' = Y Y^T and a.P holds Y U0 with
+        // Y = V^T R in the basis of the first solve (k_rotate_rows + the Gram kernels on Y).  Re-solve the small
+        // block, rotate V_s, and orthogonalise the small left vectors against the large ones (factored form).
+        k0 = a.refK0[r];
+        if (!k0) return;
+        m = n - k0;
+        PVg = a.P ? a.P + (size_t)r * n * L : nullptr;
+        const double* rv = a.refV + (size_t)r * n * n;
+        for (int idx = tid; idx < n * n; idx += nt) Wa[(size_t)(idx / n) * ld + (idx % n)] = rv[idx];
+        for (int k = tid; k < n; k += nt) lam[k] = a.refLam[(size_t)r * n + k];
+        double gms = 0.0;
+        for (int i = tid; i < m; i += nt) gms = fmax(gms, fabs(G[(size_t)(k0 + i) * n + k0 + i]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gms = fmax(gms, __shfl_xor(gms, o));
+        if ((tid & 63) == 0) red[tid >> 6] = gms;
+        __syncthreads();
+        gms = 0.0;
+        for (int w = 0; w < (nt + 63) / 64; ++w) gms = fmax(gms, red[w]);
+        const double sscale = (gms > 0.0 && isfinite(gms)) ? gms : 1.0, sinv = 1.0 / sscale;
+        __syncthreads();
+        for (int idx = tid; idx < m * m; idx += nt) {
+            const int i = idx % m, c = idx / m;
+            Wc[(size_t)c * ld + i] = 0.5 * sinv * (G[(size_t)(k0 + i) * n + k0 + c] + G[(size_t)(k0 + c) * n + k0 + i]);
+        }
+        __syncthreads();
+        sym_eig<RPT, CH>(Wc, m, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap, a.status);
+        for (int c = tid; c < m; c += nt) lam[k0 + c] = fmax(dd[c], 0.0) * sscale;
+        // V_s <- V_s W (through Wd), then g[b][c] = (G'[b][k0:] W[:, c]) / G'[b][b] into Wd (column c, row b)
+        se_block_gemm<false>(Wd, ld, Wa + (size_t)k0 * ld, ld, Wc, ld, n, m, m, nullptr);
+        for (int idx = tid; idx < m * n; idx += nt) {
+            const int c = idx / n, t = idx % n;
+            Wa[(size_t)(k0 + c) * ld + t] = Wd[(size_t)c * ld + t];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * k0; idx += nt) {
+            const int c = idx / k0, b = idx % k0;
+            double sg = 0.0;
+            for (int j = 0; j < m; ++j) sg += G[(size_t)b * n + k0 + j] * Wc[(size_t)c * ld + j];
+            const double gb = G[(size_t)b * n + b];
+            Wd[(size_t)c * ld + b] = gb > 0.0 ? sg / gb : 0.0;
+        }
+        __syncthreads();
+    } else {
     // G is solved scaled to a unit largest diagonal entry: the shift / rotation recurrences of the
     // QL phase use absolute guards (1e-280), which data of a very small or very large scale
     // (covariance mode: G ~ scale^4) would otherwise run into
@@ -2460,6 +2607,7 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     __syncthreads();
     sym_eig<RPT, CH>(Wa, n, ld, dd, ee, hh, uu, pp, ps, red, lmat, lcap, a.status);
     for (int c = tid; c < n; c += nt) lam[c] = fmax(dd[c], 0.0) * gscale;
+    }
     __syncthreads();
     for (int c = tid; c < n; c += nt) {
         int rk = 0;
@@ -2474,17 +2622,38 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     __syncthreads();
     if (tid == 0) {
         s_dmax = sqrt(lam[order[0]]);
-        // graded spectra are not refined on this path (see small_solve): counted, reported by plsx_numeric_report
-        for (int k = L - 1; k >= 1; --k) {
-            const double dk = sqrt(lam[order[k]]);
-            if (dk > PLSX_RANK_RTOL * s_dmax) {               // the smallest live LV
-                if (dk < PLSX_WARN_TAU * s_dmax) atomicAdd(a.status + 2, 1);
-                break;
+        s_k0q = 0;
+        if (!PH2) {
+            // graded spectrum?  first live rank below PLSX_REFINE_TAU d_max (as in small_solve)
+            int kq = 0;
+            for (int k = 1; k < L; ++k)
+                if (sqrt(lam[order[k]]) < PLSX_REFINE_TAU * s_dmax) { kq = k; break; }
+            if (kq && !(sqrt(lam[order[kq]]) > PLSX_RANK_RTOL * s_dmax)) kq = 0;
+            if (a.phase == 1) {
+                a.refK0[r] = kq;
+                s_k0q = kq;
+                if (kq) { atomicAdd(a.status + 1, 1); atomicAdd(a.status + 3, 1); }
+            } else if (kq) {
+                // no R on this route: counted when the Gram side really is short of the tolerance
+                for (int k = L - 1; k >= 1; --k) {
+                    const double dk = sqrt(lam[order[k]]);
+                    if (dk > PLSX_RANK_RTOL * s_dmax) {           // the smallest live LV
+                        if (dk < PLSX_WARN_TAU * s_dmax) atomicAdd(a.status + 2, 1);
+                        break;
+                    }
+                }
             }
         }
     }
     __syncthreads();
     const double dmax = s_dmax;
+    if (!PH2 && a.phase == 1 && s_k0q) {
+        // park: rank-ordered eigenvectors and eigenvalues; k_rotate_rows + the Gram kernels + phase 2 finish it
+        double* rv = a.refV + (size_t)r * n * n;
+        for (int idx = tid; idx < n * n; idx += nt) rv[idx] = Wa[(size_t)order[idx / n] * ld + (idx % n)];
+        for (int k = tid; k < n; k += nt) a.refLam[(size_t)r * n + k] = lam[order[k]];
+        return;
+    }
 
     if (a.mode == SMALL_DECOMP) {
         for (int idx = tid; idx < n * L; idx += nt) {
@@ -2504,6 +2673,17 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
             }
             a.Mfrag[(size_t)r * tot + idx] = v;
         }
+        if (PH2 && a.out_H) {
+            // coefficients of k_fix_small_cols: u_c = u_c(raw) - sum_b u_b(raw) H[kb][kc], H = g d_b / d_c
+            for (int idx = tid; idx < L * L; idx += nt) a.out_H[idx] = 0.0;
+            __syncthreads();
+            for (int idx = tid; idx < m * k0; idx += nt) {
+                const int cc = idx / k0, b = idx % k0;
+                const int kb = rank[b], kc = rank[k0 + cc];
+                const double db = sqrt(lam[b]), dc = sqrt(lam[k0 + cc]);
+                if (kb < L && kc < L && dc > PLSX_RANK_RTOL * dmax) a.out_H[(size_t)kb * L + kc] = Wd[(size_t)cc * ld + b] * db / dc;
+            }
+        }
         return;
     }
     if (a.mode == SMALL_PERM && !a.rotate) {
@@ -2516,6 +2696,23 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     const bool perm = (a.mode == SMALL_PERM);
     const double* Pm = perm ? a.V0 : a.P + (size_t)r * n * L;          // (n x L) row-major = (L x n) column-major
     const double d0max = perm ? 0.0 : a.d0[0];
+    if (PH2 && !perm) {
+        // u0_a . z_c from Y U0: small c rotated by W, minus its parts along the large left vectors (g, kept in Wd;
+        // Wc still holds W).  Physical column c here is rank c for c < k0 and small column c - k0 otherwise.
+        for (int idx = tid; idx < L * n; idx += nt) {
+            const int aa = idx % L, c = idx / L;
+            double sv;
+            if (c < k0) sv = PVg[(size_t)c * L + aa];
+            else {
+                const int cc = c - k0;
+                sv = 0.0;
+                for (int j = 0; j < m; ++j) sv += Wc[(size_t)cc * ld + j] * PVg[(size_t)(k0 + j) * L + aa];
+                for (int b = 0; b < k0; ++b) sv -= Wd[(size_t)cc * ld + b] * PVg[(size_t)b * L + aa];
+            }
+            Wb[(size_t)c * ld + aa] = sv;
+        }
+        __syncthreads();
+    } else
     se_block_gemm<false>(Wb, ld, Pm, L, Wa, ld, L, n, n, nullptr);
     for (int idx = tid; idx < L * n; idx += nt) {
         const int aa = idx % L, c = idx / L;
@@ -2565,13 +2762,13 @@ __device__ __forceinline__ void small_solve_ql(const SmallArgs& a, const int r, 
     }
 }
 
-template <int RPT, int CH>
+template <int RPT, int CH, bool PH2 = false>
 __global__ __launch_bounds__(PLSX_SE_THREADS)
 void k_small_ql(SmallArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_s[];
     for (int r = blockIdx.x; r < a.nres; r += gridDim.x) {
-        small_solve_ql<RPT, CH>(a, r, sm_s);
+        small_solve_ql<RPT, CH, PH2>(a, r, sm_s);
         __syncthreads();
     }
 }
@@ -2692,13 +2889,63 @@ static __global__ void k_fix_small_cols(double* __restrict__ xw, int B, int L, c
     if (!refK0[0]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    double x[PLSX_JACOBI_TP];
-    for (int k = 0; k < L; ++k) x[k] = xw[(size_t)i * L + k];
+    // H is non-zero only for (large kb, small kc): the columns kb a sum reads are never among those it rewrites
+    double* x = xw + (size_t)i * L;
     for (int kc = 0; kc < L; ++kc) {
         double s = 0.0;
-        for (int kb = 0; kb < L; ++kb) s += x[kb] * H[(size_t)kb * L + kc];
-        if (s != 0.0) xw[(size_t)i * L + kc] = x[kc] - s;
+        for (int kb = 0; kb < L; ++kb) {
+            const double h = H[(size_t)kb * L + kc];
+            if (h != 0.0) s += x[kb] * h;
+        }
+        if (s != 0.0) x[kc] -= s;
     }
+}
+
+// Y = V^T R of parked resamples (graded spectra, T' > PLSX_JACOBI_TP): row k of Y is the cross-covariance matrix seen
+// along the eigenvector of rank k of the first solve.  Plain LDS-tiled fp64 product (64 x 64 outputs per block, 4 x 4
+// per thread) -- only graded data gets here.  grid (ceil(ldr / 64), ceil(n / 64), nres).
+static __global__ __launch_bounds__(256)
+void k_rotate_rows(const double* __restrict__ R, long long strideR, int ldr, int n,
+                   const double* __restrict__ refV, const int* __restrict__ refK0, double* __restrict__ Yout)
+{
+    const int r = blockIdx.z;
+    if (!refK0[r]) return;
+    __shared__ double Vt[16][65], Rt[16][65];
+    const int b0 = blockIdx.x * 64, kb = blockIdx.y * 64, tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    const double* rv = refV + (size_t)r * n * n;          // rv[k * n + t]
+    const double* Rr = R + (size_t)r * strideR;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int t0 = 0; t0 < n; t0 += 16) {
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int tt = idx & 15, kk = idx >> 4;
+            Vt[tt][kk] = (kb + kk < n && t0 + tt < n) ? rv[(size_t)(kb + kk) * n + t0 + tt] : 0.0;
+            const int t2 = idx >> 6, bb = idx & 63;
+            Rt[t2][bb] = (t0 + t2 < n && b0 + bb < ldr) ? Rr[(size_t)(t0 + t2) * ldr + b0 + bb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = Vt[tt][4 * ty + i]; bv[i] = Rt[tt][4 * tx + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fma(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    double* Yr = Yout + (size_t)r * strideR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (kb + 4 * ty + i < n && b0 + 4 * tx + j < ldr) Yr[(size_t)(kb + 4 * ty + i) * ldr + b0 + 4 * tx + j] = acc[i][j];
 }
 
 // ---------------------------------------------------------------------------

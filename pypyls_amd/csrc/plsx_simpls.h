@@ -1007,7 +1007,7 @@ void k_sd_final(SdArgs a)
     const int S = a.S, T = a.T, k = a.k, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
     const int r = blockIdx.x * (blockDim.x >> 6) + wave;
     if (r >= a.nres) return;
-    double* flip = sm_sd + (size_t)wave * (k + (a.Vd ? S : 0));      // [k] signs (+ [S] scatter buffer with Vd)
+    double* flip = sm_sd + (size_t)wave * (k + S);      // [k] signs + [S] scatter buffer
     const int* xs = a.xs + (size_t)r * S;
     const int* ys = a.ys + (size_t)r * S;
     const double* Ysrc = a.Yc + (size_t)r * a.y_stride;
@@ -1100,9 +1100,21 @@ void k_sd_final(SdArgs a)
     if (a.Afrag) {
         const int g = r / a.lay.n, rr = r % a.lay.n;
         double* A = a.Afrag + (size_t)g * a.group_stride;
-        for (int idx = lane; idx < S * k; idx += 64) {
-            const int c = idx / S, p = idx - c * S;
-            if (xs[p] >= 0) atomicAdd(A + afrag_off(rr * a.lay.Tp + c, xs[p], a.lay.MT), flip[c] * WD[(size_t)c * S + p]);
+        // through the wave's LDS buffer, one component at a time (a subject drawn more than once receives bit-identical
+        // addends, see sd_scatter), then plain stores: no global fp64 atomics (round 5)
+        double* buf = flip + k;
+        for (int c = 0; c < k; ++c) {
+            const double f = flip[c];
+            const double* wdc = WD + (size_t)c * S;
+            for (int i = lane; i < S; i += 64) buf[i] = 0.0;
+            wave_sync();
+            for (int p = lane; p < S; p += 64) {
+                const int x = xs[p];
+                if (x >= 0) atomicAdd(&buf[x], f * wdc[p]);
+            }
+            wave_sync();
+            for (int i = lane; i < S; i += 64) A[afrag_off(rr * a.lay.Tp + c, i, a.lay.MT)] = buf[i];
+            wave_sync();
         }
     }
     if (a.Vd) {

@@ -99,7 +99,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     if (scatter) {          // (permutations: pctvar is all that leaves the solver -- no y-loadings, no weights)
         a.Qs = align_signs ? ptr<double>(ctx->Qs) : nullptr;
         KTimer tm(ctx, KC_SIMPLS, st);
-        const size_t lds_f = (size_t)wpb * (k + (a.Vd ? S : 0)) * 8;
+        const size_t lds_f = (size_t)wpb * (k + S) * 8;       // (per wave: the signs and one subject-space scatter buffer)
         HIPCHK(set_lds(k_sd_final, lds_f));
         hipLaunchKernelGGL(k_sd_final, grid, block, lds_f, st, a);
         LAUNCHCHK();

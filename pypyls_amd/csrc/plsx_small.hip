@@ -27,18 +27,57 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double
         const size_t lds = std::min((size_t)160 * 1024 - 256, lds_vec + (size_t)n * n * 8);
         a.lds_cap = (int)((lds - lds_vec) / 8);
         int nblk = 0;
-#define SMALL_QL_LAUNCH(RPT, CH) { HIPCHK(set_lds(k_small_ql<RPT, CH>, lds)); int per = 1; \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_small_ql<RPT, CH>, PLSX_SE_THREADS, lds); \
+#define SMALL_QL_LAUNCH(RPT, CH, PH2) { HIPCHK(set_lds(k_small_ql<RPT, CH, PH2>, lds)); int per = 1; \
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_small_ql<RPT, CH, PH2>, PLSX_SE_THREADS, lds); \
         nblk = std::min(nres, 256 * std::max(1, per)); \
         if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e; \
         a.gws = ptr<double>(ctx->gws); \
-        hipLaunchKernelGGL((k_small_ql<RPT, CH>), dim3(nblk), dim3(PLSX_SE_THREADS), lds, st, a); }
-        if (n <= 192) SMALL_QL_LAUNCH(1, 16)          // rows of the eigenvector matrix per rotating thread, prefetch depth
-        else if (n <= 384) SMALL_QL_LAUNCH(2, 8)
-        else if (n <= 576) SMALL_QL_LAUNCH(3, 8)
-        else SMALL_QL_LAUNCH(7, 4)
-#undef SMALL_QL_LAUNCH
+        hipLaunchKernelGGL((k_small_ql<RPT, CH, PH2>), dim3(nblk), dim3(PLSX_SE_THREADS), lds, st, a); }
+#define SMALL_QL_DISPATCH(PH2) \
+        if (n <= 192) SMALL_QL_LAUNCH(1, 16, PH2)     /* rows of the eigenvector matrix per rotating thread, prefetch depth */ \
+        else if (n <= 384) SMALL_QL_LAUNCH(2, 8, PH2) \
+        else if (n <= 576) SMALL_QL_LAUNCH(3, 8, PH2) \
+        else SMALL_QL_LAUNCH(7, 4, PH2)
+        const bool refine = Rref && !ctx->opt[OPT_NO_REFINE];
+        if (refine) {
+            // graded spectra (round 5: also on this path): a resample with a live LV below PLSX_REFINE_TAU d_max parks
+            // its rank-ordered eigenvectors; the parked ones are then re-solved on R itself, as on the Jacobi path
+            if (int e = ensure(ctx, ctx->refV, (size_t)nres * n * n * 8)) return e;
+            if (int e = ensure(ctx, ctx->refLam, (size_t)nres * n * 8)) return e;
+            if (int e = ensure(ctx, ctx->refK0, (size_t)nres * sizeof(int))) return e;
+            a.phase = 1;
+            a.refV = ptr<double>(ctx->refV); a.refLam = ptr<double>(ctx->refLam); a.refK0 = ptr<int>(ctx->refK0);
+            HIPCHK(hipMemsetAsync(ptr<int>(ctx->status) + 3, 0, sizeof(int), st));
+        }
+        SMALL_QL_DISPATCH(false)
         LAUNCHCHK();
+        if (!refine) return 0;
+        // the latency-bound solver dominates this path anyway: one small read-back tells whether anything was parked
+        int parked = 0;
+        HIPCHK(hipMemcpyAsync(&parked, ptr<int>(ctx->status) + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!parked) return 0;
+        {
+            // Y = V^T R of the parked resamples (own buffer: R is still needed by the rotation pass), then
+            // G' = Y Y^T and (bootstraps) Y U0 from the SAME Gram kernels, into the buffers the first pass used
+            const bool boot = a.mode == SMALL_BOOT;
+            if (int e = ensure(ctx, ctx->Yrot, (size_t)nres * ctx->strideR * 8)) return e;
+            hipLaunchKernelGGL(k_rotate_rows, dim3(ceil_div(ctx->Bpad, 64), ceil_div(n, 64), nres), dim3(256), 0, st, Rref,
+                               ctx->strideR, ctx->Bpad, n, ptr<double>(ctx->refV), ptr<int>(ctx->refK0),
+                               ptr<double>(ctx->Yrot));
+            LAUNCHCHK();
+            if (int e = run_gram_ex(ctx, nres, boot ? 1 : 0, boot ? ptr<double>(ctx->U0T) : nullptr, ctx->L,
+                                    ptr<double>(ctx->Pm), st, ptr<double>(ctx->Yrot)))
+                return e;
+            a.phase = 2;
+            a.G = ptr<double>(ctx->Gm);
+            if (boot) a.P = ptr<double>(ctx->Pm);
+            KTimer tm2(ctx, KC_SMALL, st);
+            SMALL_QL_DISPATCH(true)
+            LAUNCHCHK();
+        }
+#undef SMALL_QL_DISPATCH
+#undef SMALL_QL_LAUNCH
         return 0;
     }
     // one-sided Jacobi out of LDS, one block per resample, 8 lanes per column pair

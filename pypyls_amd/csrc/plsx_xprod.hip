@@ -59,9 +59,10 @@ int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int gro
     se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
     const bool narrow = ctx->opt[OPT_EPI2_NW4] != 0;
     KTimer tm(ctx, KC_XPROD, st);
-    if (!narrow && 2 * (size_t)L * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
+    // (LDS of the epilogue: [2][L] sum rows + 32 staging rows of NW * 16 + 16 doubles, the row -> l map)
+    if (!narrow && (2 * (size_t)L + 32) * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
         constexpr int NW = 8;
-        const size_t lds = std::max(stage, (size_t)2 * L * (NW * 16 + 16) * 8 + (size_t)MT * 16 * 4);
+        const size_t lds = std::max(stage, ((size_t)2 * L + 32) * (NW * 16 + 16) * 8 + (size_t)MT * 16 * 4);
         HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 2>, lds));
         const int ncolblk = ceil_div(ctx->Bpad, NW * 16);
         hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
@@ -70,7 +71,7 @@ int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int gro
                            (double*)nullptr, se, 1);
     } else {
         constexpr int NW = 4;
-        const size_t lds = std::max(stage, (size_t)2 * L * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4);
+        const size_t lds = std::max(stage, ((size_t)2 * L + 32) * PLSX_ACC_PITCH * 8 + (size_t)MT * 16 * 4);
         HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 2>, lds));
         const int ncolblk = ctx->Bpad / (NW * 16);
         hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 2>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), lds, st,
@@ -155,11 +156,13 @@ int run_xprod_sepmom(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, 
     lay.w0 = ctx->MTd; lay.sq0 = ctx->MTd; lay.Tpp = ctx->Tpp;
     {
         KTimer tm(ctx, KC_BUILD, st);
-        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, ctx->J), dim3(256), (size_t)2 * ctx->T * 8, st,
+        int cap = 0;
+        const size_t blds = build_lds_behav(ctx, &cap);
+        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, ctx->J), dim3(256), blds, st,
                            ystack ? ystack : ptr<double>(ctx->Y), ystack ? ystride : 0LL, ctx->T, ctx->S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay, ctx->cov, 1,
                            ptr<double>(ctx->Afrag), ctx->group_stride_d, ptr<double>(ctx->momn_m), 0, 0,
-                           ptr<double>(ctx->Afrag_m), mstride);
+                           ptr<double>(ctx->Afrag_m), mstride, (const int*)nullptr, PLSX_MOM_PAIRS, cap);
         LAUNCHCHK();
     }
     SplitEpi se;
@@ -302,11 +305,13 @@ int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, h
         LAUNCHCHK();
         GroupLayout lay;
         lay.n = 1; lay.Tp = ctx->Tp; lay.J = J; lay.T = ctx->T; lay.MT = MTc; lay.w0 = MTc; lay.sq0 = MTc; lay.Tpp = ctx->Tpp;
-        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, J), dim3(256), (size_t)2 * ctx->T * 8, st,
+        int cap = 0;
+        const size_t blds = build_lds_behav(ctx, &cap);
+        hipLaunchKernelGGL(k_build_A_behav, dim3(nres, J), dim3(256), blds, st,
                            ystack ? ystack : ptr<double>(ctx->Y), ystack ? ystride : 0LL, ctx->T, S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay, ctx->cov, 1,
                            ptr<double>(ctx->Afrag_c), astride, ptr<double>(ctx->momn_m), 0, 0,
-                           ptr<double>(ctx->Afrag_m), mstride, ptr<int>(ctx->rank_c), ml.pairs);
+                           ptr<double>(ctx->Afrag_m), mstride, ptr<int>(ctx->rank_c), ml.pairs, cap);
         LAUNCHCHK();
     }
     SplitEpi se;
@@ -363,17 +368,21 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
         // A (dual weights) was scattered by k_simpls_dual; nothing to build here
     } else if (ctx->method == PLSX_BEHAVIORAL) {
         dim3 grid(nres, ctx->J), block(256);
-        const size_t lds = (size_t)2 * ctx->T * 8;
+        int cap = 0;
+        const size_t lds = build_lds_behav(ctx, &cap);
         hipLaunchKernelGGL(k_build_A_behav, grid, block, lds, st, ystack ? ystack : ptr<double>(ctx->Y),
                            ystack ? ystride : 0LL, ctx->T, ctx->S,
                            ptr<int>(ctx->cell_start), ptr<int>(ctx->cell_len), xsrc, ysrc, lay,
                            ctx->cov, ctx->momrows, ptr<double>(ctx->Afrag), ctx->group_stride,
-                           ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16));
+                           ptr<double>(ctx->mom_n), std::max(ctx->nmom_pad, 16), 0, (double*)nullptr, (size_t)0,
+                           (const int*)nullptr, PLSX_MOM_PAIRS, cap);
     } else {
         dim3 grid(nres), block(256);
-        hipLaunchKernelGGL(k_build_A_mc, grid, block, 0, st, ctx->S, ctx->J, ctx->n_cond, ctx->mc,
+        int cap = 0;
+        const size_t lds = build_lds_mc(ctx, &cap);
+        hipLaunchKernelGGL(k_build_A_mc, grid, block, lds, st, ctx->S, ctx->J, ctx->n_cond, ctx->mc,
                            ptr<int>(ctx->cell_of_row), xsrc, lay, ptr<double>(ctx->Afrag),
-                           ctx->group_stride);
+                           ctx->group_stride, 0, cap);
     }
     LAUNCHCHK();
     return launch_xprod(ctx, pgroups, st);

@@ -89,7 +89,8 @@ def run_case(X, Y, groups, n_cond, method, mean_centering=0, n=8, min_ratio=None
     U, d, V = ref.decompose(spec, X, Yo)
     dv = np.diag(d)
     live = ref.live_lvs(d)
-    assert (~live).sum() == null_lvs, ('null LVs', dv)
+    if null_lvs is not None:
+        assert (~live).sum() == null_lvs, ('null LVs', dv)
     ratio = dv[live][0] / dv[live][-1]
     if min_ratio is not None:
         assert min_ratio <= ratio <= max_ratio, 'design has d_1/d_L = {:.3g}'.format(ratio)
@@ -297,3 +298,33 @@ def test_frontend_graded_spectrum(ratio):
         print('ratio {:g} LV {}: d/d1 = {:.2e}, bootstrap ratio rel err {:.2e}'.format(ratio, k, dv[k] / dv[0], err))
         assert err < (1e-5 if k >= 2 else 1e-3), (k, err)
     print('front-end graded {:g}: d1/dL = {:.3g}, worst per-LV rel err {:.2e}'.format(ratio, dv[0] / dv[-1], worst))
+
+
+@pytest.mark.parametrize('ratio', [1e3, 1e4, 1e5])
+@pytest.mark.parametrize('S,B,T,groups,n_cond,kind', [
+    (220, 3000, 100, [220], 1, 'y'),     # T' = 100
+    (320, 2400, 200, [320], 1, 'y'),     # T' = 200
+    (100, 1000, 100, [25], 4, 'x'),      # T' = 400, rank <= 96: the reference's own CI shape (pyls/tests/types/test_svd.py:87)
+    (660, 1500, 600, [660], 1, 'y'),     # T' = 600: the solver variant for T' > 576
+])
+def test_wide_graded_spectrum_is_refined(S, B, T, groups, n_cond, kind, ratio):
+    """graded spectra ABOVE T' = 64 (Householder + QL small solver).  The Gram side alone loses
+    eps (d_1 / d_k)^2 there as everywhere; since round 5 a graded decomposition on this path is parked, its R rotated
+    into the basis of the first solve (k_rotate_rows), G' = Y Y^T and Y U0 re-formed by the same Gram kernels and the
+    small block re-solved -- per-LV 1e-5 against the oracle for the decomposition, the permutations (both rotate
+    settings) and the bootstrap sums, and nothing is left "counted and warned".  kind 'y': the grading sits in the
+    column space of the behaviours; 'x' (25 subjects per cell: every cell's z-scored behaviours have rank 24): in the
+    row space of the features."""
+    if T == 600 and ratio != 1e4:
+        pytest.skip('one ratio at the largest shape (the solver needs seconds per decomposition)')
+    rs = np.random.RandomState(int(S + T + np.log10(ratio)))
+    if kind == 'y':
+        X = rs.randn(S, B)
+        Y = graded_behaviours(rs, S, T, ratio, 'mix')
+    else:
+        Q, _ = np.linalg.qr(rs.randn(B, S))
+        X = (rs.randn(S, S) * np.logspace(0, -2.5 * np.log10(ratio), S)) @ Q.T     # (the live LVs span ~40 % of the decades)
+        Y = rs.randn(S, T)
+    got_ratio, worst = run_case(X, Y, groups, n_cond, 'behavioral', n=3 if T == 600 else 4, null_lvs=None)
+    print('wide T\' = {}: target {:g}, d1/dL = {:.3g}, worst per-LV error {:.2e}'.format(
+        len(groups) * n_cond * T, ratio, got_ratio, worst))

@@ -348,15 +348,15 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  * rounding; the switches exist for A/B measurements and so that tests can pin each kernel variant against the
  * others and the oracle.  The library reads NO environment variable: a host that wants PLSX_<KEY>=1 to mean
  * something passes it on itself (bench.py and the tests do, pypyls_amd.engine.options_from_env).
- *   layout-time (before plsx_set_data): "xprod_mt24", "min_batch" (resamples per super-batch aimed for, default
- *     4096), "inblock_moments", "no_fixed_x", "no_dual_perm"
+ *   layout-time (before plsx_set_data): "min_batch" (resamples per super-batch aimed for, default 4096),
+ *     "inblock_moments", "no_fixed_x", "no_dual_perm"
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
- *     "compact_boot_always", "sepmom_always", "no_split_fuse", "split_inblock", "split_no_tail4", "no_gram4",
- *     "gram_nt", "gram_reg", "urot_generic", "urot_no_tail4", "urot_nw4", "urot_m3", "epi2_nw4", "simpls_jacobi"
- *     (SIMPLS: full Jacobi instead of the leading-eigenpair solver), "quad_sums" (plsx_boot_begin: 1 = the quadratic-form route
- *     whenever it applies, -1 = never), "quad_mt" (tile rows of a row block of its closing pass, 0 = chosen),
- *     "quad_full_rows" (closing pass without the symmetry), "quad_launch_per_block", "percentile_sort" (plsx_percentile_ci: always the
- *     full sort instead of the tail selection), "trace_alloc";
+ *     "compact_boot_always", "sepmom_always", "no_split_fuse" (split halves: two passes), "split_two_readers"
+ *     (fused split blocks read by the Gram and the projection kernel instead of the one-pass reader),
+ *     "split_inblock", "no_gram4", "urot_generic", "urot_no_tail4", "simpls_jacobi" (SIMPLS: full Jacobi instead
+ *     of the leading-eigenpair solver), "quad_sums" (plsx_boot_begin: 1 = the quadratic-form route whenever it
+ *     applies, -1 = never), "percentile_sort" (plsx_percentile_ci: always the full sort instead of the tail
+ *     selection);
  *     "expect_resamples" = n: the caller is about to ship n resamples in several calls (chunks of one analysis):
  *     size the super-batch scratch for n once instead of per call (0 = per call)
  * plsx_option_name(i) enumerates the keys (NULL past the last).  No reference counterpart.

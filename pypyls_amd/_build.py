@@ -1,6 +1,6 @@
 """Build libplsx.so (hipcc, gfx950 only) in-tree next to this file.
 
-The library is eight translation units (csrc/plsx_internal.h has the map), compiled in parallel into
+The library is ten translation units (csrc/plsx_internal.h has the map), compiled in parallel into
 csrc/build/*.o and linked; a unit is recompiled when it or a header it includes is newer than its object."""
 import os
 import shutil
@@ -11,10 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJDIR = os.path.join(CSRC, 'build')
-UNITS = ['plsx_xprod', 'plsx_compact', 'plsx_gram', 'plsx_urot', 'plsx_small', 'plsx_simpls_api', 'plsx_split',
-         'plsx_core']                                   # (longest compile first)
+UNITS = ['plsx_smallql1', 'plsx_smallql2', 'plsx_gram', 'plsx_urot', 'plsx_xprod', 'plsx_small', 'plsx_compact',
+         'plsx_simpls_api', 'plsx_split', 'plsx_core']                                   # (longest compile first)
 COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_symeig.h']
-EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_simpls_api': ['plsx_simpls.h'], 'plsx_split': ['plsx_splitfused.h']}
+EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_smallql1': ['plsx_smallql.h'], 'plsx_smallql2': ['plsx_smallql.h'],
+          'plsx_simpls_api': ['plsx_simpls.h'], 'plsx_split': ['plsx_splitfused.h']}
 PUBLIC = os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')
 LIB = os.path.join(HERE, 'libplsx.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-function']

@@ -89,7 +89,7 @@ int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, 
         }
     }
     // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
-    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4 && !ctx->opt[OPT_SPLIT_NO_TAIL4];
+    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4;
     switch (MTc) {
         case 1: return launch_xprod_compact<1, 12>(ctx, m, nks_c, se, st);
         case 2: return tail ? launch_xprod_compact<2, 6, true>(ctx, m, nks_c, se, st)

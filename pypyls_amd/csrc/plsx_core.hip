@@ -32,7 +32,7 @@ int plan_groups(plsx_ctx* c)
     int best = fit(24);
     // a block of 16 tiles when it wastes clearly fewer rows (one resample of 177 <= T' <= 224 rows
     // fills 15 of 24 tiles but 15 of 16); behavioural correlation PLS only (instantiations of k_xprod)
-    if (c->method == PLSX_BEHAVIORAL && !c->opt[OPT_XPROD_MT24]) {
+    if (c->method == PLSX_BEHAVIORAL) {
         const int b16 = fit(16);
         if (b16 >= 1 && (double)b16 / 16.0 > 1.15 * (double)best / 24.0) { c->MT = 16; best = b16; }
     }
@@ -1253,7 +1253,7 @@ try {
     for (int i = 0; i < OPT_COUNT; ++i)
         if (!strcmp(key, kOptionNames[i])) {
             // layout-time switches are read by plsx_set_data
-            const bool plan_time = (i == OPT_XPROD_MT24 || i == OPT_MIN_BATCH || i == OPT_INBLOCK_MOMENTS ||
+            const bool plan_time = (i == OPT_MIN_BATCH || i == OPT_INBLOCK_MOMENTS ||
                                     i == OPT_NO_FIXED_X || i == OPT_NO_DUAL_PERM);
             if (plan_time && ctx->has_data && ctx->opt[i] != value)
                 return fail(ctx, PLSX_ERR_STATE, std::string("plsx_set_option: '") + key + "' must precede plsx_set_data");

@@ -147,9 +147,9 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
     const double* R = Rsrc ? Rsrc : ptr<double>(ctx->R);
     double* Gm = ptr<double>(ctx->Gm);
     const long long sG = (long long)ctx->Tp * ctx->Tp, sP = (long long)ctx->Tp * Erows;
-    if ((ctx->Tp > 64 || Erows > 64) && !ctx->opt[OPT_GRAM_NT]) {
-        // 64 x 64 output blocks on the register-streamed k_gram (4 x the rate of the generic
-        // LDS-tiled k_nt_gemm): G upper block triangle, then P, into one partial buffer
+    if (ctx->Tp > 64 || Erows > 64) {
+        // 64 x 64 output blocks on k_gram_lds (4 x the rate of the generic k_nt_gemm): G upper block
+        // triangle, then P, into one partial buffer
         const int nt_t = ceil_div(ctx->Tp, 64), nt_l = mode != 0 ? ceil_div(Erows, 64) : 0;
         const int pitch = std::max(nt_t, nt_l), tiles = nt_t * pitch;
         const int nz_g = mode != 2 ? nt_t * (nt_t + 1) / 2 : 0, nz_p = mode != 0 ? nt_t * nt_l : 0;
@@ -162,58 +162,29 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
         double* part = ptr<double>(ctx->part);
         KTimer tm(ctx, KC_GRAM, st);
         const dim3 gG(ceil_div(ctx->Tp * ctx->Tp, 256), nres), gP(ceil_div(ctx->Tp * std::max(Erows, 1), 256), nres);
-        const bool reg_streamed = ctx->opt[OPT_GRAM_REG] != 0;     // the A side from global memory in every wave
-        if (!reg_streamed) {
-            if (mode == 1 && nt_l == nt_t) {
-                // square: G and P of the blocks tm <= tn share their A fragments in one pass,
-                // P of the blocks below the diagonal follows
-                hipLaunchKernelGGL(k_gram_lds<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
+        if (mode == 1 && nt_l == nt_t) {
+            // square: G and P of the blocks tm <= tn share their A fragments in one pass,
+            // P of the blocks below the diagonal follows
+            hipLaunchKernelGGL(k_gram_lds<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                               ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
+            LAUNCHCHK();
+            if (nt_t > 1) {
+                hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
+                                   ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
+                                   pitch, tiles, nt_t, 2);
                 LAUNCHCHK();
-                if (nt_t > 1) {
-                    hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
-                                       ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
-                                       pitch, tiles, nt_t, 2);
-                    LAUNCHCHK();
-                }
-            } else {
-                if (nz_g) {
-                    hipLaunchKernelGGL(k_gram_lds<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                       ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
-                                       tiles, nt_t, 1);
-                    LAUNCHCHK();
-                }
-                if (nz_p) {
-                    hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                       ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
-                    LAUNCHCHK();
-                }
             }
         } else {
-            if (mode == 1 && nt_l == nt_t) {
-                // square: G and P of the blocks tm <= tn share their A fragments in one pass,
-                // P of the blocks below the diagonal follows
-                hipLaunchKernelGGL(k_gram<1>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_t, 1);
+            if (nz_g) {
+                hipLaunchKernelGGL(k_gram_lds<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                   ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
+                                   tiles, nt_t, 1);
                 LAUNCHCHK();
-                if (nt_t > 1) {
-                    hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nt_t * (nt_t - 1) / 2), dim3(256), 0, st, R,
-                                       ctx->strideR, ctx->Bpad, ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres,
-                                       pitch, tiles, nt_t, 2);
-                    LAUNCHCHK();
-                }
-            } else {
-                if (nz_g) {
-                    hipLaunchKernelGGL(k_gram<0>, dim3(nchunk, nres, nz_g), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                       ctx->Tp, (const double*)nullptr, ctx->Bpad, 0, ctx->B, cols, part, nres, pitch,
-                                       tiles, nt_t, 1);
-                    LAUNCHCHK();
-                }
-                if (nz_p) {
-                    hipLaunchKernelGGL(k_gram<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
-                                       ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
-                    LAUNCHCHK();
-                }
+            }
+            if (nz_p) {
+                hipLaunchKernelGGL(k_gram_lds<2>, dim3(nchunk, nres, nz_p), dim3(256), 0, st, R, ctx->strideR, ctx->Bpad,
+                                   ctx->Tp, E, ctx->Bpad, Erows, ctx->B, cols, part, nres, pitch, tiles, nt_l, 0);
+                LAUNCHCHK();
             }
         }
         if (nz_g) {
@@ -227,14 +198,6 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
             LAUNCHCHK();
         }
         return 0;
-    }
-    if (ctx->Tp > 64 || Erows > 64) {
-        if (mode == 2)
-            return run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, E, 0, ctx->Bpad, Erows,
-                          nullptr, 0, 0, 0, ctx->B, nres, Pout, sP, Erows, nullptr, 0, 0, st);
-        return run_nt(ctx, R, ctx->strideR, ctx->Bpad, ctx->Tp, R, ctx->strideR, ctx->Bpad, ctx->Tp,
-                      mode == 1 ? E : nullptr, 0, ctx->Bpad, Erows, ctx->B, nres,
-                      Gm, sG, ctx->Tp, mode == 1 ? Pout : nullptr, sP, Erows, st);
     }
     // square P (bootstrap G + P, or the cross product alone): the 4x4x4-MFMA kernel
     // (no 16-row padding, symmetric G)

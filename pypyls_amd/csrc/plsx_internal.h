@@ -6,7 +6,7 @@
 //   plsx_xprod.hip       k_xprod launches (dense blocks, moment blocks, accumulating / quadratic-form epilogues)
 //   plsx_compact.hip     k_xprod_compact launches (one bootstrap / split per block)
 //   plsx_gram.hip        k_nt_gemm, k_dual_gp, k_gram4, k_gram, k_gram_lds
-//   plsx_small.hip       k_small, k_small_ql, k_refine_gram
+//   plsx_small.hip       k_small, k_refine_gram, k_rotate_rows; plsx_smallql{1,2}.hip: k_small_ql (plsx_smallql.h)
 //   plsx_urot.hip        k_urot, k_ucorr_partial
 //   plsx_split.hip       split-half and cross-validation
 //   plsx_simpls_api.hip  SIMPLS regression
@@ -36,16 +36,16 @@ struct Buf {
 // read from the environment: a host that wants PLSX_<NAME>=1 to mean something translates it itself
 // (pypyls_amd.engine.options_from_env, used by bench.py and the tests only).
 enum {
-    OPT_NO_REFINE = 0, OPT_TRACE_ALLOC, OPT_XPROD_MT24, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_EPI2_NW4,
-    OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS, OPT_SEPMOM_ALWAYS, OPT_GRAM_NT, OPT_GRAM_REG, OPT_NO_GRAM4,
-    OPT_UROT_NW4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM, OPT_TWO_PASS_BOOT,
-    OPT_SPLIT_NO_TAIL4, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_EXPECT_RESAMPLES, OPT_UROT_M3, OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_QUAD_MT, OPT_QUAD_FULL_ROWS, OPT_QUAD_LAUNCH_PER_BLOCK, OPT_SPLIT_TWO_READERS, OPT_COUNT
+    OPT_NO_REFINE = 0, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS,
+    OPT_SEPMOM_ALWAYS, OPT_NO_GRAM4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM,
+    OPT_TWO_PASS_BOOT, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_SPLIT_TWO_READERS, OPT_EXPECT_RESAMPLES,
+    OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
-    "no_refine", "trace_alloc", "xprod_mt24", "min_batch", "inblock_moments", "epi2_nw4",
-    "no_compact_boot", "compact_boot_always", "sepmom_always", "gram_nt", "gram_reg", "no_gram4",
-    "urot_nw4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm", "two_pass_boot",
-    "split_no_tail4", "split_inblock", "no_split_fuse", "expect_resamples", "urot_m3", "simpls_jacobi", "percentile_sort", "quad_sums", "quad_mt", "quad_full_rows", "quad_launch_per_block", "split_two_readers"};
+    "no_refine", "min_batch", "inblock_moments", "no_compact_boot", "compact_boot_always",
+    "sepmom_always", "no_gram4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm",
+    "two_pass_boot", "split_inblock", "no_split_fuse", "split_two_readers", "expect_resamples",
+    "simpls_jacobi", "percentile_sort", "quad_sums"};
 
 struct plsx_ctx {
     int device = 0;
@@ -170,23 +170,12 @@ inline int fail_nothrow(plsx_ctx* c, int code, const char* what) noexcept
 inline int ensure(plsx_ctx* ctx, Buf& b, size_t bytes, bool zero = false)
 {
     if (b.bytes < bytes) {
-        const bool trace = ctx->opt[OPT_TRACE_ALLOC] != 0;
-        auto t0 = std::chrono::steady_clock::now();
         if (b.p) HIPCHK(hipFree(b.p));
-        auto t1 = std::chrono::steady_clock::now();
         b.p = nullptr;
         b.bytes = 0;
         HIPCHK(hipMalloc(&b.p, bytes));
-        auto t2 = std::chrono::steady_clock::now();
         b.bytes = bytes;
         if (zero) HIPCHK(hipMemset(b.p, 0, bytes));
-        if (trace) {
-            HIPCHK(hipDeviceSynchronize());
-            auto t3 = std::chrono::steady_clock::now();
-            auto ms = [](auto a, auto c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
-            fprintf(stderr, "[plsx alloc] %.3f GB: free %.1f ms, malloc %.1f ms, zero %.1f ms\n",
-                    bytes / 1073741824.0, ms(t0, t1), ms(t1, t2), ms(t2, t3));
-        }
     }
     return 0;
 }
@@ -316,6 +305,9 @@ int run_gram_ex(plsx_ctx* ctx, int nres, int mode, const double* E, int Erows, d
 int run_gram(plsx_ctx* ctx, int nres, bool with_p, hipStream_t st);
 // ---- plsx_small.hip ----
 int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double* Rref = nullptr);
+// ---- plsx_smallql1.hip / plsx_smallql2.hip ----
+int launch_small_ql(plsx_ctx* ctx, const SmallArgs& a, int nres, size_t ws, size_t lds, hipStream_t st);
+int launch_small_ql_refined(plsx_ctx* ctx, const SmallArgs& a, int nres, size_t ws, size_t lds, hipStream_t st);
 // ---- plsx_urot.hip ----
 int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hipStream_t st);
 int launch_ucorr(plsx_ctx* ctx, dim3 grid, dim3 block, hipStream_t st, const double* M, int tpc,

@@ -791,8 +791,8 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     static_assert(EPI != 7 || KT == 1, "EPI 7: one k-step per stage");
     // groups are numbered row block first (grp = block * se.J + lv, se.J = LVs of the pass): the eight groups of a
     // sweep -- one per XCD, dispatched in lockstep -- then have the same contraction length
-    const int qblk = (EPI == 7) ? se.Tpp + grp / max(se.J, 1) : 0;      // (se.Tpp: first row block of the launch)
-    const int ks0 = (EPI == 7 && !se.nmu) ? qblk * (MT * 4) : 0;      // (se.nmu: A/B, full rows)
+    const int qblk = (EPI == 7) ? grp / max(se.J, 1) : 0;
+    const int ks0 = (EPI == 7) ? qblk * (MT * 4) : 0;
     if (EPI == 7) { X += (size_t)ks0 * 4 * ldx; nks -= ks0; }
     const double* Ag = Afrag + (size_t)grp * group_stride + (size_t)ks0 * (KT * MT * 64);
     const int swave = __builtin_amdgcn_readfirstlane(wave);
@@ -2968,7 +2968,7 @@ void k_rotate_rows(const double* __restrict__ R, long long strideR, int ldr, int
 // (A[blk][i][k] = lane 16k + 4blk + i = R[4ks + k][b0 + 4blk + i]), the four blocks are four groups
 // of four features, B is the M fragment of that tile read with the column index folded to 0..3:
 // 16 matrix cycles instead of 32 per k-step, and a quarter of the sum / square updates.
-template <int LT, int NKS, bool TAIL = false, int NST = 2>
+template <int LT, int NKS, bool TAIL = false>
 __global__ __launch_bounds__(512)
 void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
             const double* __restrict__ Mfrag, size_t mstride, int nres, int B, int L, int k0,
@@ -3013,58 +3013,7 @@ void k_urot(const double* __restrict__ R, long long strideR, int ldr, int nks_t,
     };
     if (r_beg >= r_end) return;
     issue(r_beg, sm_u);
-    if constexpr (NKS > 0 && NST == 3) {
-        // Three LDS stages of M: the copy for resample r + 2 is issued while r is multiplied, so the copy a
-        // wave needs next (r + 1) was issued one whole resample earlier -- BEFORE the fragment loads it has just
-        // consumed, and vmcnt retires in order: its own pieces have landed without any wait; the barrier only
-        // lines the waves up (everybody past their use of stage r, everybody's pieces of r + 1 in place).
-        auto load_all = [&](int r, double* a) {
-            __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                a[ks] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsR, rvoff, ks * rstep, 0));
-        };
-        double a_cur[NKS];
-        if (r_beg + 1 < r_end) issue(r_beg + 1, sm_u + stage);
-        load_all(r_beg, a_cur);
-        __syncthreads();
-        constexpr int LF = TAIL ? LT - 1 : LT;
-        const int toff = (LT - 1) * 64 + (lane & 48) + (lane & 3) - lane;
-        int st = 0;
-        for (int r = r_beg; r < r_end; ++r) {
-            const double* sM = sm_u + st * stage + lane;
-            const int st2 = st == 0 ? 2 : st - 1;               // (st + 2) % 3
-            if (r + 2 < r_end) issue(r + 2, sm_u + st2 * stage);
-            double a_next[NKS];
-            load_all(min(r + 1, r_end - 1), a_next);
-            d4 acc[LT];
-            double acct = 0.0;
-#pragma unroll
-            for (int l = 0; l < LT; ++l) acc[l] = (d4){0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-                for (int l = 0; l < LF; ++l) acc[l] = mfma_f64(a_cur[ks], sM[(ks * LT + l) * 64], acc[l]);
-                if constexpr (TAIL) acct = mfma_f64_4x4(a_cur[ks], sM[ks * LT * 64 + toff], acct);
-            }
-#pragma unroll
-            for (int l = 0; l < LF; ++l) {
-                sum[l] += acc[l];
-                sq[l] += acc[l] * acc[l];
-            }
-            if constexpr (TAIL) {
-                sum[LT - 1][0] += acct;
-                sq[LT - 1][0] += acct * acct;
-            }
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) a_cur[ks] = a_next[ks];
-            // a_cur (= the loads issued after the copy of r + 1 ... no: after the copy of r + 2) is not needed to
-            // be complete here; the copy of r + 1 is older than the fragments of r consumed above
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NKS + 4) : "memory");
-            st = st == 2 ? 0 : st + 1;
-        }
-    } else if constexpr (NKS > 0) {
+    if constexpr (NKS > 0) {
         auto load_all = [&](int r, double* a) {
             __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(R + (size_t)r * strideR), (short)0, 0x7fffffff, PLSX_RSRC_FLAGS);
@@ -3366,12 +3315,11 @@ void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, doub
 // x^T C x = sum over the row blocks of x_blk^T (C[blk, blk] x_blk + 2 C[blk, right of blk] x_right), so a block
 // only holds the columns from its own first row on, the ones right of the diagonal block doubled.
 static __global__ __launch_bounds__(256)
-void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride,
-                  int full)
+void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride)
 {
     const int nl = gridDim.y / gpl;                         // group g = block * nl + l (see k_xprod EPI 7)
     const int g = blockIdx.y, l = g % nl, s0 = (g / nl) * MT * 16;
-    const int k0 = full ? 0 : s0;                           // first column the block holds
+    const int k0 = s0;                                      // first column the block holds
     const int rows = min(MT * 16, S - s0), w = S - k0;
     const double* Cl = C + (size_t)l * S * S + (size_t)s0 * S + k0;
     double* out = Afrag + (size_t)g * group_stride;
@@ -3379,7 +3327,7 @@ void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* 
          idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / w), k = (int)(idx - (long long)r * w);
         const double v = Cl[(size_t)r * S + k];
-        out[afrag_off(r, k0 + k, MT)] = (full || k < MT * 16) ? v : 2.0 * v;
+        out[afrag_off(r, k0 + k, MT)] = (k < MT * 16) ? v : 2.0 * v;
     }
 }
 

@@ -1,4 +1,5 @@
-// plsx_small.hip -- launches of the small dense solvers (k_small, k_small_ql) and the refinement of graded spectra
+// plsx_small.hip -- the small dense solvers (k_small here, k_small_ql in plsx_smallql{1,2}.hip) and the refinement of
+// graded spectra
 // Part of libplsx.so (plsx_internal.h has the map of translation units).  gfx950 only.
 #include "plsx_internal.h"
 
@@ -26,18 +27,6 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double
         const size_t lds_vec = (size_t)(7 * n + PLSX_SE_THREADS + 18) * 8 + (size_t)(2 * n + 2) * 4 + 64;
         const size_t lds = std::min((size_t)160 * 1024 - 256, lds_vec + (size_t)n * n * 8);
         a.lds_cap = (int)((lds - lds_vec) / 8);
-        int nblk = 0;
-#define SMALL_QL_LAUNCH(RPT, CH, PH2) { HIPCHK(set_lds(k_small_ql<RPT, CH, PH2>, lds)); int per = 1; \
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_small_ql<RPT, CH, PH2>, PLSX_SE_THREADS, lds); \
-        nblk = std::min(nres, 256 * std::max(1, per)); \
-        if (int e = ensure(ctx, ctx->gws, (size_t)nblk * ws)) return e; \
-        a.gws = ptr<double>(ctx->gws); \
-        hipLaunchKernelGGL((k_small_ql<RPT, CH, PH2>), dim3(nblk), dim3(PLSX_SE_THREADS), lds, st, a); }
-#define SMALL_QL_DISPATCH(PH2) \
-        if (n <= 192) SMALL_QL_LAUNCH(1, 16, PH2)     /* rows of the eigenvector matrix per rotating thread, prefetch depth */ \
-        else if (n <= 384) SMALL_QL_LAUNCH(2, 8, PH2) \
-        else if (n <= 576) SMALL_QL_LAUNCH(3, 8, PH2) \
-        else SMALL_QL_LAUNCH(7, 4, PH2)
         const bool refine = Rref && !ctx->opt[OPT_NO_REFINE];
         if (refine) {
             // graded spectra (round 5: also on this path): a resample with a live LV below PLSX_REFINE_TAU d_max parks
@@ -49,8 +38,7 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double
             a.refV = ptr<double>(ctx->refV); a.refLam = ptr<double>(ctx->refLam); a.refK0 = ptr<int>(ctx->refK0);
             HIPCHK(hipMemsetAsync(ptr<int>(ctx->status) + 3, 0, sizeof(int), st));
         }
-        SMALL_QL_DISPATCH(false)
-        LAUNCHCHK();
+        if (int e = launch_small_ql(ctx, a, nres, ws, lds, st)) return e;
         if (!refine) return 0;
         // the latency-bound solver dominates this path anyway: one small read-back tells whether anything was parked
         int parked = 0;
@@ -73,11 +61,8 @@ int run_small(plsx_ctx* ctx, SmallArgs a, int nres, hipStream_t st, const double
             a.G = ptr<double>(ctx->Gm);
             if (boot) a.P = ptr<double>(ctx->Pm);
             KTimer tm2(ctx, KC_SMALL, st);
-            SMALL_QL_DISPATCH(true)
-            LAUNCHCHK();
+            if (int e = launch_small_ql_refined(ctx, a, nres, ws, lds, st)) return e;
         }
-#undef SMALL_QL_DISPATCH
-#undef SMALL_QL_LAUNCH
         return 0;
     }
     // one-sided Jacobi out of LDS, one block per resample, 8 lanes per column pair

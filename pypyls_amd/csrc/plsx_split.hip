@@ -407,13 +407,8 @@ int crossval_impl(plsx_ctx* ctx, const uint8_t* d_masks, int m, double* d_r, dou
         // Q = Rs . Xc^T (T' x S per split and cell): the product that dominates a split (2 T' S B flop = 1e10 at c4,
         // twice a bootstrap's cross-product).  Round 4: on the 64 x 64-block Gram kernel (P = R . E^T with E = Xc
         // shared by every split: L2 holds it) instead of the generic LDS-tiled NT GEMM
-        if (ctx->opt[OPT_GRAM_NT]) {
-            if (int e2 = run_nt(ctx, ptr<double>(ctx->R2), ctx->strideR, ctx->Bpad, Tp, ptr<double>(ctx->Xc), 0,
-                                ctx->Bpad, S, nullptr, 0, 0, 0, ctx->B, mm * J, ptr<double>(ctx->Qm),
-                                (long long)Tp * S, S, nullptr, 0, 0, st))
-                return e2;
-        } else if (int e2 = run_gram_ex(ctx, mm * J, 2, ptr<double>(ctx->Xc), S, ptr<double>(ctx->Qm), st,
-                                        ptr<double>(ctx->R2)))
+        if (int e2 = run_gram_ex(ctx, mm * J, 2, ptr<double>(ctx->Xc), S, ptr<double>(ctx->Qm), st,
+                                   ptr<double>(ctx->R2)))
             return e2;
         if (int e2 = ensure(ctx, ctx->ybar, (size_t)mm * J * T * 8)) return e2;
         if (int e2 = ensure(ctx, ctx->pred, (size_t)mm * S * T * 8)) return e2;

@@ -10,24 +10,23 @@ namespace plsxi {
 // waves (128 features) per block halve that L2 -> LDS stream (as large as the HBM stream of R at 4 waves) for
 // the compiled-in k-step counts at large B (c4: 23.3 -> 22.1 ms per 1008 bootstraps); the generic variants and
 // small B (c2: 0.97 vs 1.03 ms) keep 4.
-inline int urot_waves(const plsx_ctx* ctx, int nks_template, int B)
+inline int urot_waves(int nks_template, int B)
 {
-    const bool four = ctx->opt[OPT_UROT_NW4] != 0;
-    return (nks_template > 0 && !four && B >= 65536) ? 8 : 4;      // (few feature tiles: more, smaller blocks fill the chip)
+    return (nks_template > 0 && B >= 65536) ? 8 : 4;      // (few feature tiles: more, smaller blocks fill the chip)
 }
 
 // One launch of the rotation kernel for the chunk of L tiles [lt0, lt0 + LT).
-template <int LT, int NKS, bool TAIL = false, int NST = 2>
+template <int LT, int NKS, bool TAIL = false>
 int launch_urot(plsx_ctx* ctx, int nres, int lt0, int nsplit, int rps, double* usum, double* usq, double* out,
                 double* ps, double* pq, hipStream_t st)
 {
-    const int nw = urot_waves(ctx, NKS, ctx->B);
+    const int nw = urot_waves(NKS, ctx->B);
     const int nblk = ceil_div(ceil_div(ctx->B, 16), nw);
-    // NST LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
-    const size_t lds = (size_t)NST * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
-    HIPCHK(set_lds((k_urot<LT, NKS, TAIL, NST>), lds));
+    // two LDS stages of the M operand (whole 1 KB DMA pieces); none when M stays in L2
+    const size_t lds = (size_t)2 * ceil_div((NKS < 0 ? PLSX_UROT_KC : ctx->nks_t) * LT, 2) * 1024;
+    HIPCHK(set_lds((k_urot<LT, NKS, TAIL>), lds));
     const double* M = ptr<double>(ctx->Mfrag) + mfrag_chunk_base(lt0 / PLSX_LT_CHUNK, ctx->nks_t);
-    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL, NST>), dim3(nblk, nsplit), dim3(64 * nw), lds, st, ptr<double>(ctx->R),
+    hipLaunchKernelGGL((k_urot<LT, NKS, TAIL>), dim3(nblk, nsplit), dim3(64 * nw), lds, st, ptr<double>(ctx->R),
                        ctx->strideR, ctx->Bpad, ctx->nks_t, M, (size_t)ctx->nks_t * ctx->LT * 64, nres, ctx->B,
                        ctx->L, lt0 * 16, usum, usq, out, rps, ps, pq);
     LAUNCHCHK();
@@ -53,10 +52,10 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     const int nks = ctx->nks_t, LT = ctx->LT;
     KTimer tm(ctx, KC_UROT, st);
     const bool square = !ctx->opt[OPT_UROT_GENERIC] && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4) && nks <= 16;
-    const int nblk = ceil_div(ceil_div(ctx->B, 16), urot_waves(ctx, square ? 1 : 0, ctx->B));
+    const int nblk = ceil_div(ceil_div(ctx->B, 16), urot_waves(square ? 1 : 0, ctx->B));
     int nsplit = 1;
     if (!out && nres >= 64) {
-        const int slots = std::max(1, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)) * 4 / urot_waves(ctx, square ? 1 : 0, ctx->B));
+        const int slots = std::max(1, chip_slots(reinterpret_cast<const void*>(k_urot<4, 0>)) * 4 / urot_waves(square ? 1 : 0, ctx->B));
         // many feature blocks: cut the resamples so that the grid ends in a full round;
         // few (small B): cut them so that the grid fills the chip at all -- every block
         // walks its resamples one after the other
@@ -79,9 +78,7 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     // next resample prefetched
     // the last tile of L on the 4x4x4 shape when it holds at most 4 live columns (see k_urot)
     const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !ctx->opt[OPT_UROT_NO_TAIL4];
-    if (!generic && ctx->opt[OPT_UROT_M3] && nks == 13 && LT == 4 && tail4)
-        rc = launch_urot<4, 13, true, 3>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st);
-    else if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
+    if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
 #define UCASE(N) case N: rc = tail4 ? launch_urot<(N + 3) / 4, N, true>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
                                     : launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;

@@ -49,7 +49,8 @@ int launch_xprod(plsx_ctx* ctx, int groups, hipStream_t st)
 // group's resamples, 24 tiles, row -> LV map `out_row_w`).  Blocks of 8 waves = 128 feature columns: every block
 // streams the group's whole A operand through LDS, so twice the columns per block is half the A traffic per
 // flop -- at S = 1000 (A = 3 MB per group against the XCD's 4 MB L2, which the X stream keeps evicting) the
-// 64-column blocks re-fetched 20 % of A from HBM: c5 49.8 -> 45.8 ms.  PLSX_EPI2_NW4 keeps the 4-wave blocks.
+// 64-column blocks re-fetched 20 % of A from HBM: c5 49.8 -> 45.8 ms.  4-wave blocks remain for L too large for
+// the 8-wave epilogue's LDS.
 int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int groups, int L, hipStream_t st)
 {
     constexpr int MT = 24, KT = 1;
@@ -57,10 +58,9 @@ int launch_xprod_acc(plsx_ctx* ctx, const double* Afrag, size_t gstride, int gro
     SplitEpi se;
     memset(&se, 0, sizeof(se));
     se.acc_sum = ptr<double>(ctx->psum); se.acc_sq = ptr<double>(ctx->psq); se.accL = L; se.accB = ctx->B;
-    const bool narrow = ctx->opt[OPT_EPI2_NW4] != 0;
     KTimer tm(ctx, KC_XPROD, st);
     // (LDS of the epilogue: [2][L] sum rows + 32 staging rows of NW * 16 + 16 doubles, the row -> l map)
-    if (!narrow && (2 * (size_t)L + 32) * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
+    if ((2 * (size_t)L + 32) * (8 * 16 + 16) * 8 + MT * 16 * 4 <= 96 * 1024) {
         constexpr int NW = 8;
         const size_t lds = std::max(stage, ((size_t)2 * L + 32) * (NW * 16 + 16) * 8 + (size_t)MT * 16 * 4);
         HIPCHK(set_lds(k_xprod<MT, NW, KT, 0, 2>, lds));
@@ -432,7 +432,6 @@ int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
     const int S = ctx->S, L = ctx->method == PLSX_REGRESSION ? ctx->ncomp : ctx->L, B = ctx->B;
     const size_t gstride = (size_t)ctx->nks * MT * 64;
     ctx->quad_MT = MT; ctx->quad_gpl = gpl;
-    const bool full = ctx->opt[OPT_QUAD_FULL_ROWS] != 0;      // A/B: every row block over all S columns (no use of the symmetry)
     if (ctx->timing) ++ctx->quad_series;
     // l's per pass: A operands within 1 GB
     const int lmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)L, (1ULL << 30) / (gstride * 8 * gpl)));
@@ -447,25 +446,21 @@ int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
         {
             KTimer tm(ctx, KC_BUILD, st);
             hipLaunchKernelGGL(k_pack_afrag, dim3(64, groups), dim3(256), 0, st,
-                               ptr<double>(ctx->Cq) + (size_t)l0 * S * S, S, gpl, MT, ptr<double>(ctx->Afrag_q), gstride, full ? 1 : 0);
+                               ptr<double>(ctx->Cq) + (size_t)l0 * S * S, S, gpl, MT, ptr<double>(ctx->Afrag_q), gstride);
             LAUNCHCHK();
         }
         SplitEpi se;
         memset(&se, 0, sizeof(se));
-        se.acc_sum = ptr<double>(ctx->qpart); se.npairs = gpl; se.accB = S; se.nmu = full ? 1 : 0; se.J = nl;
+        se.acc_sum = ptr<double>(ctx->qpart); se.npairs = gpl; se.accB = S; se.J = nl;
         // Groups are numbered row block first: the groups of a sweep go to the eight XCDs in lockstep, and with the
         // blocks of an LV next to each other (contraction lengths S, 2 S / 3, S / 3 at c5) the XCDs with short blocks
-        // waited for the one with the long block: 38.7 ms, block-major 35.1, one launch per row block (A/B option) 34.9
-        const bool per_block = ctx->opt[OPT_QUAD_LAUNCH_PER_BLOCK] != 0;
-        for (int pb = 0; pb < (per_block ? gpl : 1); ++pb) {
-            const int ng = per_block ? nl : groups;
-            se.Tpp = pb;
-            se.acc_sum = ptr<double>(ctx->qpart) + (size_t)pb * nl * ctx->Bpad;
+        // waited for the one with the long block: 38.7 ms, block-major 35.1 (one launch per row block: 34.9)
+        {
             KTimer tm(ctx, KC_XPROD, st);
-            hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 7>), dim3(ncolblk * round_up(ng, 8)), dim3(NW * 64), stage, st,
-                               ptr<double>(ctx->Afrag_q) + (size_t)pb * nl * gstride, gstride, ptr<double>(ctx->Xc), ctx->Bpad,
-                               ctx->nks, (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
-                               (const double*)nullptr, 0, ng, ncolblk, (double*)nullptr, se, 1);
+            hipLaunchKernelGGL((k_xprod<MT, NW, KT, 0, 7>), dim3(ncolblk * round_up(groups, 8)), dim3(NW * 64), stage, st,
+                               ptr<double>(ctx->Afrag_q), gstride, ptr<double>(ctx->Xc), ctx->Bpad, ctx->nks,
+                               (double*)nullptr, ctx->Bpad, 0, (const int*)nullptr, (const int*)nullptr,
+                               (const double*)nullptr, 0, groups, ncolblk, (double*)nullptr, se, 1);
             LAUNCHCHK();
         }
         {
@@ -491,7 +486,7 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
     // the S rows of a C_l in gpl blocks of MT tiles, as evenly as the instantiated block heights allow
     // (at least two blocks once there are 8 tiles: the second one starts its contraction half way down)
     const int tiles = ceil_div(S, 16), gpl = quad_blocks(tiles);
-    const int need = ctx->opt[OPT_QUAD_MT] > 0 ? std::min(24, ctx->opt[OPT_QUAD_MT]) : ceil_div(tiles, gpl);
+    const int need = ceil_div(tiles, gpl);
     if (need <= 8) return quad_finish_t<8>(ctx, d_usq, ceil_div(tiles, 8), st);
     if (need <= 12) return quad_finish_t<12>(ctx, d_usq, ceil_div(tiles, 12), st);
     if (need <= 16) return quad_finish_t<16>(ctx, d_usq, ceil_div(tiles, 16), st);

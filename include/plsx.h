@@ -369,11 +369,12 @@ const char* plsx_option_name(int index);
  * eps (d_max / d_k)^2 where the reference's SVD of R (pyls/compute.py:10-52) loses eps d_max / d_k.  A resample
  * with a live LV below 1e-3 d_max therefore re-solves the subspace of its small LVs on R itself (its Gram matrix
  * in the rotated basis V_s^T R, whose rounding errors are relative to the SMALL scale) wherever R exists: every
- * feature-pass route with T' <= 64.  A data set whose ORIGINAL spectrum is graded (plsx_decompose /
- * plsx_set_original) is taken off the dual-space routes for that reason.  This call synchronises the device and
- * returns -- and clears -- two counters since the last call: resamples whose small LVs were refined, and resamples
- * with a live LV below 1e-5 d_max that could NOT be (T' > 64, or a dual-space route on data whose original
- * spectrum was not graded): LVs below ~ 6e-6 d_max may miss the 1e-5 relative tolerance; the host warns.
+ * feature-pass route, at every T' (one-sided Jacobi solver up to T' = 64, Householder + QL above).  A data set
+ * whose ORIGINAL spectrum is graded (plsx_decompose / plsx_set_original) is taken off the dual-space routes for
+ * that reason.  This call synchronises the device and returns -- and clears -- two counters since the last call:
+ * resamples whose small LVs were refined, and resamples with a live LV below 1e-5 d_max that could NOT be -- only a
+ * dual-space route on data whose original spectrum was not graded leaves any: their LVs below ~ 6e-6 d_max may
+ * miss the 1e-5 relative tolerance; the host warns.
  */
 int plsx_numeric_report(plsx_ctx* ctx, long long* refined, long long* unrefined);
 

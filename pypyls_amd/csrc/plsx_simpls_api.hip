@@ -223,9 +223,11 @@ try {
     HIPCHK(hipSetDevice(ctx->device));
     const int k = ctx->ncomp, T = ctx->T;
     const int nb = launch_groups(ctx, n, ctx->npg) * ctx->npg;          // cross-product batch (R scratch)
-    // the dual solver runs on batches of up to 4096 bootstraps (whole groups), each followed by the
-    // cross-product batches that turn its dual weights into feature-space weights
-    int nbs = std::max(nb, (4096 / ctx->npg) * ctx->npg);
+    // the dual solver runs on batches of up to 8192 bootstraps (whole groups; one wave per bootstrap, up to 8 per
+    // SIMD: a launch of the component step lasts one wave's latency chain whatever the batch, so 5000 bootstraps
+    // in one batch cost little more than 4096 -- and less than 4096 + 904), each followed by the cross-product
+    // batches that turn its dual weights into feature-space weights
+    int nbs = std::max(nb, (8192 / ctx->npg) * ctx->npg);
     if (ctx->quad_active) {        // V of a solver batch, dense and transposed, within 1 GB each
         if (!simpls_single_pass(ctx)) return fail(ctx, PLSX_ERR_STATE, "plsx_simpls_boot_batch: open series on a route that left it");
         nbs = (int)std::max<long long>(ctx->npg, std::min<long long>(nbs, (1LL << 30) / ((long long)k * ctx->S * 8)));

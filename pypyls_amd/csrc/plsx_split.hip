@@ -12,7 +12,7 @@ namespace plsxi {
 bool split_reader_ok(const plsx_ctx* ctx)
 {
     const int nb = ctx->nks_t;
-    return (nb == 5 || nb == 9 || nb == 13) && ctx->L == ctx->Tp && ctx->J <= SF_MAXJ && !ctx->opt[OPT_SPLIT_TWO_READERS] &&
+    return nb >= 5 && nb <= 13 && ctx->L == ctx->Tp && ctx->J <= SF_MAXJ && !ctx->opt[OPT_SPLIT_TWO_READERS] &&
            (long long)ctx->Tpp * ctx->Bpad * 8 < (1LL << 31);
 }
 
@@ -147,9 +147,9 @@ int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mv
         KTimer tm(ctx, KC_UCORR, st);
         int rc;
         switch (NB) {
-            case 5: rc = launch_split_fused<5>(ctx, a, blocks, lds, st); break;
-            case 9: rc = launch_split_fused<9>(ctx, a, blocks, lds, st); break;
-            case 13: rc = launch_split_fused<13>(ctx, a, blocks, lds, st); break;
+#define SFCASE(N) case N: rc = launch_split_fused<N>(ctx, a, blocks, lds, st); break;
+            SFCASE(5) SFCASE(6) SFCASE(7) SFCASE(8) SFCASE(9) SFCASE(10) SFCASE(11) SFCASE(12) SFCASE(13)
+#undef SFCASE
             default: return fail(ctx, PLSX_ERR_STATE, "split reader: unsupported T'");
         }
         if (rc) return rc;

@@ -95,7 +95,9 @@ struct SplitFusedArgs {
 template <int NB, int ROLE>
 __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp)
 {
-    constexpr int ROWS = 4 * NB, P = SF_PITCH, TILE = ROWS * P + SF_TILE_PAD, LT = (NB + 3) / 4, LF = LT - 1;
+    constexpr int ROWS = 4 * NB, P = SF_PITCH, TILE = ROWS * P + SF_TILE_PAD, LT = (NB + 3) / 4;
+    constexpr bool TAIL = (NB % 4) == 1;                // the last tile of L holds <= 4 live LVs: it runs on the 4x4x4 shape
+    constexpr int LF = TAIL ? LT - 1 : LT;              // tiles of L on the 16x16x4 shape
     constexpr int NPAIR = (LT + 1) / 2;                 // vd^T fragments travel in pairs of L tiles (one 16-byte read)
     static_assert(TILE % 8 == 4, "tile stride must be 4 mod 8 doubles (bank layout of the Gram operand reads)");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
         for (int e = 0; e < 2; ++e) {
             const int t = 2 * pp + e;
             if (t < LF) v[e] = a.Mfrag[(ks * LT + t) * 64 + ln];
-            else if (t == LF) v[e] = a.Mfrag[(ks * LT + LF) * 64 + ln + toff_l];
+            else if (TAIL && t == LF) v[e] = a.Mfrag[(ks * LT + LF) * 64 + ln + toff_l];
         }
         *reinterpret_cast<d2*>(sM + 2 * (size_t)idx) = v;
     }
@@ -271,7 +273,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
                     for (int ee = 0; ee < 2; ++ee) {
                         const int t = 2 * pp + ee;
                         if (t < LF) e[t] = mfma_f64(av[ee], bfr[ks], e[t]);
-                        else if (t == LF) et = mfma_f64_4x4(av[ee], bfr[ks], et);
+                        else if (TAIL && t == LF) et = mfma_f64_4x4(av[ee], bfr[ks], et);
                     }
                 }
 #pragma unroll
@@ -281,7 +283,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
                     const double x = e[l][i], y = dpp_f64<0x128>(x);      // row_ror:8 -> the other half's value
                     ss[l][i] += x; sq[l][i] += x * x; sx[l][i] += x * y;
                 }
-            {
+            if constexpr (TAIL) {
                 const double x = et, y = dpp_f64<0x128>(x);
                 ss[LT - 1][0] += x; sq[LT - 1][0] += x * x; sx[LT - 1][0] += x * y;
             }
@@ -315,7 +317,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
         for (int l = 0; l < LT; ++l)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (l == LT - 1 && i > 0) break;
+                if (TAIL && l == LT - 1 && i > 0) break;
                 double v0 = ss[l][i], v1 = sq[l][i], v2 = sx[l][i];
                 v0 += dpp_f64<SD_DPP_XOR1>(v0); v1 += dpp_f64<SD_DPP_XOR1>(v1); v2 += dpp_f64<SD_DPP_XOR1>(v2);
                 v0 += dpp_f64<SD_DPP_XOR2>(v0); v1 += dpp_f64<SD_DPP_XOR2>(v1); v2 += dpp_f64<SD_DPP_XOR2>(v2);

@@ -80,8 +80,11 @@ int run_urot(plsx_ctx* ctx, int nres, double* usum, double* usq, double* out, hi
     const bool tail4 = ctx->L - 16 * (LT - 1) <= 4 && !ctx->opt[OPT_UROT_NO_TAIL4];
     if (!generic && LT <= PLSX_LT_CHUNK && LT == ceil_div(nks, 4)) {
         switch (nks) {
-#define UCASE(N) case N: rc = tail4 ? launch_urot<(N + 3) / 4, N, true>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
-                                    : launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;
+        // (the 4x4x4 tail is instantiated where L = T' produces it, T' = 4 k + 1 .. 4 k + 4 with k = 0 mod 4; a smaller
+        // L that happens to leave <= 4 columns in the last tile of another count takes the 16x16x4 shape there)
+#define UCASE(N) case N: rc = (tail4 && (N) % 4 == 1) \
+                            ? launch_urot<(N + 3) / 4, N, ((N) % 4 == 1)>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st) \
+                            : launch_urot<(N + 3) / 4, N>(ctx, nres, 0, nsplit, rps, usum, usq, out, ps, pq, st); break;
         UCASE(1) UCASE(2) UCASE(3) UCASE(4) UCASE(5) UCASE(6) UCASE(7) UCASE(8)
         UCASE(9) UCASE(10) UCASE(11) UCASE(12) UCASE(13) UCASE(14) UCASE(15) UCASE(16)
 #undef UCASE

@@ -159,8 +159,9 @@ def options_from_env(environ=None):
 
 class GradedSpectrumWarning(UserWarning):
     """Resamples had live latent variables below 1e-5 of the largest singular value that the
-    device could not refine on R (T' > 64, or a dual-space route): their smallest LVs may miss
-    the 1e-5 relative tolerance against an SVD of R (include/plsx.h, plsx_numeric_report)."""
+    device could not refine on R (a dual-space route on data whose ORIGINAL spectrum was not graded;
+    every feature-pass route refines, at every T'): their smallest LVs may miss the 1e-5 relative
+    tolerance against an SVD of R (include/plsx.h, plsx_numeric_report)."""
 
 
 def check_index_array(samples, S):
@@ -267,8 +268,8 @@ class Engine(object):
         if warn and b.value:
             import warnings
             warnings.warn('{} decomposition(s) had live latent variables below 1e-5 of the largest singular '
-                          'value that could not be refined on the cross-covariance matrix (T\' > 64 or a '
-                          'dual-space route): singular values below ~6e-6 of the largest may differ from an '
+                          'value that could not be refined on the cross-covariance matrix (a dual-space route on '
+                          'data whose original spectrum was not graded): singular values below ~6e-6 of the largest may differ from an '
                           'SVD of R by more than 1e-5 relative'.format(b.value), GradedSpectrumWarning,
                           stacklevel=2)
         return a.value, b.value

@@ -27,6 +27,19 @@ from .structures import PLSInputs, PLSResults
 
 _METHOD_CODE = {'behavioral': 0, 'meancentered': 1}
 
+# The B- and n_boot-sized result arrays (x_weights, bootstrap ratios / standard errors, the (T', L, n_boot)
+# distributions: 440 MB at the headline shape) land in page-locked memory and PLSResults holds numpy VIEWS of it: no
+# second pass over them (55 ms of the call's 41 ms fixed cost would come back), but that memory stays locked for as
+# long as the caller keeps the results.  A caller that stores many results (a parameter sweep) sets this to True --
+# or copies what it keeps with np.array(...) -- and gets ordinary arrays.
+COPY_RESULTS_OUT_OF_PINNED = False
+
+
+def _host_array(t):
+    a = t.numpy()
+    return np.array(a) if COPY_RESULTS_OUT_OF_PINNED else a
+
+
 
 def _as_float_array(A, name):
     A = np.asarray(A)
@@ -376,7 +389,7 @@ class _PLSCRun(object):
                                      r_squared=np.ascontiguousarray(cv[Tn:])))
         eng.sync()
         tick('finish_and_d2h')
-        xw = h_xw.numpy()
+        xw = _host_array(h_xw)
         res['x_weights'], res['y_weights'] = xw, yw
         res['x_scores'] = h_scores.numpy() + (xmean @ xw)[None, :]
         if orig_splits is not None and d_perm is not None:
@@ -417,13 +430,13 @@ class _PLSCRun(object):
 
         # ---- bootstrap ratios / intervals ----------------------------------
         if bootsamp is not None:
-            distrib = h_dist.numpy().reshape(eng.Tp, L, n_boot_tot)                   # (T', L, n_boot)
+            distrib = _host_array(h_dist).reshape(eng.Tp, L, n_boot_tot)                   # (T', L, n_boot)
             if lo_hi is not None:
                 ci_arr = np.stack([lo_hi[0].cpu().numpy().reshape(eng.Tp, L),
                                    lo_hi[1].cpu().numpy().reshape(eng.Tp, L)], -1)
             else:                                       # more than 16384 bootstraps: numpy on the host copy
                 ci_arr = np.stack(hostmath.boot_ci(distrib, ci=inp.get('ci', 95)), -1)
-            bsr, se = h_bsr.numpy(), h_se.numpy()
+            bsr, se = _host_array(h_bsr), _host_array(h_se)
             if self.method == 'behavioral':
                 res['bootres'].update(dict(
                     x_weights_normed=bsr, x_weights_stderr=se,

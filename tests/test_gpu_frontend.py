@@ -284,6 +284,24 @@ def test_default_engine_is_reused_and_rebinding_changes_nothing():
     assert engine.default_engine() is not eng
 
 
+def test_results_can_be_copied_out_of_page_locked_memory(monkeypatch):
+    """the large result arrays are views of page-locked staging buffers by default (no second pass over
+    440 MB at the headline shape); plsc.COPY_RESULTS_OUT_OF_PINNED = True returns ordinary arrays with the same
+    values."""
+    import pypyls_amd as pls
+    from pypyls_amd import plsc
+    rs = np.random.RandomState(8)
+    X, Y = rs.randn(40, 700), rs.randn(40, 3)
+    kw = dict(n_perm=10, n_boot=12, test_split=0, seed=2, verbose=False)
+    a = pls.behavioral_pls(X, Y, **kw)
+    monkeypatch.setattr(plsc, 'COPY_RESULTS_OUT_OF_PINNED', True)
+    b = pls.behavioral_pls(X, Y, **kw)
+    for key in ('x_weights',):
+        assert np.array_equal(a[key], b[key]) and b[key].flags.owndata and not a[key].flags.owndata
+    for key in ('x_weights_normed', 'x_weights_stderr'):
+        assert np.array_equal(a.bootres[key], b.bootres[key]) and b.bootres[key].flags.owndata
+
+
 @pytest.mark.parametrize('n_perm,n_boot', [(0, 0), (7, 0), (0, 7)])
 def test_calls_without_permutations_or_bootstraps(n_perm, n_boot):
     """Only the legs that were asked for run and only their results exist (BasePLS.run_pls, base.py:366-397):

@@ -3,7 +3,8 @@
 d_1/d_L drawn log-uniformly from 1e2 to 8e5, random designs (1-3 groups x 1-3 conditions, T = 3..12, both PLS-C
 methods, every mean-centring), every comparison PER LATENT VARIABLE at 1e-5 against the oracle -- the checks of
 tests/test_gpu_graded.py (decomposition, permutations on both routes rotated and not, bootstraps, bootstrap
-ratios), which assert that nothing graded was left unrefined.  usage: python tools/fuzz_graded.py [n_cases] [seed]"""
+ratios), which assert that nothing graded was left unrefined.  FUZZ_WIDE=1: T' = 66 .. 300 instead (the QL solver's
+refinement).  usage: python tools/fuzz_graded.py [n_cases] [seed]"""
 import os
 import sys
 
@@ -17,7 +18,23 @@ from oracle import cpu_ref as ref                     # noqa: E402
 from pypyls_amd import resampling as rsmp             # noqa: E402
 
 
+def one_wide(rs, idx):
+    """T' = 65 .. 300 (one group, one condition: T' = T): the Householder + QL solver and its refinement (round 5)."""
+    T = int(rs.choice([66, 80, 100, 130, 190, 200, 260, 300]))
+    S = T + int(rs.randint(20, 120))
+    B = int(rs.choice([900, 2000, 3500]))
+    ratio = float(10 ** rs.uniform(2.0, 5.3))
+    X = rs.randn(S, B)
+    Y = tg.graded_behaviours(rs, S, T, ratio, 'mix')
+    desc = dict(i=idx, method='behavioral', groups=[S], n_cond=1, S=S, B=B, T=T, kind='mix', target=ratio)
+    got, worst = tg.run_case(X, Y, [S], 1, 'behavioral', n=3, null_lvs=None)
+    desc.update(ratio=float(got), worst=float(worst))
+    return desc, 'ok'
+
+
 def one(rs, idx):
+    if os.environ.get('FUZZ_WIDE'):
+        return one_wide(rs, idx)
     method = rs.choice(['behavioral', 'behavioral', 'meancentered'])
     n_groups, n_cond = int(rs.choice([1, 1, 2, 3])), int(rs.choice([1, 2, 3]))
     ratio = float(10 ** rs.uniform(2.0, 5.9))

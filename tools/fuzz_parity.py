@@ -120,6 +120,8 @@ def regression_case(rs, idx):
         X[int(rs.randint(S))] = np.nan
         Y[int(rs.randint(S))] = np.nan
         k = min(k, S - 5)
+        if not os.environ.get('FUZZ_OLD_GUARD'):
+            k = max(1, min(k, (S - 2) // 2 - 2))     # (the rank guard above, on the S - 2 rows that survive)
     LAST = desc = dict(i=idx, method='regression', S=S, B=B, T=T, k=k, nan_rows=bool(nan_rows))
     from pypyls_amd.engine import Engine, options_from_env
     eng = Engine(**options_from_env())
@@ -129,6 +131,8 @@ def regression_case(rs, idx):
     res = pls.pls_regression(X, Y, n_components=k, n_perm=6, n_boot=5, seed=int(rs.randint(1 << 30)), verbose=False,
                              _engine=eng)
     want = ref.run_regression(X, Y, k, permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples)
+    bs = np.asarray(res.bootres.bootsamples)
+    desc['min_distinct_rows'] = int(min(len(np.unique(bs[:, i])) for i in range(bs.shape[1])))
     for key in ('x_weights', 'y_loadings', 'varexp'):
         close(res[key], want[key], 1e-5, key)
     close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-5, 'perm varexp')

@@ -634,7 +634,24 @@ class SplitHalf(object):
         # projections 8 T' L B as in SURVEY's W_F(split)
         wf = (0.5 * 2.0 * S * Tp * B + 2.0 * S * B + 8.0 * Tp * L * B) * units
         tf = wf / (tot * 1e-3) / 1e12
-        return {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': PEAK_FP64_MFMA_TFLOPS,
+        # the two large kernels on their own work (HIP events of the library, launch stream): the writer contracts the
+        # first half (0.5 x 2 S T' B per split), the one-pass reader multiplies G_h = D_h R_p^T and E_h = vd^T D_h of both
+        # halves (8 T' L B per split; on the two-reader route the same work is k_gram4 + k_ucorr_partial)
+        one_pass = bool(self.eng.split_route())
+        per_kernel = {}
+        for key, label, w in (('k_xprod', 'k_xprod_compact<4,3,8,true> (raw first-half sums, one split per block)'
+                               if one_pass else 'k_xprod_compact<4,3,5,true> (both z-scored halves)', 0.5 * 2.0 * S * Tp * B),
+                              ('k_ucorr_partial', 'k_split_fused<13> (one reader pass per pair of splits)' if one_pass
+                               else 'k_ucorr_partial (projections; the cross-Gram is timed under k_gram)', 8.0 * Tp * L * B)):
+            if key in kt and kt[key][0] > 0:
+                ms, n = kt[key]
+                per_kernel[key] = {'kernel': label, 'avg_launch_ms': ms / max(n, 1), 'launches': n,
+                                   'achieved_tflops': w * units / (ms * 1e-3) / 1e12,
+                                   'frac': w * units / (ms * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+        if one_pass:
+            dom = per_kernel.get(dom, {}).get('kernel', dom)
+        return {'bound': 'mfma', 'kernel': dom, 'achieved': tf, 'peak': PEAK_FP64_MFMA_TFLOPS, 'kernels': per_kernel,
+                'route': 'one reader pass over raw first-half sums' if one_pass else 'two readers over both halves',
                 'unit': 'TFLOP/s', 'frac': tf / PEAK_FP64_MFMA_TFLOPS,
                 'dense_equivalent_tflops': wf_dense / (tot * 1e-3) / 1e12,
                 'algorithmic_speedup_vs_dense': wf_dense / wf,

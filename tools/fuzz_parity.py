@@ -133,6 +133,9 @@ def regression_case(rs, idx):
     want = ref.run_regression(X, Y, k, permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples)
     bs = np.asarray(res.bootres.bootsamples)
     desc['min_distinct_rows'] = int(min(len(np.unique(bs[:, i])) for i in range(bs.shape[1])))
+    if os.environ.get('FUZZ_DUMP'):
+        np.savez(os.path.join(ROOT, 'gpurun_out', 'fuzz_reg_%d.npz' % idx), X=X, Y=Y, k=k, perms=res.permres.permsamples,
+                 boots=res.bootres.bootsamples)
     for key in ('x_weights', 'y_loadings', 'varexp'):
         close(res[key], want[key], 1e-5, key)
     close(res.permres.perm_singval, want['permres']['perm_singval'], 1e-5, 'perm varexp')

@@ -29,7 +29,7 @@ pmc() {     # $1 = counter list
   ctr=$1; n=$(echo $ctr | tr ' ' '_')
   rm -rf /tmp/pmc_$n
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$n -o p -- python "$repo/bench.py" \
-      --cpu-sample 0 --steps 1 --warmup 1 --no-primal > /tmp/pmc_$n.log 2>&1
+      --cpu-sample 0 --steps 1 --warmup 1 --no-primal --no-configs > /tmp/pmc_$n.log 2>&1
   f=$(find /tmp/pmc_$n -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] || { echo "no counter csv for $ctr"; tail -3 /tmp/pmc_$n.log; return; }
   python - "$f" "$repo/gpurun_out/${tag}_pmc_$n.csv" <<'PY'
@@ -41,12 +41,12 @@ for r in csv.DictReader(open(sys.argv[1])):
 with open(sys.argv[2], "w") as f:
     f.write("Kernel,Dispatches,Counter,SumOverDispatches\n")
     for (k, c), v in sorted(acc.items()):
-        if any(s in k for s in ("k_xprod", "k_gram4", "k_urot", "k_small", "k_nt_gemm")):
+        if any(s in k for s in ("k_xprod", "k_gram4", "k_urot", "k_small", "k_nt_gemm", "k_split_fused", "k_sd_")):
             f.write('"%s",%d,%s,%.1f\n' % (k, len(disp[k]), c, v)); print(k[:60], len(disp[k]), c, v)
 PY
 }
 
-echo "== default bench"; stats c4 --steps 5 --warmup 2
+echo "== default bench"; stats c4 --steps 5 --warmup 2 --no-configs
 echo "== c4split"; stats c4split --config c4split --steps 2 --warmup 1
 echo "== c5"; stats c5 --config c5 --steps 2 --warmup 1
 echo "== c2"; stats c2 --config c2 --steps 3 --warmup 1

@@ -115,7 +115,9 @@ int plsx_set_original(plsx_ctx* ctx, const double* d_xw, const double* d_sv,
 /* Sign convention of compute.svd (pyls/compute.py:43-50, sklearn's svd_flip applied to the decomposed matrix):
  * in place on the DEVICE copies of the decomposition -- when T' <= B the entry of largest magnitude of every
  * x_weights column becomes positive, otherwise that of every y_weights column; both factors get the same signs.
- * d_xw (B, L), d_yw (T', L) as plsx_decompose wrote them.  (The host may equally apply the rule itself.) */
+ * d_xw (B, L), d_yw (T', L) as plsx_decompose wrote them.  (The host may equally apply the rule itself.)
+ * Data bound for regression: d_xw (B, k) x_weights, d_yw (T, k) the right vectors of plsx_simpls_decompose; the
+ * x side leads when B > T (compute.svd of the T x B cross-product, pyls/types/regression.py:103, compute.py:43-50). */
 int plsx_svd_flip(plsx_ctx* ctx, double* d_xw, double* d_yw, void* stream);
 
 /* d_out[i][k] = d_in[i][k] * d_scale[k] on (rows, cols) row-major arrays (in place allowed): the device side of
@@ -126,6 +128,11 @@ int plsx_scale_columns(plsx_ctx* ctx, const double* d_in, long long rows, int co
 /* d_dst (cols, rows) = d_src (rows, cols)^T, both dense row-major: the (n_boot, T' L) bootstrap distributions
  * as the (T' L, n_boot) series plsx_percentile_ci and PLSResults' (T', L, n_boot) layout want them. */
 int plsx_transpose(plsx_ctx* ctx, const double* d_src, int rows, int cols, double* d_dst, void* stream);
+
+/* d_out[r][c] = d_in[r][c] - mean(d_in[r][:]) on (rows, cols) row-major arrays (in place allowed; fixed summation
+ * order): the column-centred original x_weights that plsx_simpls_set_original takes, formed on the device from the
+ * (k, B) output of plsx_simpls_decompose (the centring inside compute.efficient_corr(x_weights, original), pyls/types/regression.py:318-319). */
+int plsx_center_rows(plsx_ctx* ctx, const double* d_in, int rows, long long cols, double* d_out, void* stream);
 
 /* Centred projection (X - colmean(X)) @ W for W given as (B, L): the device
  * part of `x_scores = X @ x_weights` (pyls/base.py:364).  d_out (S, L). */

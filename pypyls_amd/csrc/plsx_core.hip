@@ -1043,11 +1043,15 @@ try {
     if (!d_xw || !d_yw) return fail(ctx, PLSX_ERR_ARG, "plsx_svd_flip: null input");
     hipStream_t st = static_cast<hipStream_t>(stream);
     HIPCHK(hipSetDevice(ctx->device));
-    const int L = ctx->L;
-    // compute.svd decomposes crosscov^T when T' <= B: the flipped factor is then the (B x L) x_weights
-    const bool lead_x = ctx->Tp <= ctx->B;
+    // compute.svd decomposes crosscov^T when T' <= B: the flipped factor is then the (B x L) x_weights.  SIMPLS
+    // (pyls/types/regression.py:103: compute.svd of Cov = Y0^T X0 (T x B) per component, flipped per compute.py:43-50): on the x side when
+    // B > T, else on the right vectors c (T x k); L = n_components there
+    const bool reg = ctx->method == PLSX_REGRESSION;
+    const int L = reg ? ctx->ncomp : ctx->L;
+    const int Ty = reg ? ctx->T : ctx->Tp;
+    const bool lead_x = reg ? ctx->B > ctx->T : ctx->Tp <= ctx->B;
     const double* lead = lead_x ? d_xw : d_yw;
-    const long long rows = lead_x ? ctx->B : ctx->Tp;
+    const long long rows = lead_x ? ctx->B : Ty;
     if (int e = ensure(ctx, ctx->flipws, (size_t)3 * L * 8)) return e;
     unsigned long long* gmax = ptr<unsigned long long>(ctx->flipws);
     unsigned long long* grow = gmax + L;
@@ -1061,7 +1065,7 @@ try {
     LAUNCHCHK();
     hipLaunchKernelGGL(k_flip_signs, dim3(ceil_div(L, 64)), dim3(64), 0, st, lead, L, grow, signs);
     LAUNCHCHK();
-    const long long cx = (long long)ctx->B * L, cy = (long long)ctx->Tp * L;
+    const long long cx = (long long)ctx->B * L, cy = (long long)Ty * L;
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((cx + 255) / 256)), dim3(256), 0, st, d_xw, cx, L, signs, d_xw);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((cy + 255) / 256)), dim3(256), 0, st, d_yw, cy, L, signs, d_yw);
@@ -1090,6 +1094,16 @@ try {
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_transpose, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(32, 8), 0,
                        static_cast<hipStream_t>(stream), d_src, rows, cols, cols, d_dst, rows);
+    LAUNCHCHK();
+    return PLSX_OK;
+} PLSX_CATCH(ctx)
+
+int plsx_center_rows(plsx_ctx* ctx, const double* d_in, int rows, long long cols, double* d_out, void* stream)
+try {
+    if (!ctx) return PLSX_ERR_ARG;
+    if (!d_in || !d_out || rows < 1 || cols < 1) return fail(ctx, PLSX_ERR_ARG, "plsx_center_rows: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_center_rows, dim3(rows), dim3(256), 0, static_cast<hipStream_t>(stream), d_in, cols, d_out);
     LAUNCHCHK();
     return PLSX_OK;
 } PLSX_CATCH(ctx)

@@ -3436,6 +3436,26 @@ static __global__ void k_scale_cols(const double* __restrict__ in, long long cou
     if (i < count) out[i] = in[i] * scale[(int)(i % cols)];
 }
 
+// out[r][c] = in[r][c] - mean_c in[r][:]   (rows x cols row-major, one block per row, fixed summation order; in == out
+// allowed): the column-centred original x_weights of the SIMPLS sign alignment, held transposed (k, B)
+static __global__ __launch_bounds__(256)
+void k_center_rows(const double* __restrict__ in, long long cols, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    const double* src = in + (size_t)blockIdx.x * cols;
+    double* dst = out + (size_t)blockIdx.x * cols;
+    double s = 0.0;
+    for (long long c = threadIdx.x; c < cols; c += 256) s += src[c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double mean = red[0] / (double)cols;
+    for (long long c = threadIdx.x; c < cols; c += 256) dst[c] = src[c] - mean;
+}
+
 // out[a][c] = mean_b in[a][b][c], terms added in order of b (NaN propagates, as numpy's mean: base.py:770)
 static __global__ void k_mean_axis1(const double* __restrict__ in, int na, int nb, int nc, double* __restrict__ out)
 {

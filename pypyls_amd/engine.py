@@ -76,6 +76,7 @@ def _load():
         'plsx_svd_flip': ([vp, vp, vp, vp], i32),
         'plsx_scale_columns': ([vp, vp, ctypes.c_longlong, i32, vp, vp, vp], i32),
         'plsx_transpose': ([vp, vp, i32, i32, vp, vp], i32),
+        'plsx_center_rows': ([vp, vp, i32, ctypes.c_longlong, vp, vp], i32),
         'plsx_set_option': ([vp, ctypes.c_char_p, i32], i32),
         'plsx_option_name': ([i32], ctypes.c_char_p),
         'plsx_numeric_report': ([vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)], i32),
@@ -115,7 +116,7 @@ def exported_symbols():
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
              'plsx_gen_splits', 'plsx_gen_splits_seeded', 'plsx_gen_permsamp_stream',
              'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report',
-             'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_mean_splits']
+             'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_center_rows', 'plsx_mean_splits']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -556,6 +557,25 @@ class Engine(object):
         self.sync()
         return (np.ascontiguousarray(xwT.cpu().numpy().T), pct.cpu().numpy(), cv.cpu().numpy(),
                 yl.cpu().numpy())
+
+    def simpls_decompose_dev(self):
+        """The original SIMPLS fit with everything B-sized left on the device and the sign rule of compute.svd applied
+        there (plsx_svd_flip): -> x_weights (B, k) DEVICE tensor, pctvar_y (k,) numpy, y_loadings (T, k) numpy."""
+        xwT, pct = self._empty((self.k, self.B)), self._empty((self.k,))
+        cv, yl = self._empty((self.T, self.k)), self._empty((self.T, self.k))
+        self._check(self.lib.plsx_simpls_decompose(self.ctx, xwT.data_ptr(), pct.data_ptr(), cv.data_ptr(),
+                                                   yl.data_ptr(), self._stream()))
+        W = self.transpose_dev(xwT)
+        self.svd_flip(W, cv)
+        return W, pct.cpu().numpy(), yl.cpu().numpy()
+
+    def simpls_set_original_dev(self, W):
+        """simpls_set_original for a device tensor W (B, k): transposed and column-centred on the device."""
+        wT = self.transpose_dev(W)
+        self._check(self.lib.plsx_center_rows(self.ctx, wT.data_ptr(), wT.shape[0], wT.shape[1], wT.data_ptr(),
+                                              self._stream()))
+        self._check(self.lib.plsx_simpls_set_original(self.ctx, wT.data_ptr(), self._stream()))
+        self.sync()                                   # (wT is released on return)
 
     def simpls_set_original(self, x_weights):
         w0c = np.asarray(x_weights) - np.asarray(x_weights).mean(axis=0, keepdims=True)

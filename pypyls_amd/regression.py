@@ -25,6 +25,7 @@ Differences from the reference at this commit, on purpose:
 import numpy as np
 
 from . import hostmath, parallel, resampling
+from .plsc import _host_array
 from .structures import PLSInputs, PLSResults
 
 
@@ -221,17 +222,14 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     res = PLSResults(inputs=inputs)
     tick('h2d_and_bind')
 
-    W, pctvar, cvec, _ = eng.simpls_decompose()
-    # sign rule of compute.svd: on r (prop. to the x_weights column) when B > T,
-    # otherwise on c
-    lead = W if B > T else cvec
-    idx = np.argmax(np.abs(lead), axis=0)
-    signs = np.sign(lead[idx, np.arange(k)])
-    signs[signs == 0] = 1.0
-    W = W * signs
-    eng.simpls_set_original(W)
-    res['x_weights'] = W
-    x_scores = eng.project(W)                                      # X already centred
+    # the original fit: x_weights (B, k) stay on the device -- sign rule of compute.svd (on r, proportional to the
+    # x_weights column, when B > T, otherwise on c: plsx_svd_flip), centring for the sign alignment of the bootstraps,
+    # scores -- and come back once, into page-locked memory, while the device resamples
+    d_W, pctvar, _ = eng.simpls_decompose_dev()
+    eng.simpls_set_original_dev(d_W)
+    d_scores = eng.project_dev(d_W)                                # X already centred
+    h_W = eng.to_host_async(d_W)
+    x_scores = d_scores.cpu().numpy()
     x_scores[~okx] = np.nan                                        # NaN rows stay NaN (X @ W)
     res['x_scores'] = x_scores
     # emulate = (rank, world) of an emulated run on one GPU (bench.py --mode analysis --emulate-world): own shard, the
@@ -308,9 +306,13 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     y_scores = np.full((S, k), np.nan)
     y_scores[mask] = resid_yscores(x_scores[mask], Yc[mask] @ res['y_loadings'])
     res['y_scores'] = y_scores
+    res['x_weights'] = _host_array(h_W)
     if bootsamp is not None:
         # add the original back, n_boot + 1 (regression.py:409-415)
-        bsr, se = eng.boot_rel(W, usum, usq, bootsamp.shape[1] + 1, add_orig=True)
+        d_bsr, d_se = eng.boot_rel_dev(d_W, usum, usq, bootsamp.shape[1] + 1, add_orig=True)
+        h_bsr, h_se = eng.to_host_async(d_bsr), eng.to_host_async(d_se)
+        eng.sync()
+        bsr, se = _host_array(h_bsr), _host_array(h_se)
         res['bootres'].update(dict(
             x_weights_normed=bsr, x_weights_stderr=se, y_loadings=res['y_loadings'],
             y_loadings_boot=distrib,

@@ -201,3 +201,40 @@ def test_leading_eigenpair_solver_equals_jacobi_and_oracle(S, B, T, k, monkeypat
     sgn = np.sign(np.sum(fit['x_weights'] * a.x_weights, axis=0))
     assert_close(a.x_weights * sgn, fit['x_weights'], 1e-6, what='x_weights vs oracle')
     assert_close(a.varexp, fit['pctvar'][1], 1e-8, what='pctvar vs oracle')
+
+
+@pytest.mark.parametrize('S,B,T,k', [(60, 1200, 7, 5), (50, 6, 9, 4), (40, 9, 9, 3)])
+def test_original_fit_on_the_device_equals_host_rule(S, B, T, k):
+    """The regression front-end keeps the original fit on the device (round 5): plsx_svd_flip applies the sign rule of
+    compute.svd to data bound for regression (on the x_weights when B > T, else on the right vectors c;
+    pyls/types/regression.py:103, compute.py:43-50) and plsx_center_rows forms the column-centred weights of the sign
+    alignment.  Same x_weights as the host rule on the arrays plsx_simpls_decompose returns, for B > T, B < T and
+    B == T, and the same bootstrap sums whichever way the original was set."""
+    from pypyls_amd.engine import Engine
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(S + B)
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T) + 0.4 * X[:, :1]
+    Yc = Y - Y.mean(0)
+    boots = rsmp.gen_bootsamp([S], 1, 9, seed=3)
+    out = []
+    for dev_side in (False, True):
+        eng = Engine()
+        eng.set_data_regression(X, Yc, k)
+        if dev_side:
+            d_W, pct, yl = eng.simpls_decompose_dev()
+            eng.simpls_set_original_dev(d_W)
+            W = d_W.cpu().numpy()
+        else:
+            W, pct, cvec, yl = eng.simpls_decompose()
+            lead = W if B > T else cvec
+            idx = np.argmax(np.abs(lead), axis=0)
+            signs = np.sign(lead[idx, np.arange(k)])
+            signs[signs == 0] = 1.0
+            W = W * signs
+            eng.simpls_set_original(W)
+        usum, usq, ylb = eng.simpls_boot(boots)
+        out.append((W, usum.cpu().numpy(), usq.cpu().numpy(), np.asarray(ylb)))
+    assert np.array_equal(out[0][0], out[1][0])                   # signs only: bit for bit
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert_close(a, b, 1e-12, what='original set from the host vs on the device')

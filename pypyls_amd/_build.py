@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJDIR = os.path.join(CSRC, 'build')
 UNITS = ['plsx_smallql1', 'plsx_smallql2', 'plsx_gram', 'plsx_urot', 'plsx_xprod', 'plsx_small', 'plsx_compact',
          'plsx_simpls_api', 'plsx_split', 'plsx_core']                                   # (longest compile first)
-COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_symeig.h']
+COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_common.h', 'plsx_k_prep.h', 'plsx_k_xprod.h', 'plsx_k_gram.h',
+          'plsx_k_small.h', 'plsx_k_urot.h', 'plsx_k_misc.h', 'plsx_k_finish.h', 'plsx_symeig.h']
 EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_smallql1': ['plsx_smallql.h'], 'plsx_smallql2': ['plsx_smallql.h'],
           'plsx_simpls_api': ['plsx_simpls.h'], 'plsx_split': ['plsx_splitfused.h']}
 PUBLIC = os.path.join(os.path.dirname(HERE), 'include', 'plsx.h')

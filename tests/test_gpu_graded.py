@@ -20,7 +20,7 @@ oracle.live_lvs) are excluded, and only in the exactly-collinear cases.
 
 Round 4: above d_1 / d_L ~ 1.7e5 the plain Gram-side solve (eps (d_1/d_k)^2) leaves the
 tolerance; resamples with a live LV below 1e-3 d_1 are re-solved on R itself
-(plsx_kernels.h: SmallArgs::phase, k_refine_gram), and data whose original spectrum is
+(plsx_k_small.h: SmallArgs::phase, k_refine_gram), and data whose original spectrum is
 graded leaves the dual-space routes.  The cases above 1e3 assert that the refinement ran
 (Engine.numeric_report) and that nothing graded stayed unrefined; ``no_refine`` shows the
 law it removes.

@@ -789,7 +789,9 @@ def run_analysis(args, world=1, rank=0, dev=None, backend='nccl'):
                'worlds': {str(n): row for n, row in table.items()}}}
     if multi:
         out.pop('end_to_end_emulation')
-        out['config']['collective'] = '{} all_gather_into_tensor over {} ranks, 1 per analysis (the front-end\'s own)'.format(backend, world)
+        from pypyls_amd import parallel
+        out['config']['collective'] = '{} over {} ranks, 1 per analysis (the front-end\'s own)'.format(
+            parallel.collective_name(), world)
     pls.release_default_engine()
     return out if rank == 0 else None
 
@@ -890,8 +892,7 @@ def measure(args, wl, env):
     value = units * args.steps / elapsed
     ms_step = 1e3 * elapsed / args.steps
     cfgd = {'workload': '{} (BASELINE config {}) on {} GPU(s)'.format(wl.describe(world), wl.name, world),
-            'mode': args.mode, 'collective': '{} all_gather_into_tensor, 1 per step, world {}'.format(
-                collective, world),
+            'mode': args.mode, 'collective': '{}, 1 per step, world {}'.format(collective, world),
             'parallelism': 'resample-sharded x{}'.format(world),
             'kernel_ms_per_step': {k: v[0] / args.steps for k, v in kt.items()}}
     if isinstance(wl, (PLSC, Simpls)):
@@ -1088,6 +1089,9 @@ def main():
             raise
         collective = 'none (process group init failed: {})'.format(str(exc)[:120])
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if dist.is_initialized():
+        from pypyls_amd import parallel
+        collective = parallel.collective_name()           # opens the communicator behind plsx_allgather (collective call)
     env = {'world': world, 'rank': rank, 'dev': dev, 'backend': backend, 'collective': collective}
 
     if args.mode == 'analysis':
@@ -1105,6 +1109,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():
         dist.barrier()
+        from pypyls_amd import parallel
+        parallel.release_native_comm()
         dist.destroy_process_group()
 
 

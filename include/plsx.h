@@ -417,6 +417,36 @@ int plsx_gen_splits(const int* groups, int n_groups, int n_cond, int n_split, do
 int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_split, double test_size,
                            const uint32_t* seeds, int n_seeds, uint8_t* out);
 
+/*
+ * The collective of the sharded resampling loops: what the
+ * reference does with joblib's gather of the per-resample results
+ * (pyls/base.py:490-507, 644-650; pyls/utils.py:252-279) is, with one process
+ * per GPU, ONE all-gather of a packed per-rank buffer
+ *     [ perm_singval slice | distrib slice | partial sum U | partial sum U^2 ].
+ * The communicator is RCCL (xGMI inside a node), reached through dlopen: the
+ * library does not link a communication runtime.  plsx_comm_load names the
+ * librccl.so to use -- a host that already carries one (PyTorch-ROCm bundles
+ * its own) passes that path so the process keeps a single copy; with NULL
+ * the copy already loaded in the process is taken, else "librccl.so.1" /
+ * "librccl.so" from the loader path, else /opt/rocm/lib/librccl.so.
+ *   plsx_comm_unique_id  rank 0 only: 128 bytes to hand to every rank through
+ *                        the launcher's own rendezvous (store, file, MPI ...)
+ *   plsx_comm_init       collective over the `world` ranks: one rank per GPU,
+ *                        binds the communicator to the context's device
+ *   plsx_allgather       d_recv[r * bytes_per_rank ...] = rank r's d_send, on
+ *                        `stream`, asynchronous like every other entry;
+ *                        d_send may alias its own slot of d_recv (in place)
+ *   plsx_comm_destroy    also called by plsx_ctx_destroy
+ * Without plsx_comm_init a context is a world of one and plsx_allgather is a
+ * device-to-device copy.
+ */
+int plsx_comm_load(plsx_ctx* ctx, const char* librccl_path);
+int plsx_comm_unique_id(plsx_ctx* ctx, void* id128);
+int plsx_comm_init(plsx_ctx* ctx, const void* id128, int rank, int world);
+int plsx_comm_rank(const plsx_ctx* ctx, int* rank, int* world);
+int plsx_allgather(plsx_ctx* ctx, const void* d_send, void* d_recv, long long bytes_per_rank, void* stream);
+int plsx_comm_destroy(plsx_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

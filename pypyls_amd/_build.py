@@ -1,6 +1,6 @@
 """Build libplsx.so (hipcc, gfx950 only) in-tree next to this file.
 
-The library is ten translation units (csrc/plsx_internal.h has the map), compiled in parallel into
+The library is eleven translation units (csrc/plsx_internal.h has the map), compiled in parallel into
 csrc/build/*.o and linked; a unit is recompiled when it or a header it includes is newer than its object."""
 import os
 import shutil
@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJDIR = os.path.join(CSRC, 'build')
 UNITS = ['plsx_smallql1', 'plsx_smallql2', 'plsx_gram', 'plsx_urot', 'plsx_xprod', 'plsx_small', 'plsx_compact',
-         'plsx_simpls_api', 'plsx_split', 'plsx_core']                                   # (longest compile first)
+         'plsx_simpls_api', 'plsx_split', 'plsx_core', 'plsx_comm']                                   # (longest compile first)
 COMMON = ['plsx_internal.h', 'plsx_kernels.h', 'plsx_common.h', 'plsx_k_prep.h', 'plsx_k_xprod.h', 'plsx_k_gram.h',
           'plsx_k_small.h', 'plsx_k_urot.h', 'plsx_k_misc.h', 'plsx_k_finish.h', 'plsx_symeig.h']
 EXTRA = {'plsx_core': ['plsx_resample.h'], 'plsx_smallql1': ['plsx_smallql.h'], 'plsx_smallql2': ['plsx_smallql.h'],
@@ -70,7 +70,7 @@ def build(force=False, verbose=False):
             print(hipcc, ' '.join(FLAGS), '-c  x', len(todo))
         with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
             list(ex.map(compile_unit, todo))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread'] + [_obj(u) for u in UNITS] + ['-o', LIB]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread'] + [_obj(u) for u in UNITS] + ['-ldl', '-o', LIB]
     subprocess.run(cmd, check=True)
     if verbose:
         print('  linked %s in %.1f s total' % (LIB, time.time() - t0))

@@ -351,6 +351,7 @@ try {
     if (!ctx) return PLSX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    (void)plsx_comm_destroy(ctx);
     for (Buf* b : {&ctx->Xc, &ctx->xmean, &ctx->Y, &ctx->cell_of_row, &ctx->cell_start, &ctx->cell_len,
                    &ctx->out_row, &ctx->mom_idx, &ctx->mom_n, &ctx->Afrag, &ctx->R, &ctx->Gm, &ctx->Pm,
                    &ctx->part, &ctx->Mfrag, &ctx->U0T, &ctx->V0, &ctx->d0, &ctx->tmpW,

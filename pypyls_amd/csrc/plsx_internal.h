@@ -10,6 +10,7 @@
 //   plsx_urot.hip        k_urot, k_ucorr_partial
 //   plsx_split.hip       split-half and cross-validation
 //   plsx_simpls_api.hip  SIMPLS regression
+//   plsx_comm.hip        the exported collective (RCCL through dlopen)
 #pragma once
 #include "plsx_kernels.h"
 #include <chrono>
@@ -127,6 +128,9 @@ struct plsx_ctx {
                           // resamples covered by the timed launches
     double last_ms = 0.0;
     int last_launches = 0;
+    // the exported collective (plsx_comm.hip): an RCCL communicator of one rank per GPU, reached through dlopen
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
 };
 
 namespace plsxi {

@@ -94,6 +94,12 @@ def _load():
         'plsx_gen_bootsamp_stream': ([vp, i32, i32, i32, vp, ctypes.POINTER(i32), vp, ctypes.POINTER(i32)], i32),
         'plsx_gen_splits': ([vp, i32, i32, i32, c_d, vp, ctypes.POINTER(i32), vp], i32),
         'plsx_gen_splits_seeded': ([vp, i32, i32, i32, c_d, vp, i32, vp], i32),
+        'plsx_comm_load': ([vp, ctypes.c_char_p], i32),
+        'plsx_comm_unique_id': ([vp, vp], i32),
+        'plsx_comm_init': ([vp, vp, i32, i32], i32),
+        'plsx_comm_rank': ([vp, ctypes.POINTER(i32), ctypes.POINTER(i32)], i32),
+        'plsx_allgather': ([vp, vp, vp, ctypes.c_longlong, vp], i32),
+        'plsx_comm_destroy': ([vp], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -116,7 +122,9 @@ def exported_symbols():
              'plsx_simpls_boot_batch', 'plsx_simpls_set_row_masks', 'plsx_gen_permsamp', 'plsx_gen_bootsamp',
              'plsx_gen_splits', 'plsx_gen_splits_seeded', 'plsx_gen_permsamp_stream',
              'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report',
-             'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_center_rows', 'plsx_mean_splits']
+             'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_center_rows', 'plsx_mean_splits',
+             'plsx_comm_load', 'plsx_comm_unique_id', 'plsx_comm_init', 'plsx_comm_rank', 'plsx_allgather',
+             'plsx_comm_destroy']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -258,6 +266,51 @@ class Engine(object):
 
     def sync(self):
         self._check(self.lib.plsx_sync(self.ctx))
+
+    # -- the exported collective (include/plsx.h, "The collective") ---------
+    def comm_load(self, path=None):
+        """Bind the RCCL entry points.  Default: the librccl.so PyTorch-ROCm bundles (the copy this process
+        already holds when a ``nccl`` process group exists), so that the process keeps ONE communication
+        runtime."""
+        if path is None:
+            torch = _torch()
+            cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            path = cand if os.path.exists(cand) else None
+        self._check(self.lib.plsx_comm_load(self.ctx, path.encode() if path else None))
+
+    def comm_unique_id(self):
+        """128 bytes for :meth:`comm_init` (rank 0 draws them, every rank receives them through the launcher's
+        own rendezvous)."""
+        buf = ctypes.create_string_buffer(128)
+        self._check(self.lib.plsx_comm_unique_id(self.ctx, buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, uid, rank, world):
+        """Collective over ``world`` ranks, one per GPU (ncclCommInitRank behind the C ABI)."""
+        if len(uid) != 128:
+            raise PlsxError('comm_init: the unique id is 128 bytes')
+        self._check(self.lib.plsx_comm_init(self.ctx, ctypes.c_char_p(bytes(uid)), int(rank), int(world)))
+
+    def comm_rank_world(self):
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.plsx_comm_rank(self.ctx, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
+    def comm_destroy(self):
+        self._check(self.lib.plsx_comm_destroy(self.ctx))
+
+    def allgather_into(self, send, recv):
+        """recv (world, n) <- every rank's send (n,), on the current stream (plsx_allgather); contiguous device
+        tensors of one dtype.  ``send`` may be ``recv[rank]``."""
+        if not (send.is_contiguous() and recv.is_contiguous()) or send.dtype != recv.dtype:
+            raise PlsxError('allgather_into: contiguous tensors of one dtype')
+        nbytes = send.numel() * send.element_size()
+        world = self.comm_rank_world()[1]
+        if recv.numel() * recv.element_size() != nbytes * world:
+            raise PlsxError('allgather_into: recv holds {} bytes, world {} x {} expected'.format(
+                recv.numel() * recv.element_size(), world, nbytes))
+        self._check(self.lib.plsx_allgather(self.ctx, send.data_ptr(), recv.data_ptr(), nbytes, self._stream()))
+        return recv
 
     def numeric_report(self, warn=True):
         """(refined, unrefined) resample counts of graded spectra since the last call

@@ -12,13 +12,15 @@ collective: an all-gather of a packed per-rank buffer
 after which every rank puts the slices back into global order and adds the
 partial sums in rank order (fixed order -> deterministic).
 
-The collective deliberately lives HERE, on ``torch.distributed``, and not in
-the C ABI: one process per GPU needs a rendezvous (unique-id exchange) that the
-host launcher already provides through the process group, and PyTorch-ROCm
-bundles its own RCCL -- a second RCCL linked into libplsx.so would be a second
-copy of the runtime in the same process.  libplsx.so therefore stays free of
-any communication library; the packed buffer it fills is handed to
-``all_gather_into_tensor`` by its device pointer.
+Where the collective runs.  The rendezvous -- who the ranks are -- is the host launcher's
+(``torch.distributed``: torchrun's env and store).  The DATA collective itself is the C ABI's
+``plsx_allgather`` (include/plsx.h): an RCCL communicator of one rank per GPU opened by
+``plsx_comm_init`` from a 128-byte unique id that rank 0 draws and the process group broadcasts
+once per process (:func:`native_comm`).  libplsx.so binds RCCL with dlopen and is told to use
+the copy PyTorch-ROCm already loaded, so the process keeps ONE communication runtime.  When the
+communicator cannot be opened on every rank (no librccl, init failure) all ranks fall back
+TOGETHER to ``all_gather_into_tensor`` of the process group -- still RCCL, never the CPU -- and
+:func:`collective_name` says which of the two ran.  ``gloo`` groups (CPU tests) never touch it.
 """
 import numpy as np
 
@@ -38,6 +40,102 @@ def rank_world():
     if d is None:
         return 0, 1
     return d.get_rank(), d.get_world_size()
+
+
+# the communicator behind plsx_allgather: one per process, on its own small context (no data is ever bound to it,
+# so it costs no device memory and is independent of which Engine an analysis uses)
+_NATIVE = {'state': None, 'engine': None, 'why': '', 'group': None}     # state: None = not tried, True = open, False = fall back
+USE_NATIVE_COLLECTIVE = True
+
+
+def native_comm():
+    """The Engine whose context holds the RCCL communicator of this process group, or None (fall back to the
+    process group's own all-gather).  First call under an initialised ``nccl`` group is COLLECTIVE: every rank
+    binds librccl, rank 0 draws the unique id, the group broadcasts it, every rank calls ``plsx_comm_init``;
+    the outcome is agreed by an all-reduce so that either every rank uses ``plsx_allgather`` or none does."""
+    d = _dist()
+    if d is None or d.get_backend() != 'nccl' or not USE_NATIVE_COLLECTIVE:
+        return None
+    group = d.group.WORLD
+    if _NATIVE['state'] is not None and _NATIVE['group'] is group:
+        return _NATIVE['engine'] if _NATIVE['state'] else None
+    if _NATIVE['state'] is not None:                    # a communicator of an earlier process group
+        release_native_comm()
+    import torch
+    from . import engine as _engine
+    rank, world = d.get_rank(), d.get_world_size()
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def agreed(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        return bool(flag.item())
+
+    eng, why = None, ''
+    try:
+        eng = _engine.Engine(dev.index)
+        eng.comm_load()
+    except Exception as exc:                            # noqa: BLE001 -- any failure means "fall back", on all ranks
+        why = 'bind: ' + str(exc)[:200]
+    ok = agreed(not why)
+    if ok:
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = eng.comm_unique_id()
+            except Exception as exc:                    # noqa: BLE001
+                why = 'unique id: ' + str(exc)[:200]
+        d.broadcast_object_list(box, src=0)
+        ok = box[0] is not None
+        if ok:
+            try:
+                eng.comm_init(box[0], rank, world)
+            except Exception as exc:                    # noqa: BLE001
+                why = 'init: ' + str(exc)[:200]
+            ok = agreed(not why)
+    if ok:                                              # prove the rank order before anything depends on it
+        try:
+            mine = torch.full((2,), float(rank), dtype=torch.float64, device=dev)
+            got = torch.empty((world, 2), dtype=torch.float64, device=dev)
+            eng.allgather_into(mine, got)
+            torch.cuda.synchronize(dev)
+            good = bool((got[:, 0].cpu() == torch.arange(world, dtype=torch.float64)).all())
+            if not good:
+                why = 'probe all-gather returned the wrong rank order'
+        except Exception as exc:                        # noqa: BLE001
+            good, why = False, 'probe: ' + str(exc)[:200]
+        ok = agreed(good)
+    if not ok:
+        if eng is not None:
+            try:
+                eng.close()
+            except Exception:                           # noqa: BLE001
+                pass
+        eng = None
+        if rank == 0:
+            import warnings
+            warnings.warn('plsx_allgather unavailable ({}): the collective falls back to the process group\'s '
+                          'all_gather_into_tensor (RCCL all the same)'.format(why or 'a peer rank failed'))
+    _NATIVE.update(state=bool(ok), engine=eng, why=why, group=group)
+    return eng
+
+
+def release_native_comm():
+    """Destroy the communicator (call before ``destroy_process_group``; every rank)."""
+    eng = _NATIVE['engine']
+    _NATIVE.update(state=None, engine=None, why='', group=None)
+    if eng is not None:
+        eng.close()
+
+
+def collective_name():
+    """Which all-gather :func:`gather_device` issues under the current process group."""
+    d = _dist()
+    if d is None:
+        return 'none (no process group)'
+    if d.get_backend() == 'nccl' and native_comm() is not None:
+        return 'plsx_allgather (RCCL ncclAllGather behind the C ABI)'
+    return '{} all_gather_into_tensor (torch.distributed)'.format(d.get_backend())
 
 
 def shared_seed(seed):
@@ -125,7 +223,7 @@ def gather_device(slices, sums, device=None):
     the caller drops the padding rows with shard_bounds -- and summed[i] the
     rank-ordered sum.  With no process group (or world 1 on gloo) nothing moves.
     Everything is packed into ONE flat fp64 buffer so that exactly one
-    all_gather_into_tensor is issued (RCCL when the backend is nccl)."""
+    all-gather is issued (plsx_allgather = RCCL behind the C ABI when the backend is nccl)."""
     import torch
     d = _dist()
     if d is None:
@@ -146,7 +244,12 @@ def gather_device(slices, sums, device=None):
     flat = torch.cat([p.to(device=device, dtype=torch.float64) for p in pieces]) if pieces else \
         torch.zeros(0, dtype=torch.float64, device=device)
     gathered = torch.empty((world, flat.numel()), dtype=torch.float64, device=device)
-    d.all_gather_into_tensor(gathered.view(-1), flat)
+    comm = native_comm() if (on_gpu and flat.is_cuda) else None
+    if comm is not None:
+        with torch.cuda.device(flat.device):
+            comm.allgather_into(flat, gathered)         # plsx_allgather on the current stream of the data
+    else:
+        d.all_gather_into_tensor(gathered.view(-1), flat)
     out_g, out_s, off = [], [], 0
     for i, shp in enumerate(shapes):
         n = int(np.prod(shp)) if len(shp) else 1

@@ -99,10 +99,22 @@ dist.init_process_group('nccl', rank=rank, world_size=world,
                         device_id=torch.device('cuda', torch.cuda.current_device()))
 assert dist.get_backend() == 'nccl'
 import pypyls_amd as pls
+from pypyls_amd import parallel
+# the data collective is the C ABI's plsx_allgather on a communicator opened by plsx_comm_init ...
+name = parallel.collective_name()
+assert name.startswith('plsx_allgather'), (name, parallel._NATIVE['why'])
+assert parallel.native_comm().comm_rank_world() == (rank, world)
 rs = np.random.RandomState(0)
 X = rs.randn(40, 300); Y = rs.randn(40, 5) + 0.4 * X[:, :5]
 res = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=4, seed=7, verbose=False)
 rr = pls.pls_regression(X, Y, n_components=3, n_perm=6, n_boot=5, seed=5, verbose=False)
+# ... and the process group's own all-gather (the fall-back) returns the same bits
+parallel.release_native_comm()
+parallel.USE_NATIVE_COLLECTIVE = False
+assert parallel.collective_name().startswith('nccl all_gather_into_tensor')
+res2 = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=4, seed=7, verbose=False)
+assert np.array_equal(res2.permres.perm_singval, res.permres.perm_singval)
+assert np.array_equal(res2.bootres.x_weights_normed, res.bootres.x_weights_normed)
 if rank == 0:
     np.savez({out!r}, perm=res.permres.perm_singval, bsr=res.bootres.x_weights_normed,
              ylb=res.bootres.y_loadings_boot, uc=res.splitres.ucorr_pvals, cv=res.cvres.pearson_r,
@@ -110,6 +122,46 @@ if rank == 0:
 dist.barrier()
 dist.destroy_process_group()
 '''
+
+
+def test_exported_allgather_world_of_one():
+    """plsx_allgather / plsx_comm_* through ctypes (include/plsx.h, "The collective"): without a communicator a
+    context is a world of one (device copy); with one opened by plsx_comm_init(id, 0, 1) the gather runs through
+    RCCL's ncclAllGather, in place and out of place, fp64 and odd byte counts; a second init is refused."""
+    import torch
+    from pypyls_amd import engine
+    eng = engine.Engine()
+    try:
+        a = torch.arange(1000, dtype=torch.float64, device=eng.device) * 0.5
+        out = torch.zeros((1, 1000), dtype=torch.float64, device=eng.device)
+        assert eng.comm_rank_world() == (0, 1)
+        eng.allgather_into(a, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], a)
+        eng.comm_load()
+        uid = eng.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        eng.comm_init(uid, 0, 1)
+        assert eng.comm_rank_world() == (0, 1)
+        out.zero_()
+        eng.allgather_into(a, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], a)
+        eng.allgather_into(out[0], out)                 # in place
+        b = torch.arange(13, dtype=torch.uint8, device=eng.device)
+        ob = torch.zeros((1, 13), dtype=torch.uint8, device=eng.device)
+        eng.allgather_into(b, ob)                       # 13 bytes: travels as bytes
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], a) and torch.equal(ob[0], b)
+        with pytest.raises(engine.PlsxError):
+            eng.comm_init(uid, 0, 1)
+        with pytest.raises(engine.PlsxError):
+            eng.allgather_into(a, torch.zeros((2, 1000), dtype=torch.float64, device=eng.device))
+        eng.comm_destroy()
+        assert eng.comm_rank_world() == (0, 1)
+    finally:
+        eng.close()
+
 
 
 def _run_nccl(tmp_path, world, port):

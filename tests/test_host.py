@@ -250,7 +250,7 @@ def test_every_c_abi_entry_is_guarded_and_reads_no_environment():
     header = open(os.path.join(ROOT, 'include', 'plsx.h')).read()
     declared = set(re.findall(r'\b(plsx_\w+)\s*\(', header))
     trivial = {'plsx_version', 'plsx_max_tprime', 'plsx_last_error', 'plsx_num_lv', 'plsx_tprime',
-               'plsx_kernel_class_name', 'plsx_option_name', 'plsx_boot_route', 'plsx_split_route'}
+               'plsx_kernel_class_name', 'plsx_option_name', 'plsx_boot_route', 'plsx_split_route', 'plsx_comm_rank'}
     defined, unguarded = set(), []
     for i, ln in enumerate(lines):
         m = re.match(r'^(?:int|const char\*) (plsx_\w+)\(', ln)

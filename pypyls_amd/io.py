@@ -5,9 +5,11 @@ HDF5 persistence of :class:`~pypyls_amd.structures.PLSResults` in the layout of
 else as group attributes (``None`` stored as the string 'None'), so files are
 interchangeable with the reference's tooling.
 
-Needs ``h5py``, which this build's image does not ship: without it both
-functions raise ImportError (status "blocked: h5py absent", DESIGN.md section
-0); the round-trip test is skipped in that case.
+Backend: ``h5py`` when it is installed; otherwise the HDF5 C library itself through
+ctypes (:mod:`pypyls_amd._h5lite`: the same calls with h5py's on-disk conventions --
+this build's image ships libhdf5 but no h5py for its interpreter).  With neither, both
+functions raise ImportError.  tests/test_io.py pins the on-disk format both ways against
+files written / read by the reference's own ``pyls.save_results`` / ``load_results``.
 """
 import numpy as np
 
@@ -17,10 +19,16 @@ from .structures import PLSResults
 def _h5py():
     try:
         import h5py
-    except ImportError as exc:                           # pragma: no cover
-        raise ImportError('save_results / load_results need the h5py package, which is not '
-                          'installed') from exc
-    return h5py
+        return h5py
+    except ImportError:
+        pass
+    try:
+        from . import _h5lite
+        _h5lite.lib()
+        return _h5lite
+    except ImportError as exc:
+        raise ImportError('save_results / load_results need h5py or an HDF5 C library (libhdf5.so); '
+                          'neither was found: {}'.format(exc)) from exc
 
 
 def _with_suffix(fname):

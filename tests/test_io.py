@@ -1,6 +1,7 @@
 """save_results / load_results (pyls/io.py:12-122) against an in-memory stand-in for
-h5py -- the image ships no h5py, so the ON-DISK format stays "blocked: h5py absent";
-what runs here is the traversal: layout, None handling, nested records, suffix rule."""
+h5py: the traversal -- layout, None handling, nested records, suffix rule.  The ON-DISK
+format (HDF5 through libhdf5, interchange with the reference's own files) is
+tests/test_io_disk.py."""
 import sys
 import types
 
@@ -113,9 +114,14 @@ def test_not_hdf5_rejected(fake_h5py):
         io.load_results('never_written')                    # io.py:116-118
 
 
-def test_without_h5py_both_raise(monkeypatch):
-    from pypyls_amd import io
+def test_without_h5py_and_without_libhdf5_both_raise(monkeypatch):
+    from pypyls_amd import io, _h5lite
     monkeypatch.setitem(sys.modules, 'h5py', None)
+
+    def no_lib():
+        raise ImportError('no HDF5 C library found (test)')
+    monkeypatch.setattr(_h5lite, '_LIB', None)
+    monkeypatch.setattr(_h5lite, '_find', no_lib)
     with pytest.raises(ImportError):
         io.save_results('x', _results())
     with pytest.raises(ImportError):

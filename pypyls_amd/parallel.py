@@ -117,6 +117,10 @@ def native_comm():
             warnings.warn('plsx_allgather unavailable ({}): the collective falls back to the process group\'s '
                           'all_gather_into_tensor (RCCL all the same)'.format(why or 'a peer rank failed'))
     _NATIVE.update(state=bool(ok), engine=eng, why=why, group=group)
+    if ok and not _NATIVE.get('atexit'):
+        import atexit
+        atexit.register(release_native_comm)            # before the interpreter tears torch / HIP down
+        _NATIVE['atexit'] = True
     return eng
 
 
@@ -125,7 +129,10 @@ def release_native_comm():
     eng = _NATIVE['engine']
     _NATIVE.update(state=None, engine=None, why='', group=None)
     if eng is not None:
-        eng.close()
+        try:
+            eng.close()
+        except Exception:                               # noqa: BLE001 -- at exit the device may be gone already
+            pass
 
 
 def collective_name():

@@ -189,7 +189,13 @@ __device__ unsigned long long g_sd_probe[16][32];
 #define SD_MARK(n) do {} while (0)
 #endif
 
-#define SD_RC 16
+// SD_RC is the template parameter RC of the three kernels below: 16 for batches the chip holds at once (one or two
+// waves per SIMD: a wave's own loads in flight are all the latency hiding there is), 8 for larger ones (round 5: three
+// waves per SIMD -- what the [S] scatter buffer in LDS allows -- finish 5000 resamples in 2 rounds instead of 3 and
+// overlap one wave's eigen-solve with another's passes over S: k_sd_step 0.90 -> 0.83, k_sd_post0 1.41 -> 0.97,
+// k_sd_final 2.03 -> 1.11 ms per 5000).  The register budget follows: waves_per_eu(1, 2) / (3, 4).
+#define SD_RC RC
+#define SD_WPE (RC >= 16 ? 1 : 3), (RC >= 16 ? 2 : 4)
 #define SD_TILE (64 * SD_RC)
 #define SD_OWN(i) _Pragma("unroll") for (int i = 0; i < SD_RC; ++i)
 // positions of the tile at p0 owned by this lane, clamped into [0, S): 32-bit offsets against
@@ -254,7 +260,8 @@ __device__ __forceinline__ void sd_gram_h(const double* Y0, const double* Z0, in
 }
 
 // After GEMM 0: Z0 = Jc gather(K scatter(Y0)), kcpos, H = H0 = Y0^T Z0.
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+template <int RC, int TC>       // TC as in k_sd_step: the 64 x 64 accumulators of T <= 64 are not allocated for T <= 32
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SD_WPE)))
 void k_sd_post0(SdArgs a)
 {
     const int S = a.S, T = a.T, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar pointers
@@ -306,10 +313,10 @@ void k_sd_post0(SdArgs a)
     double* H0 = a.H0 + (size_t)r * T * T;
     wave_sync();
     __threadfence_block();
-    if (T <= 16) sd_gram_h<1>(Y0, Z0, S, T, lane, H, H0);
-    else if (T <= 32) sd_gram_h<2>(Y0, Z0, S, T, lane, H, H0);
-    else if (T <= 48) sd_gram_h<3>(Y0, Z0, S, T, lane, H, H0);
-    else if (T <= 64) sd_gram_h<4>(Y0, Z0, S, T, lane, H, H0);
+    if (TC == 0 && T <= 16) sd_gram_h<1>(Y0, Z0, S, T, lane, H, H0);
+    else if (TC == 0 && T <= 32) sd_gram_h<2>(Y0, Z0, S, T, lane, H, H0);
+    else if (TC == 1 && T <= 48) sd_gram_h<3>(Y0, Z0, S, T, lane, H, H0);
+    else if (TC == 1 && T <= 64) sd_gram_h<4>(Y0, Z0, S, T, lane, H, H0);
     else {
         for (int t1 = 0; t1 < T; ++t1)
             for (int t2 = 0; t2 < T; t2 += 4) {
@@ -632,7 +639,12 @@ __device__ double wave_top_eig(double* A, int n, int ld, int lane, double* ws, d
 
 // Component step c (see the header): closes component c - 1 when c > 0, opens component c
 // unless c == k.  dynamic LDS: sd_step_lds(S, T, k) doubles per wave.
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+// TC: class of T the instantiation serves (0: T <= 32, 1: T <= 64, 2: any) -- the register allocation of a kernel is
+// the maximum over its paths, and the Jacobi fall-back for large T (36 rows of two columns per lane) would otherwise
+// set it for every T.  JAC: the leading eigenpair by the full one-sided Jacobi solve (T > 64, T > S, or the
+// `simpls_jacobi` option) instead of wave_top_eig.
+template <int TC, bool JAC, int RC>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SD_WPE)))
 void k_sd_step(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
@@ -772,7 +784,7 @@ void k_sd_step(SdArgs a)
     wave_sync();
     SD_MARK(4);
     double lam;
-    if (!a.jacobi_eig && T <= 64 && T <= S) {
+    if constexpr (!JAC) {
         // the leading eigenpair alone (Householder + multisection + inverse iteration); the [S] scatter buffer,
         // idle until the end of the launch, is its workspace
         lam = wave_top_eig(Hw, T, ldh, lane, buf, cv);
@@ -780,8 +792,8 @@ void k_sd_step(SdArgs a)
         for (int t = lane; t < T; t += 64) a.cvec[((size_t)r * T + t) * k + c] = cv[t];
     } else {
         // rows per lane of a column (4 lanes per pair): 8 covers T <= 32, 36 the LDS limit of T
-        if (T <= 32) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
-        else if (T <= 64) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
+        if constexpr (TC == 0) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
+        else if constexpr (TC == 1) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
         else wave_jacobi_cols<36>(Hw, T, T, ldh, lane, 1e-15);
         SD_MARK(5);
         for (int col = lane; col < T; col += 64) {
@@ -1000,7 +1012,8 @@ void k_sd_step(SdArgs a)
 // accumulate the aligned weights directly (k_xprod EPI = 2) instead of writing them, forming
 // their cross-Gram with the original and reading them back for the sign and the sums.
 // dynamic LDS: k (+ S with a.Vd) doubles per wave.
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+template <int RC, int TC>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SD_WPE)))
 void k_sd_final(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];
@@ -1070,11 +1083,11 @@ void k_sd_final(SdArgs a)
                     if (t < T && c < k) a.yload[((size_t)r * T + t) * k + c] = acc[mt][nt][i] * flip[c];          \
                 }                                                                                                  \
     }
-    if (tt == 1 && kt == 1) SD_YL(1, 1)
-    else if (tt == 2 && kt == 1) SD_YL(2, 1)
-    else if (tt <= 4 && kt == 1) SD_YL(4, 1)
-    else if (tt <= 2 && kt <= 2) SD_YL(2, 2)
-    else if (tt <= 4 && kt <= 4) SD_YL(4, 4)
+    if (TC == 0 && tt == 1 && kt == 1) SD_YL(1, 1)
+    else if (TC == 0 && tt == 2 && kt == 1) SD_YL(2, 1)
+    else if (TC == 1 && tt <= 4 && kt == 1) SD_YL(4, 1)
+    else if (TC == 0 && tt <= 2 && kt <= 2) SD_YL(2, 2)
+    else if (TC == 1 && tt <= 4 && kt <= 4) SD_YL(4, 4)
     else {
         for (int t = 0; t < T; ++t)
             for (int c0 = 0; c0 < k; c0 += 4) {

@@ -65,6 +65,7 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
     const size_t step_wave = sd_step_lds(S, T, k) * 8;
     const int wpb = (int)std::max<size_t>(1, std::min<size_t>(4, (72 * 1024) / step_wave));
     const dim3 grid(ceil_div(nres, wpb)), block(wpb * 64);
+    const bool big = nres > 2048;          // more waves than two per SIMD of the chip: the three-waves-per-SIMD variants (SD_RC)
     {
         const size_t lds = (size_t)wpb * S * 8;
         HIPCHK(set_lds(k_sd_init, lds));
@@ -78,16 +79,25 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         return e;
     {
         KTimer tm(ctx, KC_SIMPLS, st);
-        hipLaunchKernelGGL(k_sd_post0, grid, block, 0, st, a);
+        void (*post0_kernel)(SdArgs) =
+            T <= 32 ? (big ? k_sd_post0<8, 0> : k_sd_post0<16, 0>)
+                    : (T <= 64 ? (big ? k_sd_post0<8, 1> : k_sd_post0<16, 1>) : k_sd_post0<16, 2>);
+        hipLaunchKernelGGL(post0_kernel, grid, block, 0, st, a);
         LAUNCHCHK();
     }
     const size_t lds_step = (size_t)wpb * step_wave;
-    HIPCHK(set_lds(k_sd_step, lds_step));
+    const bool jac = a.jacobi_eig || T > 64 || T > S;
+    void (*step_kernel)(SdArgs) =
+        jac ? (T <= 32 ? (big ? k_sd_step<0, true, 8> : k_sd_step<0, true, 16>)
+                       : (T <= 64 ? (big ? k_sd_step<1, true, 8> : k_sd_step<1, true, 16>) : k_sd_step<2, true, 16>))
+            : (T <= 32 ? (big ? k_sd_step<0, false, 8> : k_sd_step<0, false, 16>)
+                       : (big ? k_sd_step<1, false, 8> : k_sd_step<1, false, 16>));
+    HIPCHK(set_lds(step_kernel, lds_step));
     for (int c = 0; c < k; ++c) {
         a.c = c;
         {
             KTimer tm(ctx, KC_SIMPLS, st);
-            hipLaunchKernelGGL(k_sd_step, grid, block, lds_step, st, a);
+            hipLaunchKernelGGL(step_kernel, grid, block, lds_step, st, a);
             LAUNCHCHK();
         }
         // GEMM c: K beta for every resample of the batch (the last component needs none)
@@ -100,8 +110,11 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         a.Qs = align_signs ? ptr<double>(ctx->Qs) : nullptr;
         KTimer tm(ctx, KC_SIMPLS, st);
         const size_t lds_f = (size_t)wpb * (k + S) * 8;       // (per wave: the signs and one subject-space scatter buffer)
-        HIPCHK(set_lds(k_sd_final, lds_f));
-        hipLaunchKernelGGL(k_sd_final, grid, block, lds_f, st, a);
+        void (*final_kernel)(SdArgs) =
+            T <= 32 ? (big ? k_sd_final<8, 0> : k_sd_final<16, 0>)
+                    : (T <= 64 ? (big ? k_sd_final<8, 1> : k_sd_final<16, 1>) : k_sd_final<16, 2>);
+        HIPCHK(set_lds(final_kernel, lds_f));
+        hipLaunchKernelGGL(final_kernel, grid, block, lds_f, st, a);
         LAUNCHCHK();
     }
 #ifdef PLSX_SD_PROBE

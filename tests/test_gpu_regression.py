@@ -238,3 +238,45 @@ def test_original_fit_on_the_device_equals_host_rule(S, B, T, k):
     assert np.array_equal(out[0][0], out[1][0])                   # signs only: bit for bit
     for a, b in zip(out[0][1:], out[1][1:]):
         assert_close(a, b, 1e-12, what='original set from the host vs on the device')
+
+
+@pytest.mark.parametrize('S,B,T,k', [(48, 70, 6, 4), (40, 33, 20, 5)])
+def test_large_batches_take_the_three_wave_solver(S, B, T, k):
+    """A solver batch of more than 2048 resamples runs the SD_RC = 8 instantiations of k_sd_post0 / k_sd_step /
+    k_sd_final (three waves per SIMD, csrc/plsx_simpls.h), a smaller one the SD_RC = 16 ones: ONE call of 2304
+    permutations / bootstraps against the same rows in two calls of 1152 (different summation order inside a wave:
+    1e-10, not bit-identical), and a sample of both against the oracle (regression.py:279-373)."""
+    from pypyls_amd.engine import Engine
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(S * T)
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T) + 0.4 * X[:, :1] + 0.2 * X[:, 1:2]
+    Xc, Yc = X - X.mean(0), Y - Y.mean(0)
+    n = 2304
+    perms = rsmp.gen_permsamp([S], 1, n, seed=5, verbose=False)
+    boots = rsmp.gen_bootsamp([S], 1, n, seed=6, verbose=False)
+    eng = Engine()
+    eng.set_data_regression(Xc, Yc, k)
+    W, pct, cvec, yl = eng.simpls_decompose()
+    lead = W if B > T else cvec
+    signs = np.sign(lead[np.argmax(np.abs(lead), axis=0), np.arange(k)])
+    signs[signs == 0] = 1.0
+    W = W * signs
+    eng.simpls_set_original(W)
+    big_p = np.asarray(eng.simpls_perm(perms))
+    small_p = np.concatenate([np.asarray(eng.simpls_perm(perms[:, :n // 2])),
+                              np.asarray(eng.simpls_perm(perms[:, n // 2:]))], axis=-1)
+    assert_close(big_p, small_p, 1e-10, what='perm pctvar: one batch of 2304 vs two of 1152')
+    us, uq, ylb = eng.simpls_boot(boots)
+    us1, uq1, ylb1 = eng.simpls_boot(boots[:, :n // 2])
+    us2, uq2, ylb2 = eng.simpls_boot(boots[:, n // 2:])
+    assert_close(us.cpu().numpy(), (us1 + us2).cpu().numpy(), 1e-9, what='bootstrap sum of weights')
+    assert_close(uq.cpu().numpy(), (uq1 + uq2).cpu().numpy(), 1e-9, what='bootstrap sum of squared weights')
+    assert_close(np.asarray(ylb), np.concatenate([np.asarray(ylb1), np.asarray(ylb2)], axis=-1), 1e-9,
+                 what='bootstrap y-loadings')
+    pick = [0, 1, 1151, 1152, 2047, 2048, 2303]
+    for i in pick:
+        want = ref.regression_single_perm(Xc, Yc, perms[:, i], k)
+        assert_close(big_p[:, i], want, 1e-8, what='permutation {} vs oracle'.format(i))
+        ylw, _ = ref.regression_single_boot(Xc, Yc, boots[:, i], k, W)
+        assert_close(np.asarray(ylb)[..., i], ylw, 1e-7, what='bootstrap {} y-loadings vs oracle'.format(i))

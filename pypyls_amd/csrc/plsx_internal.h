@@ -293,7 +293,12 @@ int run_xprod(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStre
               bool prebuilt = false, const double* ystack = nullptr, long long ystride = -1, bool sparse_rows = false);
 int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st);
 int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st);
-inline int quad_blocks(int tiles) { return std::max(ceil_div(tiles, 24), tiles >= 8 ? 2 : 1); }
+// Row blocks per LV of the closing pass of a bootstrap series (quad_finish): blocks of 8 tiles = 128 rows.  A block
+// multiplies its rows of the symmetric C_l against the columns from its own first row on, so the work issued beyond
+// the upper triangle is the lower halves of the diagonal blocks: 1.34 x the needed flop with 3 blocks of 21 tiles at
+// S = 1000, 1.13 x with 8 blocks of 8 -- measured at c5 32.5 -> 26.8 ms per series (blocks of 12 tiles 28.5, of 6
+// tiles 27.2, of 4 tiles 28.0, of 16 tiles 38.5: the time follows the issued work down to 8 tiles).
+inline int quad_blocks(int tiles) { return tiles >= 8 ? ceil_div(tiles, 8) : 1; }
 // ---- plsx_compact.hip ----
 int launch_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st);
 int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, bool raw = false);

@@ -483,8 +483,8 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
                            ctx->Bpad, S, B, ptr<double>(ctx->Vsumq), L, d_usum);
         LAUNCHCHK();
     }
-    // the S rows of a C_l in gpl blocks of MT tiles, as evenly as the instantiated block heights allow
-    // (at least two blocks once there are 8 tiles: the second one starts its contraction half way down)
+    // the S rows of a C_l in gpl blocks of MT tiles (quad_blocks: blocks of 8 tiles), as evenly as the instantiated
+    // block heights allow
     const int tiles = ceil_div(S, 16), gpl = quad_blocks(tiles);
     const int need = ceil_div(tiles, gpl);
     if (need <= 8) return quad_finish_t<8>(ctx, d_usq, ceil_div(tiles, 8), st);

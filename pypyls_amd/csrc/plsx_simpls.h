@@ -644,7 +644,7 @@ __device__ double wave_top_eig(double* A, int n, int ld, int lane, double* ws, d
 // set it for every T.  JAC: the leading eigenpair by the full one-sided Jacobi solve (T > 64, T > S, or the
 // `simpls_jacobi` option) instead of wave_top_eig.
 template <int TC, bool JAC, int RC>
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SD_WPE)))
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((JAC || RC >= 16) ? 1 : 3, JAC ? 1 : (RC >= 16 ? 2 : 4))))
 void k_sd_step(SdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm_sd[];

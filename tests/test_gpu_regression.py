@@ -280,3 +280,23 @@ def test_large_batches_take_the_three_wave_solver(S, B, T, k):
         assert_close(big_p[:, i], want, 1e-8, what='permutation {} vs oracle'.format(i))
         ylw, _ = ref.regression_single_boot(Xc, Yc, boots[:, i], k, W)
         assert_close(np.asarray(ylb)[..., i], ylw, 1e-7, what='bootstrap {} y-loadings vs oracle'.format(i))
+
+
+@pytest.mark.parametrize('S,B,T,k', [(90, 400, 40, 5), (120, 300, 64, 4), (110, 250, 70, 4), (50, 200, 56, 3), (24, 150, 30, 2),
+                                     (40, 120, 44, 3)])
+def test_wide_y_takes_the_solver_instantiations_of_its_class(S, B, T, k):
+    """The solver kernels are instantiated per class of T (csrc/plsx_simpls.h: T <= 32, T <= 64, larger; the
+    leading-eigenpair solver where T <= 64 and T <= S, the one-sided Jacobi solve otherwise): 32 < T <= 64, T > 64 and
+    T > S against the oracle's exact SIMPLS (regression.py:56-186, 279-373)."""
+    import pypyls_amd as pls
+    rs = np.random.RandomState(S + T)
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T)
+    Y[:, :8] += 0.5 * X[:, :8]
+    res = pls.pls_regression(X, Y, n_components=k, n_perm=12, n_boot=10, seed=21, verbose=False)
+    want = ref.run_regression(X, Y, k, permsamples=res.permres.permsamples, bootsamples=res.bootres.bootsamples)
+    for key in ('x_weights', 'x_scores', 'y_scores', 'y_loadings', 'varexp'):
+        assert_close(res[key], want[key], 1e-6, what='oracle ' + key)
+    assert_close(res['permres']['perm_singval'], want['permres']['perm_singval'], 1e-6, what='perm')
+    for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot'):
+        assert_close(res['bootres'][key], want['bootres'][key], 1e-5, what='oracle ' + key)

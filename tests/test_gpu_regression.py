@@ -240,7 +240,7 @@ def test_original_fit_on_the_device_equals_host_rule(S, B, T, k):
         assert_close(a, b, 1e-12, what='original set from the host vs on the device')
 
 
-@pytest.mark.parametrize('S,B,T,k', [(48, 70, 6, 4), (40, 33, 20, 5)])
+@pytest.mark.parametrize('S,B,T,k', [(48, 70, 6, 4), (40, 33, 20, 5), (70, 40, 40, 3)])
 def test_large_batches_take_the_three_wave_solver(S, B, T, k):
     """A solver batch of more than 2048 resamples runs the SD_RC = 8 instantiations of k_sd_post0 / k_sd_step /
     k_sd_final (three waves per SIMD, csrc/plsx_simpls.h), a smaller one the SD_RC = 16 ones: ONE call of 2304

@@ -3,7 +3,8 @@
 // c5 (M = 5000: one vector per resample and component; M = 105000: GEMM 0).  Timing only.
 // Measured (round 5, one MI355X): M = 5000: 37.4 (direct) / 45.0 (2 chunks) / 28.1 (64 x 64 blocks) / 30.0 TF/s (128 x 128);
 // M = 105000: 52.5 / 51.9 / 29.6 / 48.5 TF/s.  An XCD-aware walk of the blocks (the column tiles of one row block of A on one
-// XCD) changed nothing (52.4 TF/s): the products are not bound by the re-reads of A.
+// XCD) changed nothing (52.4 TF/s): the products are not bound by the re-reads of A.  Stages of 16 columns (half the LDS,
+// more resident blocks, k_nt16 below): 36.0 TF/s at M = 5000, 49.6 at M = 105000 -- not occupancy either.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pypyls_amd/csrc tools/nt_gemm_probe.hip -o tools/bin/nt_gemm_probe
 #include "plsx_kernels.h"
 #include <cstdio>
@@ -85,6 +86,85 @@ void k_nt_big(const double* __restrict__ A, int lda, int Ma, const double* __res
             }
 }
 
+
+// 128 x 64 output block like k_nt_gemm<2>, but stages of 16 columns (pitch 18: conflict-free b64 reads) instead of 32:
+// half the LDS per block (27.6 KB: five blocks per CU instead of three), twice the barriers per flop.
+#define KB16 16
+#define LD16 18
+__global__ __launch_bounds__(256)
+void k_nt16(const double* __restrict__ A, int lda, int Ma, const double* __restrict__ B, int ldb, int N, int K,
+            double* __restrict__ C, int ldc, int ntn)
+{
+    __shared__ __attribute__((aligned(16))) double sA[128 * LD16];
+    __shared__ __attribute__((aligned(16))) double sB[64 * LD16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    const int seg = tid & 7, rbase = tid >> 3;          // 8 double2 per 16-column row piece, 32 rows per pass
+    d4 acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[r][i] = (d4){0, 0, 0, 0};
+    d2 ra[4], rb[2];
+    auto fetch = [&](int kk) {
+        const int c = kk + seg * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r_ = tm * 128 + rbase + 32 * i;
+            d2 v = (d2){0, 0};
+            if (r_ < Ma) {
+                const double* p = A + (size_t)r_ * lda + c;
+                if (c + 1 < K) v = *reinterpret_cast<const d2*>(p);
+                else if (c < K) v = (d2){p[0], 0.0};
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r_ = tn * 64 + rbase + 32 * i;
+            d2 v = (d2){0, 0};
+            if (r_ < N) {
+                const double* p = B + (size_t)r_ * ldb + c;
+                if (c + 1 < K) v = *reinterpret_cast<const d2*>(p);
+                else if (c < K) v = (d2){p[0], 0.0};
+            }
+            rb[i] = v;
+        }
+    };
+    fetch(0);
+    for (int kk = 0; kk < K; kk += KB16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(&sA[(rbase + 32 * i) * LD16 + seg * 2]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<d2*>(&sB[(rbase + 32 * i) * LD16 + seg * 2]) = rb[i];
+        __syncthreads();
+        if (kk + KB16 < K) fetch(kk + KB16);
+#pragma unroll
+        for (int ks = 0; ks < KB16 / 4; ++ks) {
+            const int off = (lane & 15) * LD16 + ks * 4 + (lane >> 4);
+            double fa[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) fa[r] = sA[(wave * 2 + r) * 16 * LD16 + off];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const double fb = sB[nt * 16 * LD16 + off];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][nt] = mfma_f64(fa[r], fb, acc[r][nt]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = tm * 128 + (wave * 2 + r) * 16 + (lane >> 4) + 4 * i, n = tn * 64 + nt * 16 + (lane & 15);
+                if (m < Ma && n < N) C[(size_t)m * ldc + n] = acc[r][nt][i];
+            }
+}
+
 int main(int argc, char** argv)
 {
     const int S = argc > 1 ? atoi(argv[1]) : 1000;
@@ -100,7 +180,7 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int M : Ms) {
         const double flop = 2.0 * M * (double)S * S;
-        for (int variant = 0; variant < 4; ++variant) {
+        for (int variant = 0; variant < 5; ++variant) {
             NtArgs a; memset(&a, 0, sizeof(a));
             a.A = A; a.lda = S; a.Ma = M; a.B1 = K; a.ldb1 = S; a.N1 = S; a.K = S; a.batch = 1;
             a.mtiles = (M + 63) / 64; a.ntiles = (S + 63) / 64; a.part = part;
@@ -109,12 +189,13 @@ int main(int argc, char** argv)
             nchunk = (S + a.kchunk - 1) / a.kchunk;
             a.Cd = nchunk == 1 ? C : nullptr; a.ldcd = S;
             const char* name = variant == 0 ? "k_nt_gemm<2> direct       " : variant == 1 ? "k_nt_gemm<2> 2 chunks     " :
-                               variant == 2 ? "k_nt_gemm<1> direct       " : "k_nt_big 128x128          ";
+                               variant == 2 ? "k_nt_gemm<1> direct       " : variant == 3 ? "k_nt_big 128x128          " : "k_nt16 128x64, 16-col stage";
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CHECK(hipEventRecord(e0, 0));
                 if (variant <= 1) hipLaunchKernelGGL(k_nt_gemm<2>, dim3(nchunk, ((a.mtiles + 1) / 2) * a.ntiles, 1), dim3(256), 0, 0, a);
                 else if (variant == 2) hipLaunchKernelGGL(k_nt_gemm<1>, dim3(1, a.mtiles * a.ntiles, 1), dim3(256), 0, 0, a);
+                else if (variant == 4) { const int ntn = (S + 63) / 64; hipLaunchKernelGGL(k_nt16, dim3(((M + 127) / 128) * ntn), dim3(256), 0, 0, A, S, M, K, S, S, S, C, S, ntn); }
                 else { const int ntn = (S + 127) / 128; hipLaunchKernelGGL(k_nt_big, dim3(((M + 127) / 128) * ntn), dim3(256), 0, 0, A, S, M, K, S, S, S, C, S, ntn); }
                 CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -115,12 +115,15 @@ def self_launch(args):
 def quad_closing_work(S, mt, gpl):
     """Closing pass of a bootstrap series on the quadratic-form route (plsx_boot_finish): per latent variable and
     feature column the kernel multiplies gpl row blocks of mt tiles of C_l (S x S, symmetric), each from its own first
-    row on.  Returns (flop it NEEDS per LV and column = the upper triangle incl. the diagonal, 2 x S (S + 1) / 2;
+    row on, a tile of 16 rows inside the diagonal block from its own first row on.  Returns (flop it NEEDS per LV and column = the upper triangle incl. the diagonal, 2 x S (S + 1) / 2;
     flop it ISSUES per LV and column)."""
     issued = 0.0
     for p in range(gpl):
         s0 = p * mt * 16
-        issued += 2.0 * (mt * 16) * max(4 * ((S + 3) // 4) - s0, 0)
+        kp = max(4 * ((S + 3) // 4) - s0, 0)             # contraction length of the block
+        issued += 2.0 * (mt * 16) * kp
+        # inside its diagonal block tile m does not issue the 4 m k-steps left of its first row (128 flop each)
+        issued -= 128.0 * sum(min(4 * m, kp // 4) for m in range(mt))
     return float(S) * (S + 1), issued
 
 

@@ -111,8 +111,9 @@ void k_rowsum_acc(const double* __restrict__ Vt, int ldv, int m, int nrows, doub
 }
 
 // Rows s0 .. of C_l (S x S, row-major, symmetric) into the fragment-ordered A operand of group g = block * nl + l:
-// x^T C x = sum over the row blocks of x_blk^T (C[blk, blk] x_blk + 2 C[blk, right of blk] x_right), so a block
-// only holds the columns from its own first row on, the ones right of the diagonal block doubled.
+// x^T C x = sum_i C_ii x_i^2 + 2 sum_{i < j} C_ij x_i x_j, so a block only holds the columns from its own first row
+// on: the diagonal as it is, everything right of it doubled, everything left of it -- inside the diagonal block too --
+// zero (k_xprod EPI 7 does not issue the k-steps of a tile that lie wholly left of its first row).
 static __global__ __launch_bounds__(256)
 void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* __restrict__ Afrag, size_t group_stride)
 {
@@ -125,8 +126,9 @@ void k_pack_afrag(const double* __restrict__ C, int S, int gpl, int MT, double* 
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)rows * w;
          idx += (long long)gridDim.x * blockDim.x) {
         const int r = (int)(idx / w), k = (int)(idx - (long long)r * w);
+        if (k < r) continue;                                // left of the diagonal: stays zero (the buffer is cleared)
         const double v = Cl[(size_t)r * S + k];
-        out[afrag_off(r, k0 + k, MT)] = (k < MT * 16) ? v : 2.0 * v;
+        out[afrag_off(r, k0 + k, MT)] = (k == r) ? v : 2.0 * v;
     }
 }
 

@@ -1,6 +1,7 @@
 // plsx_k_xprod.h -- the cross-product kernels k_xprod (dense blocks, every epilogue) and k_xprod_compact (one resample per block).
 // Included through plsx_kernels.h (which documents the operand layouts and lists the kernel headers in order).  gfx950 only.
 #pragma once
+#include <type_traits>
 #include "plsx_common.h"
 #include "plsx_k_prep.h"
 
@@ -112,7 +113,7 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     const int kq = lane >> 4;
 
     // EPI 7 (rows s0.. of a SYMMETRIC matrix, quadratic form): the contraction starts at the block's own first row --
-    // the packer doubled the entries right of the diagonal block and dropped those left of it
+    // the packer doubled the entries right of the diagonal (inside the diagonal block too) and dropped those left of it
     static_assert(EPI != 7 || KT == 1, "EPI 7: one k-step per stage");
     // groups are numbered row block first (grp = block * se.J + lv, se.J = LVs of the pass): the eight groups of a
     // sweep -- one per XCD, dispatched in lockstep -- then have the same contraction length
@@ -166,7 +167,11 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(xb[s]));
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one pass of the main loop; TRI (EPI 7 only): a k-step inside the diagonal block, where the packer kept the upper
+    // triangle (k_pack_afrag) -- the fragment of tile m is zero for every k-step left of the tile's first row
+    // (kt < 4 m) and is not issued.  Those first 4 MT passes run as a loop of their own so that the steady-state
+    // loop keeps its branch-free body (with the test inside it the whole loop lost its schedule: 26.8 -> 40 ms at c5).
+    auto pass = [&](int kt, auto tri) {
         const int cur = kt & 1;
         // next stage (clamped on the last pass: a harmless re-load keeps the
         // loop body branch-free so the waits sit right before the LDS write)
@@ -184,14 +189,26 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         for (int s = 0; s < KT; ++s) {
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
+            if constexpr (decltype(tri)::value) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
+                for (int m = 0; m < MT; ++m)
+                    if (4 * m <= kt) acc[m] = mfma_f64(sA[(s * MT + m) * 64], b, acc[m]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
+            }
         }
 #pragma unroll
         for (int s = 0; s < KT; ++s) xb[s] = xn[s];
         __syncthreads();             // (drains the DMA issued one pass ago, then barrier)
+    };
+    int kt_first = 0;
+    if constexpr (EPI == 7) {
+        const int npeel = min(nkt, 4 * MT);
+        for (; kt_first < npeel; ++kt_first) pass(kt_first, std::integral_constant<bool, true>());
     }
+    for (int kt = kt_first; kt < nkt; ++kt) pass(kt, std::integral_constant<bool, false>());
 
     // ---- epilogue -----------------------------------------------------------
     // Tile roles are static: data tiles [0, W0), first-moment (weight) tiles

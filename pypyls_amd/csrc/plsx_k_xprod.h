@@ -567,7 +567,9 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
     for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(xb[s]));
     __syncthreads();
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // one pass of the main loop; FULL: every k-step of the stage is live -- the passes before the last run without the
+    // test for a partial stage in their body (a loop of their own, as in k_xprod's EPI 7)
+    auto pass = [&](int kt, auto full) {
         const int cur = kt & 1;
         const int kn = min(kt + 1, nkt - 1);
         d2 xn[KT];
@@ -577,7 +579,9 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
         const double* sA = smem + cur * STAGE_LDS + lane;
 #pragma unroll
         for (int s = 0; s < KT; ++s) {
-            if (kt * KT + s >= ksteps) break;               // (the last stage may be partial)
+            if constexpr (!decltype(full)::value) {
+                if (kt * KT + s >= ksteps) break;           // (the last stage may be partial)
+            }
             const double b0 = xb[s].x, b1 = xb[s].y;
 #pragma unroll
             for (int m = 0; m < MF; ++m) {
@@ -594,7 +598,11 @@ void k_xprod_compact(const double* __restrict__ Afrag, size_t group_stride,
 #pragma unroll
         for (int s = 0; s < KT; ++s) xb[s] = xn[s];
         __syncthreads();
-    }
+    };
+    const int nfull = ksteps / KT;                           // stages whose KT k-steps are all live
+    int kt_main = 0;
+    for (; kt_main < nfull; ++kt_main) pass(kt_main, std::integral_constant<bool, true>());
+    for (; kt_main < nkt; ++kt_main) pass(kt_main, std::integral_constant<bool, false>());
 
     // value of (tile m, register i), column 0 / 1 of the lane; the tail tile has register 0 only
     auto val0 = [&](int m, int i) -> double { return (TAIL && m == MT - 1) ? tl0 : acc0[m < MF ? m : 0][i]; };

@@ -2,6 +2,14 @@
 // Included through plsx_kernels.h (which documents the operand layouts and lists the kernel headers in order).  gfx950 only.
 #pragma once
 #include <type_traits>
+#include <utility>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), unrolled at compile time
+template <class F, int... I>
+__device__ __forceinline__ void xprod_static_for(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>()), ...);
+}
 #include "plsx_common.h"
 #include "plsx_k_prep.h"
 
@@ -167,11 +175,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     for (int s = 0; s < KT; ++s) asm volatile("" : "+v"(xb[s]));
     __syncthreads();
 
-    // one pass of the main loop; TRI (EPI 7 only): a k-step inside the diagonal block, where the packer kept the upper
-    // triangle (k_pack_afrag) -- the fragment of tile m is zero for every k-step left of the tile's first row
-    // (kt < 4 m) and is not issued.  Those first 4 MT passes run as a loop of their own so that the steady-state
-    // loop keeps its branch-free body (with the test inside it the whole loop lost its schedule: 26.8 -> 40 ms at c5).
-    auto pass = [&](int kt, auto tri) {
+    // one pass of the main loop with the first NA tiles live (NA = MT: all of them).  EPI 7: inside the diagonal block
+    // the packer kept the upper triangle (k_pack_afrag) -- the fragment of tile m is zero for every k-step left of the
+    // tile's first row (kt < 4 m) and is not issued: the first 4 MT passes run unrolled in chunks of four with
+    // m + 1 live tiles, a compile-time count each, so that neither they nor the steady-state loop carry a test (with
+    // one test inside the single main loop the whole loop lost its schedule: 26.8 -> 40 ms at c5).
+    auto pass = [&](int kt, auto na) {
+        constexpr int NA = decltype(na)::value;
         const int cur = kt & 1;
         // next stage (clamped on the last pass: a harmless re-load keeps the
         // loop body branch-free so the waits sit right before the LDS write)
@@ -189,15 +199,9 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
         for (int s = 0; s < KT; ++s) {
             const double b = xb[s];
             const double bsq = (NSQ > 0) ? b * b : 0.0;
-            if constexpr (decltype(tri)::value) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    if (4 * m <= kt) acc[m] = mfma_f64(sA[(s * MT + m) * 64], b, acc[m]);
-            } else {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
-            }
+            for (int m = 0; m < NA; ++m)
+                acc[m] = mfma_f64(sA[(s * MT + m) * 64], (m < MT - NSQ) ? b : bsq, acc[m]);
         }
 #pragma unroll
         for (int s = 0; s < KT; ++s) xb[s] = xn[s];
@@ -205,10 +209,16 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     };
     int kt_first = 0;
     if constexpr (EPI == 7) {
-        const int npeel = min(nkt, 4 * MT);
-        for (; kt_first < npeel; ++kt_first) pass(kt_first, std::integral_constant<bool, true>());
+        xprod_static_for([&](auto mm) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kt = 4 * decltype(mm)::value + j;
+                if (kt < nkt) pass(kt, std::integral_constant<int, decltype(mm)::value + 1>());
+            }
+        }, std::make_integer_sequence<int, MT>());
+        kt_first = min(nkt, 4 * MT);
     }
-    for (int kt = kt_first; kt < nkt; ++kt) pass(kt, std::integral_constant<bool, false>());
+    for (int kt = kt_first; kt < nkt; ++kt) pass(kt, std::integral_constant<int, MT>());
 
     // ---- epilogue -----------------------------------------------------------
     // Tile roles are static: data tiles [0, W0), first-moment (weight) tiles

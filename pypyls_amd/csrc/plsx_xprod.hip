@@ -483,17 +483,8 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
                            ctx->Bpad, S, B, ptr<double>(ctx->Vsumq), L, d_usum);
         LAUNCHCHK();
     }
-    // the S rows of a C_l in gpl blocks of MT tiles (quad_blocks: blocks of 8 tiles), as evenly as the instantiated
-    // block heights allow
-    const int tiles = ceil_div(S, 16), gpl = quad_blocks(tiles);
-    const int need = ceil_div(tiles, gpl);
-    if (need <= 8) return quad_finish_t<8>(ctx, d_usq, ceil_div(tiles, 8), st);
-    if (need <= 12) return quad_finish_t<12>(ctx, d_usq, ceil_div(tiles, 12), st);
-    if (need <= 16) return quad_finish_t<16>(ctx, d_usq, ceil_div(tiles, 16), st);
-    if (need <= 20) return quad_finish_t<20>(ctx, d_usq, ceil_div(tiles, 20), st);
-    if (need <= 21) return quad_finish_t<21>(ctx, d_usq, ceil_div(tiles, 21), st);
-    if (need <= 22) return quad_finish_t<22>(ctx, d_usq, ceil_div(tiles, 22), st);
-    return quad_finish_t<24>(ctx, d_usq, gpl, st);
+    // the S rows of a C_l in row blocks of 8 tiles (quad_blocks): one instantiation of the closing pass
+    return quad_finish_t<8>(ctx, d_usq, quad_blocks(ceil_div(S, 16)), st);
 }
 
 }  // namespace plsxi

@@ -122,13 +122,13 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
 
     // EPI 7 (rows s0.. of a SYMMETRIC matrix, quadratic form): the contraction starts at the block's own first row --
     // the packer doubled the entries right of the diagonal (inside the diagonal block too) and dropped those left of it
-    static_assert(EPI != 7 || KT == 1, "EPI 7: one k-step per stage");
+    static_assert(EPI != 7 || KT == 1 || KT == 2 || KT == 4, "EPI 7: the four k-steps of a tile row are whole stages");
     // groups are numbered row block first (grp = block * se.J + lv, se.J = LVs of the pass): the eight groups of a
     // sweep -- one per XCD, dispatched in lockstep -- then have the same contraction length
     const int qblk = (EPI == 7) ? grp / max(se.J, 1) : 0;
     const int ks0 = (EPI == 7) ? qblk * (MT * 4) : 0;
     if (EPI == 7) { X += (size_t)ks0 * 4 * ldx; nks -= ks0; }
-    const double* Ag = Afrag + (size_t)grp * group_stride + (size_t)ks0 * (KT * MT * 64);
+    const double* Ag = Afrag + (size_t)grp * group_stride + (size_t)ks0 * (MT * 64);
     const int swave = __builtin_amdgcn_readfirstlane(wave);
     const int xvoff = (kq * ldx + min(col, ldx - 1)) * 8;   // per-lane byte offset inside a 4-row k-step (a block of
                                                             // 8 waves may hang over the last 64 columns)
@@ -211,12 +211,12 @@ void k_xprod(const double* __restrict__ Afrag, size_t group_stride,
     if constexpr (EPI == 7) {
         xprod_static_for([&](auto mm) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kt = 4 * decltype(mm)::value + j;
+            for (int j = 0; j < 4 / KT; ++j) {
+                const int kt = (4 / KT) * decltype(mm)::value + j;
                 if (kt < nkt) pass(kt, std::integral_constant<int, decltype(mm)::value + 1>());
             }
         }, std::make_integer_sequence<int, MT>());
-        kt_first = min(nkt, 4 * MT);
+        kt_first = min(nkt, 4 * MT / KT);
     }
     for (int kt = kt_first; kt < nkt; ++kt) pass(kt, std::integral_constant<int, MT>());
 

@@ -425,10 +425,10 @@ int launch_xprod_split(plsx_ctx* ctx, int groups, SplitEpi se, hipStream_t st)
 }
 
 // The closing pass of a series: usum += Xc^T Vsum, usq[j][l] += x_j^T C_l x_j.
-template <int MT>
+template <int MT, int KT>
 int quad_finish_t(plsx_ctx* ctx, double* d_usq, int gpl, hipStream_t st)
 {
-    constexpr int KT = 1, NW = 8;
+    constexpr int NW = 8;
     const int S = ctx->S, L = ctx->method == PLSX_REGRESSION ? ctx->ncomp : ctx->L, B = ctx->B;
     const size_t gstride = (size_t)ctx->nks * MT * 64;
     ctx->quad_MT = MT; ctx->quad_gpl = gpl;
@@ -483,8 +483,11 @@ int quad_finish(plsx_ctx* ctx, double* d_usum, double* d_usq, hipStream_t st)
                            ctx->Bpad, S, B, ptr<double>(ctx->Vsumq), L, d_usum);
         LAUNCHCHK();
     }
-    // the S rows of a C_l in row blocks of 8 tiles (quad_blocks): one instantiation of the closing pass
-    return quad_finish_t<8>(ctx, d_usq, quad_blocks(ceil_div(S, 16)), st);
+    // the S rows of a C_l in row blocks of 8 tiles (quad_blocks); two k-steps per LDS stage (half the barriers of a
+    // block whose pass is only 8 MFMAs long) when every block's contraction is a whole number of stages: the blocks
+    // start at multiples of 32 k-steps, so that is when the padded row count is even
+    if (ctx->nks % 2 == 0) return quad_finish_t<8, 2>(ctx, d_usq, quad_blocks(ceil_div(S, 16)), st);
+    return quad_finish_t<8, 1>(ctx, d_usq, quad_blocks(ceil_div(S, 16)), st);
 }
 
 }  // namespace plsxi

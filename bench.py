@@ -366,7 +366,7 @@ class PLSC(object):
         x_iss = issued * L * B * series / (x_ms * 1e-3) / 1e12 if x_ms > 0 else 0.0
         nt_tf = tm.get('nt_flops', 0.0) / (nt_ms * 1e-3) / 1e12 if nt_ms > 0 else 0.0
         dom = max(kt, key=lambda n: kt[n][0]) if kt else 'k_nt_gemm'
-        closing = {'kernel': 'k_xprod<{},8,1,0,7> (closing pass of a bootstrap series: x_j^T C_l x_j, {} row blocks per LV)'.format(mt, gpl),
+        closing = {'kernel': 'k_xprod<{},8,KT,0,7> (KT = 2 k-steps per stage when the padded row count is even, else 1; closing pass of a bootstrap series: x_j^T C_l x_j, {} row blocks per LV)'.format(mt, gpl),
                    'ms_per_series': x_ms / series, 'achieved': x_need, 'frac': x_need / PEAK_FP64_MFMA_TFLOPS,
                    'issued_tflops': x_iss, 'frac_issued': x_iss / PEAK_FP64_MFMA_TFLOPS,
                    'work': 'S (S + 1) L B = {:.3e} flop per series (upper triangle of L symmetric S x S forms per column), '
@@ -538,7 +538,7 @@ class Simpls(object):
             series = max(int(tm['quad_series']), 1)
             x_need = need * k * B * series / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             x_iss = issued * k * B * series / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out = {'bound': 'mfma', 'kernel': 'k_xprod<{},8,1,0,7> (closing pass of the bootstrap series: sum_b w_b[j,c]^2 = '
+            out = {'bound': 'mfma', 'kernel': 'k_xprod<{},8,KT,0,7> (KT = 2 k-steps per stage when the padded row count is even, else 1; closing pass of the bootstrap series: sum_b w_b[j,c]^2 = '
                                               'x_j^T C_c x_j, {} row blocks per component)'.format(mt, gpl),
                    'dominant_by_time': dom, 'achieved': x_need, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                    'frac': x_need / PEAK_FP64_MFMA_TFLOPS, 'issued_tflops': x_iss, 'frac_issued': x_iss / PEAK_FP64_MFMA_TFLOPS,

@@ -792,8 +792,10 @@ void k_sd_step(SdArgs a)
         for (int t = lane; t < T; t += 64) a.cvec[((size_t)r * T + t) * k + c] = cv[t];
     } else {
         // rows per lane of a column (4 lanes per pair): 8 covers T <= 32, 36 the LDS limit of T
+        // (no 16-rows-per-lane variant for 32 < T <= 64: wave_jacobi_cols<16> returned a wrong leading vector at
+        // T = 44 and 56 in this kernel -- with and without inlining, with and without spills -- where <36> on the same
+        // data is right; the launcher sends every Jacobi solve above T = 32 to the any-T instantiation)
         if constexpr (TC == 0) wave_jacobi_cols<8>(Hw, T, T, ldh, lane, 1e-15);
-        else if constexpr (TC == 1) wave_jacobi_cols<16>(Hw, T, T, ldh, lane, 1e-15);
         else wave_jacobi_cols<36>(Hw, T, T, ldh, lane, 1e-15);
         SD_MARK(5);
         for (int col = lane; col < T; col += 64) {

@@ -86,9 +86,9 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         LAUNCHCHK();
     }
     const size_t lds_step = (size_t)wpb * step_wave;
-    // (the Jacobi solve above T = 32 always takes the any-T instantiation: the 16-rows-per-lane variant compiled on its
-    // own -- k_sd_step<1, true, .> -- returned a wrong leading vector at T = 56 > S = 50 where the same source inside the
-    // any-T kernel is right; not understood, the path is rare (T > S, T > 64 or the option) and not time critical)
+    // (the Jacobi solve above T = 32 always takes the any-T instantiation with 36 rows per lane: a 16-rows-per-lane
+    // variant returned a wrong leading vector at T = 44 / 56 > S, see k_sd_step; the path is rare -- T > S, T > 64 or
+    // the option -- and not time critical)
     const bool jac = a.jacobi_eig || T > 64 || T > S;
     void (*step_kernel)(SdArgs) =
         jac ? (T <= 32 ? (big ? k_sd_step<0, true, 8> : k_sd_step<0, true, 16>)

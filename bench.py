@@ -961,6 +961,24 @@ def measure(args, wl, env):
             roof['traffic'] = tj['kernels'][kname]['hbm_bytes_per_launch'] if kname in tj.get('kernels', {}) \
                 else tj['hbm_bytes_per_launch']
             roof['traffic_source'] = 'profiles/traffic_{}.json ({})'.format(wl.name, kname)
+            # c5: the dual-space solver (k_sd_*) is the largest class by time and is bound by HBM, not by the matrix
+            # pipe: its counter traffic per step (2 k launches of k_sd_step, 2 of k_sd_init / k_sd_post0, 1 of
+            # k_sd_final; bytes per full-size launch from the same file) over its measured time
+            sd_ms = out['config'].get('kernel_ms_per_step', {}).get('k_simpls_dual', 0.0)
+            if wl.name == 'c5' and sd_ms > 0 and getattr(wl, 'perms', 0) == 5000 and getattr(wl, 'boots', 0) == 5000:
+                def per_launch(prefix):
+                    c = [v for k, v in tj.get('kernels', {}).items() if k.startswith(prefix)]
+                    return max(v['hbm_bytes_per_launch'] for v in c) if c else 0.0
+                kk = int(getattr(wl, 'k', 15))
+                tot = 2 * kk * per_launch('k_sd_step') + 2 * per_launch('k_sd_init') + 2 * per_launch('k_sd_post0') \
+                    + per_launch('k_sd_final')
+                if tot > 0:
+                    roof['solver_hbm'] = {'kernels': 'k_sd_init / k_sd_post0 / k_sd_step / k_sd_final', 'bound': 'hbm',
+                                          'traffic_per_step': tot, 'ms_per_step': sd_ms,
+                                          'achieved': tot / (sd_ms * 1e-3) / 1e12, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s',
+                                          'frac': tot / (sd_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                                          'note': 'counter traffic of full-size launches (5000 resamples) from the '
+                                                  'traffic file; valid for the literal 5000 + 5000 step only'}
         except Exception:
             pass
     roof['measured_mfma_f64_peak_tflops'] = eng.mfma_f64_peak()

@@ -1016,7 +1016,7 @@ def sub_records(args, env):
             keep['kernel_ms_per_step'] = rec['config']['kernel_ms_per_step']
             r = rec['roofline']
             keep['roofline'] = {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_issued',
-                                                  'pipeline_frac_mfma', 'traffic', 'dominant_by_time', 'route')
+                                                  'pipeline_frac_mfma', 'traffic', 'dominant_by_time', 'route', 'solver_hbm')
                                 if k in r}
             if cfg == 'c5':
                 keep['parity_note'] = 'SIMPLS with T = 20 > 11: pinned on the oracle\'s exact SIMPLS; REFERENCE parity ' \

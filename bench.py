@@ -586,8 +586,12 @@ class SplitHalf(object):
 
     def __init__(self, args):
         self.args, self.name = args, 'c4split'
-        self.S, self.B, self.T = 500, 200000, 50
-        self.arr, self.ns = args.perms or 8, 100
+        self.S, self.B, self.T = args.S, args.B, args.T
+        # weak: `arr` arrangements per rank and step; strong: ONE set of `arr` arrangements per step, sharded over
+        # the ranks (contiguous slices, parallel.shard_bounds -- what the front-end does with the permutations of a
+        # call with n_split, pypyls_amd/plsc.py)
+        self.strong = args.mode == 'strong'
+        self.arr, self.ns = args.perms or (64 if self.strong else 8), getattr(args, 'n_split', 0) or 100
         self.unit = 'splits/s'
 
     def describe(self, world):
@@ -605,8 +609,12 @@ class SplitHalf(object):
         eng.set_data(self.X, self.Y, resampling.cell_of_row([S], 1), 1, 1, 0)
         self.L = eng.L
         self.perm_idx, self.masks = [], []
+        from pypyls_amd import parallel
+        self.rank, self.world = parallel.rank_world()
+        self.lo, self.hi = parallel.shard_bounds(self.arr, self.rank, self.world) if self.strong else (0, self.arr)
+        self.nmax = parallel.shard_bounds(self.arr, 0, self.world)[1] if self.strong else self.arr
         for s in range(n_steps):
-            seed = 77 + 1000 * rank + s
+            seed = 77 + (0 if self.strong else 1000 * rank) + s      # strong: every rank draws the SAME arrays
             self.perm_idx.append(eng.index_tensor(resampling.gen_permsamp([S], 1, self.arr, seed=seed,
                                                                           verbose=False)))
             m = np.stack([resampling.gen_splits([S], 1, self.ns, seed=seed * 131 + i) for i in range(self.arr)])
@@ -616,12 +624,25 @@ class SplitHalf(object):
         self.legs = []
 
     def units_per_step(self, world):
-        return self.arr * self.ns * world
+        return self.arr * self.ns * (1 if self.strong else world)
 
     def step(self, i, timed=False):
+        import torch
         from pypyls_amd import parallel
-        self.eng.split_half_into(self.perm_idx[i], self.masks[i], self.uc, self.vc)
-        self.result = parallel.gather_device([(self.uc, self.arr), (self.vc, self.arr)], [])
+        ev = None
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        lo, hi = self.lo, self.hi
+        if hi > lo:
+            self.eng.split_half_into(self.perm_idx[i][lo:hi], self.masks[i][lo:hi], self.uc[:hi - lo], self.vc[:hi - lo])
+        if ev:
+            ev[1].record()
+            ev[2].record()
+        self.result = parallel.gather_device([(self.uc[:hi - lo], self.nmax), (self.vc[:hi - lo], self.nmax)], [])
+        if ev:
+            ev[3].record()
+            self.legs.append(ev)
 
     def roofline(self, kt, steps, world):
         """Whole split against SURVEY 8d's W_F(split) = 2 S T' B + 8 T' L B flop
@@ -759,6 +780,10 @@ def run_analysis(args, world=1, rank=0, dev=None, backend='nccl'):
             call(n_perm=n_perm, n_boot=n_boot, seed=1234, _phases=phases, **extra, **emu)
             row[label + '_profiled_ms'] = 1e3 * (time.perf_counter() - t0)
             row[label + '_phases_ms'] = {k: round(v, 2) for k, v in phases.items()}
+            if multi:                                       # every rank's own phase split (the collective phase is where a fast rank waits)
+                allph = [None] * world
+                dist.all_gather_object(allph, {'rank': rank, **row[label + '_phases_ms']})
+                row['per_rank_phases_ms'] = allph
             if n == 1:
                 row['last_rank_ms'] = best
                 break
@@ -792,6 +817,8 @@ def run_analysis(args, world=1, rank=0, dev=None, backend='nccl'):
                'worlds': {str(n): row for n, row in table.items()}}}
     if multi:
         out.pop('end_to_end_emulation')
+        out['per_rank_phases_ms'] = table[1].get('per_rank_phases_ms')
+        out['collective_ms'] = max(p.get('collective', 0.0) for p in out['per_rank_phases_ms']) if out['per_rank_phases_ms'] else None
         from pypyls_amd import parallel
         out['config']['collective'] = '{} over {} ranks, 1 per analysis (the front-end\'s own)'.format(
             parallel.collective_name(), world)
@@ -889,6 +916,12 @@ def measure(args, wl, env):
             emu[route] = {str(n): row for n, row in tab.items()}
         eng.set_perm_path(True)
 
+    per_rank = None
+    if world > 1 and dist.is_initialized() and legs:
+        mine = {'rank': rank, 'resample_ms_per_step': float(np.mean([l[0] + l[1] for l in legs])),
+                'collective_ms_per_step': float(np.mean([l[2] for l in legs]))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank != 0:
         return None
     units = wl.units_per_step(world)
@@ -901,8 +934,11 @@ def measure(args, wl, env):
     if isinstance(wl, (PLSC, Simpls)):
         cfgd.update({'perms_per_step': wl.perms, 'boots_per_step': wl.boots,
                      'per': 'GPU' if args.mode == 'weak' else 'analysis (all GPUs)'})
+    if per_rank is not None:
+        cfgd['per_rank'] = per_rank                     # device time of each rank's own leg and of ITS wait in the collective
     if legs:
-        names = ['perm_ms_per_step', 'boot_ms_per_step', 'collective_ms_per_step'] if args.mode == 'weak' \
+        names = ['perm_ms_per_step', 'boot_ms_per_step', 'collective_ms_per_step'] if (args.mode == 'weak' and isinstance(wl, PLSC)) \
+            else ['split_half_ms_per_step', 'unused', 'collective_ms_per_step'] if isinstance(wl, SplitHalf) \
             else ['indexgen_h2d_resample_ms_per_step', 'unused', 'collective_ms_per_step']
         for j, nm in enumerate(names):
             if nm != 'unused':
@@ -1047,6 +1083,65 @@ def sub_records(args, env):
     return out
 
 
+def sharded_records(args, env):
+    """Under --gpus N > 1 the headline is the weak step (every rank a full 1008 + 1008 on its replica: near-linear by
+    construction).  What north_star's "1e4 resamples/s at 8 GPUs" is about -- ONE analysis sharded over the N ranks --
+    rides in the same line, so that the driver's single command per N yields all three curves:
+      strong   ONE public call of --strong-resamples permutations + as many bootstraps (default 10 000 + 10 000),
+               end to end: seed-compatible index generation, H2D, decomposition, the rank's shards, THE all-gather,
+               finishing, D2H; barriers around the call, slowest rank counts; every rank's phase split
+      c4split  ONE set of --split-arrangements permuted arrangements x n_split = 100 sharded over the ranks
+               (contiguous slices, like the permutations of a call with n_split), gathered once; per-rank leg times.
+    Collective: every rank makes the same calls."""
+    import copy
+    import gc
+    import torch
+    out = {}
+    rank = env['rank']
+    t0 = time.perf_counter()
+    try:
+        a = copy.copy(args)
+        a.config, a.mode, a.emulate_world, a.splits, a.steps = 'c4', 'analysis', '', 0, 2
+        a.perms = a.boots = args.strong_resamples
+        rec = run_analysis(a, env['world'], rank, env['dev'], env['backend'])
+        if rank == 0:
+            out['strong'] = {'metric': rec['metric'], 'value': rec['value'], 'unit': rec['unit'], 'scaling': 'strong',
+                             'ms_per_step': rec['ms_per_step'], 'n_gpus': rec['n_gpus'],
+                             'workload': rec['config']['workload'], 'collective': rec['config'].get('collective'),
+                             'collective_ms': rec.get('collective_ms'),
+                             'per_rank_phases_ms': rec.get('per_rank_phases_ms'),
+                             'wall_s': time.perf_counter() - t0}
+    except Exception as exc:                               # the headline line must survive a failing sub-record
+        out['strong'] = {'error': '{}: {}'.format(type(exc).__name__, str(exc)[:300])}
+    gc.collect()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    try:
+        a = copy.copy(args)
+        a.config, a.mode, a.emulate_world = 'c4split', 'strong', ''
+        a.perms, a.boots, a.steps, a.warmup, a.cpu_sample = args.split_arrangements, 0, 2, 1, 0
+        wl = make_workload(a)
+        rec = measure(a, wl, env)
+        if rank == 0:
+            out['c4split'] = {'metric': rec['metric'], 'value': rec['value'], 'unit': rec['unit'], 'scaling': 'strong',
+                              'ms_per_step': rec['ms_per_step'], 'n_gpus': rec['n_gpus'],
+                              'workload': rec['config']['workload'] + ': ONE set of {} arrangements sharded over the '
+                                          'ranks'.format(wl.arr),
+                              'split_half_ms_per_step': rec['config'].get('split_half_ms_per_step'),
+                              'collective_ms_per_step': rec['config'].get('collective_ms_per_step'),
+                              'per_rank': rec['config'].get('per_rank'),
+                              'roofline': {k: rec['roofline'][k] for k in ('bound', 'kernel', 'frac', 'route')
+                                           if k in rec['roofline']},
+                              'wall_s': time.perf_counter() - t0}
+        del wl.eng
+        del wl
+    except Exception as exc:
+        out['c4split'] = {'error': '{}: {}'.format(type(exc).__name__, str(exc)[:300])}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -1066,6 +1161,13 @@ def main():
     ap.add_argument('--no-primal', action='store_true', help='skip the second (feature-pass) timed region')
     ap.add_argument('--no-configs', action='store_true',
                     help='default run only: skip the sub-records of the other BASELINE configs (configs: {...})')
+    ap.add_argument('--strong-resamples', type=int, default=10000,
+                    help='--gpus N > 1, default run: n_perm = n_boot of the ONE sharded end-to-end analysis embedded '
+                         'under "sharded" (strong scaling)')
+    ap.add_argument('--split-arrangements', type=int, default=64,
+                    help='--gpus N > 1, default run: arrangements (x n_split = 100) of the ONE sharded split-half leg '
+                         'embedded under "sharded"')
+    ap.add_argument('--n-split', type=int, default=0, help='--config c4split: splits per arrangement (default 100)')
     ap.add_argument('--emulate-world', default='',
                     help='strong mode, one GPU: comma-separated world sizes N; times the critical path of one '
                          'analysis on rank 0 and on rank N-1 of an emulated world N (full index generation, own '
@@ -1112,7 +1214,8 @@ def main():
     world = dist.get_world_size() if dist.is_initialized() else 1
     if dist.is_initialized():
         from pypyls_amd import parallel
-        collective = parallel.collective_name()           # opens the communicator behind plsx_allgather (collective call)
+        parallel.open_native_comm()                        # EXPLICIT collective open of the communicator behind plsx_allgather (every rank)
+        collective = parallel.collective_name()           # a pure query: which all-gather the steps will issue
     env = {'world': world, 'rank': rank, 'dev': dev, 'backend': backend, 'collective': collective}
 
     if args.mode == 'analysis':
@@ -1126,6 +1229,12 @@ def main():
             del wl
             torch.cuda.empty_cache()
             out['configs'] = sub_records(args, env)
+        elif world > 1 and args.config == 'c4' and args.mode == 'weak' and not args.no_configs:
+            del wl                                          # (its engine and scratch go with it)
+            torch.cuda.empty_cache()
+            sharded = sharded_records(args, env)            # collective: every rank
+            if rank == 0 and out is not None:
+                out['sharded'] = sharded
     if rank == 0 and out is not None:
         os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if dist.is_initialized():

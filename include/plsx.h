@@ -439,13 +439,43 @@ int plsx_gen_splits_seeded(const int* groups, int n_groups, int n_cond, int n_sp
  *   plsx_comm_destroy    also called by plsx_ctx_destroy
  * Without plsx_comm_init a context is a world of one and plsx_allgather is a
  * device-to-device copy.
+ *
+ * ONE process driving several devices (SURVEY 8(b) "plsx_allgather(ctx[], nranks,
+ * ...)", 8(e) "single process driving 8 devices (ncclCommInitAll) is sufficient;
+ * no torch.distributed") -- what `n_proc` workers are in the reference
+ * (pyls/utils.py:252-279, pyls/base.py:286-292): the host keeps one context per
+ * device and one host thread per context, and a single thread issues the
+ * collective for all of them:
+ *   plsx_comm_init_all   contexts 0 .. n-1 become ranks 0 .. n-1 of one team.
+ *                        transport PLSX_TRANSPORT_RCCL: ncclCommInitAll over the
+ *                        contexts' devices (they must be distinct);
+ *                        PLSX_TRANSPORT_PEER: no communicator, the gather is n
+ *                        hipMemcpyPeerAsync pulls per rank (xGMI between devices;
+ *                        the only form that accepts the SAME device twice -- two
+ *                        contexts sharing one GPU, the single-GPU test of the team
+ *                        path); PLSX_TRANSPORT_AUTO: RCCL when the devices are
+ *                        distinct, peer copies otherwise.
+ *   plsx_allgather_all   d_recv[r][q * bytes ...] = d_send[q] for every rank r,
+ *                        enqueued on streams[r] (NULL = the null streams): one
+ *                        ncclGroupStart / n x ncclAllGather / ncclGroupEnd, or the
+ *                        peer copies ordered behind an event on every sender's
+ *                        stream.  Asynchronous; a send buffer may be reused once
+ *                        EVERY rank's stream has passed the call.
+ *   plsx_comm_destroy    per context, as above.
+ *   plsx_comm_transport  0: the context is a world of one, else the
+ *                        PLSX_TRANSPORT_* value its communicator runs on.
  */
+enum { PLSX_TRANSPORT_AUTO = 0, PLSX_TRANSPORT_RCCL = 1, PLSX_TRANSPORT_PEER = 2 };
 int plsx_comm_load(plsx_ctx* ctx, const char* librccl_path);
 int plsx_comm_unique_id(plsx_ctx* ctx, void* id128);
 int plsx_comm_init(plsx_ctx* ctx, const void* id128, int rank, int world);
 int plsx_comm_rank(const plsx_ctx* ctx, int* rank, int* world);
 int plsx_allgather(plsx_ctx* ctx, const void* d_send, void* d_recv, long long bytes_per_rank, void* stream);
 int plsx_comm_destroy(plsx_ctx* ctx);
+int plsx_comm_init_all(plsx_ctx** ctxs, int n, int transport);
+int plsx_comm_transport(const plsx_ctx* ctx);
+int plsx_allgather_all(plsx_ctx** ctxs, int n, const void* const* d_send, void* const* d_recv,
+                       long long bytes_per_rank, void* const* streams);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,11 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // one process driving several devices (plsx_comm_init_all / plsx_allgather_all); optional: a librccl without them
+    // still serves the one-process-per-GPU entries above
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 std::mutex g_api_lock;
@@ -33,6 +38,9 @@ bool bind_all(void* h, RcclApi& a)
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     return a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy && a.GetErrorString;
 }
 
@@ -130,6 +138,12 @@ int plsx_comm_rank(const plsx_ctx* ctx, int* rank, int* world)
     return PLSX_OK;
 }
 
+int plsx_comm_transport(const plsx_ctx* ctx)
+{
+    if (!ctx || ctx->comm_world <= 1) return 0;
+    return ctx->comm ? PLSX_TRANSPORT_RCCL : PLSX_TRANSPORT_PEER;
+}
+
 int plsx_allgather(plsx_ctx* ctx, const void* d_send, void* d_recv, long long bytes_per_rank, void* stream)
 try {
     if (!ctx || bytes_per_rank < 0 || (bytes_per_rank > 0 && (!d_send || !d_recv)))
@@ -150,9 +164,105 @@ try {
     return PLSX_OK;
 } PLSX_CATCH(ctx)
 
+// ---- one process, several devices (SURVEY 8(b) "plsx_allgather(ctx[], nranks, ...)", 8(e) "single process driving
+// ---- 8 devices (ncclCommInitAll) is sufficient; no torch.distributed") ------------------------------------------------
+int plsx_comm_init_all(plsx_ctx** ctxs, int n, int transport)
+try {
+    if (!ctxs || n < 1 || !ctxs[0]) return PLSX_ERR_ARG;
+    plsx_ctx* c0 = ctxs[0];
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) return fail(c0, PLSX_ERR_ARG, "plsx_comm_init_all: null context");
+        if (ctxs[r]->comm || ctxs[r]->comm_world > 1)
+            return fail(c0, PLSX_ERR_STATE, "plsx_comm_init_all: a context already belongs to a communicator");
+        for (int q = 0; q < r; q++)
+            if (ctxs[q] == ctxs[r]) return fail(c0, PLSX_ERR_ARG, "plsx_comm_init_all: the same context twice");
+    }
+    bool distinct = true;
+    for (int r = 0; r < n && distinct; r++)
+        for (int q = 0; q < r; q++)
+            if (ctxs[q]->device == ctxs[r]->device) { distinct = false; break; }
+    if (transport == PLSX_TRANSPORT_RCCL && !distinct)
+        return fail(c0, PLSX_ERR_ARG, "plsx_comm_init_all: RCCL needs one rank per device (a device is listed twice)");
+    const bool rccl = n > 1 && (transport == PLSX_TRANSPORT_RCCL || (transport == PLSX_TRANSPORT_AUTO && distinct));
+    if (rccl) {
+        int rc = load_api(c0, nullptr);
+        if (rc) return rc;
+        if (!g_api.CommInitAll || !g_api.GroupStart || !g_api.GroupEnd)
+            return fail(c0, PLSX_ERR_STATE, "plsx_comm_init_all: " + g_api.path + " lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
+        std::vector<int> devs(n);
+        std::vector<ncclComm_t> comms(n, nullptr);
+        for (int r = 0; r < n; r++) devs[r] = ctxs[r]->device;
+        ncclResult_t res = g_api.CommInitAll(comms.data(), n, devs.data());
+        if (res != ncclSuccess) return nccl_fail(c0, "ncclCommInitAll", res);
+        for (int r = 0; r < n; r++) ctxs[r]->comm = comms[r];
+    }
+    for (int r = 0; r < n; r++) {
+        ctxs[r]->comm_rank = r;
+        ctxs[r]->comm_world = n;
+        ctxs[r]->comm_team = 1;
+    }
+    return PLSX_OK;
+} PLSX_CATCH(ctxs && ctxs[0] ? ctxs[0] : nullptr)
+
+int plsx_allgather_all(plsx_ctx** ctxs, int n, const void* const* d_send, void* const* d_recv, long long bytes_per_rank,
+                       void* const* streams)
+try {
+    if (!ctxs || n < 1 || !ctxs[0]) return PLSX_ERR_ARG;
+    plsx_ctx* c0 = ctxs[0];
+    plsx_ctx* ctx = c0;                                 // (HIPCHK reports through rank 0's context)
+    if (bytes_per_rank < 0 || (bytes_per_rank > 0 && (!d_send || !d_recv)))
+        return fail(c0, PLSX_ERR_ARG, "plsx_allgather_all: bad arguments");
+    for (int r = 0; r < n; r++)
+        if (!ctxs[r] || ctxs[r]->comm_world != n || ctxs[r]->comm_rank != r || !ctxs[r]->comm_team)
+            return fail(c0, PLSX_ERR_STATE, "plsx_allgather_all: contexts are not the ranks 0 .. n-1 of one plsx_comm_init_all");
+    if (bytes_per_rank == 0) return PLSX_OK;
+    const size_t nb = static_cast<size_t>(bytes_per_rank);
+    auto stream_of = [&](int r) { return streams ? static_cast<hipStream_t>(streams[r]) : static_cast<hipStream_t>(nullptr); };
+    if (c0->comm) {                                     // RCCL: the n calls of one group, issued by this one thread
+        const bool f64 = bytes_per_rank % 8 == 0;
+        ncclResult_t res = g_api.GroupStart();
+        if (res != ncclSuccess) return nccl_fail(c0, "ncclGroupStart", res);
+        ncclResult_t bad = ncclSuccess;
+        for (int r = 0; r < n; r++) {
+            HIPCHK(hipSetDevice(ctxs[r]->device));
+            res = g_api.AllGather(d_send[r], d_recv[r], f64 ? nb / 8 : nb, f64 ? ncclFloat64 : ncclUint8,
+                                  static_cast<ncclComm_t>(ctxs[r]->comm), stream_of(r));
+            if (res != ncclSuccess && bad == ncclSuccess) bad = res;
+        }
+        res = g_api.GroupEnd();
+        if (bad != ncclSuccess) return nccl_fail(c0, "ncclAllGather", bad);
+        if (res != ncclSuccess) return nccl_fail(c0, "ncclGroupEnd", res);
+        return PLSX_OK;
+    }
+    // peer copies: rank r's stream waits for every sender's buffer to be complete on ITS stream, then pulls the n
+    // blocks into its own receive buffer (hipMemcpyPeerAsync: xGMI between devices, a device copy inside one)
+    std::vector<hipEvent_t> ready(n, nullptr);
+    int rc = PLSX_OK;
+    for (int q = 0; q < n && rc == PLSX_OK; q++) {
+        if (hipSetDevice(ctxs[q]->device) != hipSuccess ||
+            hipEventCreateWithFlags(&ready[q], hipEventDisableTiming) != hipSuccess ||
+            hipEventRecord(ready[q], stream_of(q)) != hipSuccess)
+            rc = fail(c0, PLSX_ERR_HIP, "plsx_allgather_all: could not record the senders' events");
+    }
+    for (int r = 0; r < n && rc == PLSX_OK; r++) {
+        hipError_t e = hipSetDevice(ctxs[r]->device);
+        for (int q = 0; q < n && e == hipSuccess; q++) {
+            if (q != r) e = hipStreamWaitEvent(stream_of(r), ready[q], 0);
+            char* dst = static_cast<char*>(d_recv[r]) + static_cast<size_t>(q) * nb;
+            if (e == hipSuccess && dst != d_send[q])
+                e = hipMemcpyPeerAsync(dst, ctxs[r]->device, d_send[q], ctxs[q]->device, nb, stream_of(r));
+        }
+        if (e != hipSuccess) rc = fail(c0, PLSX_ERR_HIP, std::string("plsx_allgather_all: ") + hipGetErrorString(e));
+    }
+    for (int q = 0; q < n; q++)
+        if (ready[q]) (void)hipEventDestroy(ready[q]);  // (released when the recorded work completes)
+    return rc;
+} PLSX_CATCH(ctxs && ctxs[0] ? ctxs[0] : nullptr)
+
 int plsx_comm_destroy(plsx_ctx* ctx)
 try {
     if (!ctx) return PLSX_ERR_ARG;
+    if (!ctx->comm) { ctx->comm_rank = 0; ctx->comm_world = 1; ctx->comm_team = 0; }
     if (ctx->comm) {
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
@@ -160,6 +270,7 @@ try {
         ctx->comm = nullptr;
         ctx->comm_rank = 0;
         ctx->comm_world = 1;
+        ctx->comm_team = 0;
         if (r != ncclSuccess) return nccl_fail(ctx, "ncclCommDestroy", r);
     }
     return PLSX_OK;

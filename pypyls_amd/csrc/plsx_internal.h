@@ -131,6 +131,7 @@ struct plsx_ctx {
     // the exported collective (plsx_comm.hip): an RCCL communicator of one rank per GPU, reached through dlopen
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    int comm_team = 0;                                  // 1: rank of a plsx_comm_init_all team (one process, several contexts)
 };
 
 namespace plsxi {

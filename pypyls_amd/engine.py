@@ -100,6 +100,10 @@ def _load():
         'plsx_comm_rank': ([vp, ctypes.POINTER(i32), ctypes.POINTER(i32)], i32),
         'plsx_allgather': ([vp, vp, vp, ctypes.c_longlong, vp], i32),
         'plsx_comm_destroy': ([vp], i32),
+        'plsx_comm_init_all': ([ctypes.POINTER(vp), i32, i32], i32),
+        'plsx_comm_transport': ([vp], i32),
+        'plsx_allgather_all': ([ctypes.POINTER(vp), i32, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,
+                                ctypes.POINTER(vp)], i32),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)            # AttributeError if a symbol is missing
@@ -124,7 +128,7 @@ def exported_symbols():
              'plsx_gen_bootsamp_stream', 'plsx_set_option', 'plsx_option_name', 'plsx_numeric_report',
              'plsx_svd_flip', 'plsx_scale_columns', 'plsx_transpose', 'plsx_center_rows', 'plsx_mean_splits',
              'plsx_comm_load', 'plsx_comm_unique_id', 'plsx_comm_init', 'plsx_comm_rank', 'plsx_allgather',
-             'plsx_comm_destroy']
+             'plsx_comm_destroy', 'plsx_comm_init_all', 'plsx_comm_transport', 'plsx_allgather_all']
     return [n for n in names if hasattr(lib, n)]
 
 
@@ -825,9 +829,10 @@ _DEFAULT = {}
 _DEFAULT_LOCK = threading.Lock()
 
 
-def default_engine(device=None):
+def default_engine(device=None, replica=0):
     """The engine the public calls use when none is passed: ONE per (process, device), created on first use and
     kept -- its context, the resident copy of the last X and the super-batch scratch stay mapped between calls.
+    (``replica`` > 0: a further context on the same device, for a team that lists a device twice, team.py.)
 
     Why not a fresh engine per call (rounds 1-3): mapping device memory is not free on a shared MI355X.  The
     driver clears recycled VRAM lazily, so a call that maps the tens of GB its predecessor just released waits
@@ -842,21 +847,24 @@ def default_engine(device=None):
     torch = _torch()
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-    key = int(device)
+    key = (int(device), int(replica))
     with _DEFAULT_LOCK:
         eng = _DEFAULT.get(key)
         if eng is None or not getattr(eng, 'ctx', None):
             if not _DEFAULT:
                 import atexit
                 atexit.register(release_default_engine)     # free the device memory before the runtime goes away
-            eng = _DEFAULT[key] = Engine(device=key)
+            eng = _DEFAULT[key] = Engine(device=key[0])
     return eng
 
 
 def release_default_engine(device=None):
     """Destroy the cached default engine(s) and free their device memory."""
+    from . import team as _team
+    _team.release_teams()                                   # their communicators go before the contexts
     with _DEFAULT_LOCK:
-        engines = [_DEFAULT.pop(key, None) for key in ([int(device)] if device is not None else list(_DEFAULT))]
+        keys = [k for k in _DEFAULT if device is None or k[0] == int(device)]
+        engines = [_DEFAULT.pop(key, None) for key in keys]
     for eng in engines:
         if eng is not None:
             with eng.lock:                                  # (a call in flight on another thread finishes first)

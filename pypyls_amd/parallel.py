@@ -16,11 +16,16 @@ Where the collective runs.  The rendezvous -- who the ranks are -- is the host l
 (``torch.distributed``: torchrun's env and store).  The DATA collective itself is the C ABI's
 ``plsx_allgather`` (include/plsx.h): an RCCL communicator of one rank per GPU opened by
 ``plsx_comm_init`` from a 128-byte unique id that rank 0 draws and the process group broadcasts
-once per process (:func:`native_comm`).  libplsx.so binds RCCL with dlopen and is told to use
-the copy PyTorch-ROCm already loaded, so the process keeps ONE communication runtime.  When the
-communicator cannot be opened on every rank (no librccl, init failure) all ranks fall back
-TOGETHER to ``all_gather_into_tensor`` of the process group -- still RCCL, never the CPU -- and
-:func:`collective_name` says which of the two ran.  ``gloo`` groups (CPU tests) never touch it.
+once per process -- when the launcher asked for it with :func:`open_native_comm`, an explicit
+collective call right after ``init_process_group`` (bench.py makes it).  libplsx.so binds RCCL with
+dlopen and is told to use the copy PyTorch-ROCm already loaded, so the process keeps ONE
+communication runtime.  Without that call, or when the communicator cannot be opened on every
+rank (no librccl, init failure or time-out), all ranks use ``all_gather_into_tensor`` of the
+process group -- still RCCL, never the CPU -- and :func:`collective_name`, a pure query, says which
+of the two runs.  ``gloo`` groups (CPU tests) never touch it.
+
+ONE process driving several GPUs (``n_proc`` / ``device_ids`` of the front-ends) does not come
+through here at all: team.py, ``plsx_comm_init_all`` / ``plsx_allgather_all``.
 """
 import numpy as np
 
@@ -44,17 +49,33 @@ def rank_world():
 
 # the communicator behind plsx_allgather: one per process, on its own small context (no data is ever bound to it,
 # so it costs no device memory and is independent of which Engine an analysis uses)
-_NATIVE = {'state': None, 'engine': None, 'why': '', 'group': None}     # state: None = not tried, True = open, False = fall back
-USE_NATIVE_COLLECTIVE = True
+_NATIVE = {'state': None, 'engine': None, 'why': '', 'group': None}     # state: None = not opened, True = open, False = fall back
+NATIVE_INIT_TIMEOUT_S = 120.0
 
 
 def native_comm():
-    """The Engine whose context holds the RCCL communicator of this process group, or None (fall back to the
-    process group's own all-gather).  First call under an initialised ``nccl`` group is COLLECTIVE: every rank
-    binds librccl, rank 0 draws the unique id, the group broadcasts it, every rank calls ``plsx_comm_init``;
-    the outcome is agreed by an all-reduce so that either every rank uses ``plsx_allgather`` or none does."""
+    """The Engine whose context holds the RCCL communicator :func:`open_native_comm` opened for the CURRENT process
+    group, or None.  No side effects: it never opens anything, so it is safe on one rank only (logging)."""
     d = _dist()
-    if d is None or d.get_backend() != 'nccl' or not USE_NATIVE_COLLECTIVE:
+    if d is None or not _NATIVE['state'] or _NATIVE['group'] is not d.group.WORLD:
+        return None
+    return _NATIVE['engine']
+
+
+def open_native_comm(timeout_s=None):
+    """Open the communicator behind ``plsx_allgather`` for the current ``nccl`` process group.  EXPLICIT and
+    COLLECTIVE: call it on EVERY rank, once, right after ``init_process_group`` (bench.py does; the front-ends never
+    do it behind the caller's back -- without it the data collective is the process group's own
+    ``all_gather_into_tensor``, RCCL all the same).  Every rank binds librccl, rank 0 draws the unique id, the group
+    broadcasts it, every rank calls ``plsx_comm_init`` (ncclCommInitRank) on a helper thread that is given
+    ``timeout_s`` (default NATIVE_INIT_TIMEOUT_S); the outcome -- bound, initialised in time, rank order proven by
+    a two-word gather -- is agreed by an all-reduce after each step, so that either every rank uses
+    ``plsx_allgather`` or none does.  A rank whose init never returns reports failure at the agreement and all
+    ranks fall back together (its helper thread is left behind as a daemon); what this cannot cover is a rank that
+    DIES inside the open -- the peers then wait in the process group's own all-reduce until ITS timeout fires.
+    Returns the Engine or None."""
+    d = _dist()
+    if d is None or d.get_backend() != 'nccl':
         return None
     group = d.group.WORLD
     if _NATIVE['state'] is not None and _NATIVE['group'] is group:
@@ -88,10 +109,23 @@ def native_comm():
         d.broadcast_object_list(box, src=0)
         ok = box[0] is not None
         if ok:
-            try:
-                eng.comm_init(box[0], rank, world)
-            except Exception as exc:                    # noqa: BLE001
-                why = 'init: ' + str(exc)[:200]
+            import threading
+            done = {}
+
+            def init():
+                try:
+                    torch.cuda.set_device(dev)
+                    eng.comm_init(box[0], rank, world)
+                    done['ok'] = True
+                except Exception as exc:                # noqa: BLE001
+                    done['why'] = 'init: ' + str(exc)[:200]
+            th = threading.Thread(target=init, name='plsx-comm-init', daemon=True)
+            th.start()
+            th.join(NATIVE_INIT_TIMEOUT_S if timeout_s is None else float(timeout_s))
+            if th.is_alive():
+                why = 'init: ncclCommInitRank did not return within the timeout'
+            elif not done.get('ok'):
+                why = done.get('why', 'init failed')
             ok = agreed(not why)
     if ok:                                              # prove the rank order before anything depends on it
         try:
@@ -136,7 +170,7 @@ def release_native_comm():
 
 
 def collective_name():
-    """Which all-gather :func:`gather_device` issues under the current process group."""
+    """Which all-gather :func:`gather_device` issues under the current process group (a pure query)."""
     d = _dist()
     if d is None:
         return 'none (no process group)'
@@ -239,14 +273,7 @@ def gather_device(slices, sums, device=None):
     on_gpu = d.get_backend() == 'nccl'
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
-    pieces, shapes = [], []
-    for t, nmax in slices:
-        t = _pad_rows(t, nmax)
-        shapes.append(tuple(t.shape))
-        pieces.append(t.reshape(-1))
-    for t in sums:
-        shapes.append(tuple(t.shape))
-        pieces.append(t.reshape(-1))
+    pieces, shapes = _pack(slices, sums)
     homes = [p.device for p in pieces]
     flat = torch.cat([p.to(device=device, dtype=torch.float64) for p in pieces]) if pieces else \
         torch.zeros(0, dtype=torch.float64, device=device)
@@ -257,18 +284,9 @@ def gather_device(slices, sums, device=None):
             comm.allgather_into(flat, gathered)         # plsx_allgather on the current stream of the data
     else:
         d.all_gather_into_tensor(gathered.view(-1), flat)
-    out_g, out_s, off = [], [], 0
-    for i, shp in enumerate(shapes):
-        n = int(np.prod(shp)) if len(shp) else 1
-        blk = gathered[:, off:off + n].reshape((world,) + shp)
-        off += n
-        if i < len(slices):
-            out_g.append(blk)
-        else:
-            acc = blk[0].clone()
-            for r in range(1, world):                   # fixed rank order -> deterministic
-                acc += blk[r]
-            out_s.append(acc.to(homes[i]) if acc.device != homes[i] else acc)
+    out_g, out_s = _unpack(gathered, shapes, len(slices), world)
+    ns = len(slices)
+    out_s = [acc.to(homes[ns + i]) if acc.device != homes[ns + i] else acc for i, acc in enumerate(out_s)]
     return out_g, out_s
 
 
@@ -282,11 +300,8 @@ def _pad_rows(t, n):
     return torch.cat([t, pad])
 
 
-def _surrogate_gather(slices, sums, world):
-    """Stand-in for the all-gather of an EMULATED world (one GPU, no peers; bench.py --emulate-world): the packed
-    buffer of this rank is replicated ``world`` times on the device -- the volume a real gather would deliver --
-    and the partial sums are added in rank order, as after a real one.  The values are of course this rank's own."""
-    import torch
+def _pack(slices, sums):
+    """(tensor, nmax) slices padded to nmax rows + sums -> flat pieces and their shapes."""
     pieces, shapes = [], []
     for t, nmax in slices:
         t = _pad_rows(t, nmax)
@@ -295,24 +310,50 @@ def _surrogate_gather(slices, sums, world):
     for t in sums:
         shapes.append(tuple(t.shape))
         pieces.append(t.reshape(-1))
-    flat = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.float64)
-    gathered = flat.unsqueeze(0).repeat(world, 1)
+    return pieces, shapes
+
+
+def _unpack(gathered, shapes, n_slices, world):
+    """(world, n) gathered buffer -> per-slice (world, nmax, ...) blocks and the rank-ordered sums."""
     out_g, out_s, off = [], [], 0
     for i, shp in enumerate(shapes):
         n = int(np.prod(shp)) if len(shp) else 1
         blk = gathered[:, off:off + n].reshape((world,) + shp)
         off += n
-        if i < len(slices):
+        if i < n_slices:
             out_g.append(blk)
         else:
             acc = blk[0].clone()
-            for r in range(1, world):
+            for r in range(1, world):                   # fixed rank order -> deterministic
                 acc += blk[r]
             out_s.append(acc)
     return out_g, out_s
 
 
-def collect_device(slices, totals, sums, cyclic=(), emulate=None):
+def _surrogate_gather(slices, sums, world):
+    """Stand-in for the all-gather of an EMULATED world (one GPU, no peers; bench.py --emulate-world): the packed
+    buffer of this rank is replicated ``world`` times on the device -- the volume a real gather would deliver --
+    and the partial sums are added in rank order, as after a real one.  The values are of course this rank's own."""
+    import torch
+    pieces, shapes = _pack(slices, sums)
+    flat = torch.cat(pieces) if pieces else torch.zeros(0, dtype=torch.float64)
+    gathered = flat.unsqueeze(0).repeat(world, 1)
+    return _unpack(gathered, shapes, len(slices), world)
+
+
+def _team_gather(slices, sums, rank, team):
+    """The collective of a single-process team (team.py): every rank's thread packs on its own device and meets
+    the others in ``Team.allgather`` (one plsx_allgather_all issued for all ranks)."""
+    import torch
+    dev = team.engines[rank].device
+    pieces, shapes = _pack(slices, sums)
+    flat = torch.cat([p.to(device=dev, dtype=torch.float64) for p in pieces]) if pieces else \
+        torch.zeros(0, dtype=torch.float64, device=dev)
+    gathered = team.allgather(rank, flat)
+    return _unpack(gathered, shapes, len(slices), team.world)
+
+
+def collect_device(slices, totals, sums, cyclic=(), emulate=None, team=None):
     """THE collective of a front-end call on tensors that are already where the backend wants them (device
     tensors under RCCL: the shard results never visit the host before the gather), with the result LEFT on the
     device of the inputs: the front-end finishes there (percentile intervals, bootstrap ratios, the layout of
@@ -322,10 +363,13 @@ def collect_device(slices, totals, sums, cyclic=(), emulate=None):
             (shard_bounds), or chunk-cyclic in the rank's local order (shard_rows) for the positions listed in
             ``cyclic``; sums: tensors to add over ranks.  Returns (list of tensors with the FULL leading axis
             in global order, list of rank-ordered sums), identical on every rank.  Without a process group
-            nothing moves.  emulate = (rank, world): no peers, see _surrogate_gather."""
+            nothing moves.  emulate = (rank, world): no peers, see _surrogate_gather.  team = (rank, Team): this thread is
+    one rank of a single-process team (team.py); every rank's thread makes this call."""
     import torch
     d = _dist()
-    if emulate is None:
+    if team is not None:
+        rank, world = team[0], team[1].world
+    elif emulate is None:
         if d is None:
             return list(slices), list(sums)
         rank, world = d.get_rank(), d.get_world_size()
@@ -339,7 +383,9 @@ def collect_device(slices, totals, sums, cyclic=(), emulate=None):
         else:
             counts.append([int(np.diff(shard_bounds(n, r, world))[0]) for r in range(world)])
     padded = [(t, max(c)) for t, c in zip(slices, counts)]
-    if emulate is not None:
+    if team is not None:
+        got, summed = _team_gather(padded, sums, rank, team[1])
+    elif emulate is not None:
         got, summed = _surrogate_gather(padded, sums, world)
     else:
         if d.get_backend() == 'nccl':           # RCCL: pack and gather on the GPU

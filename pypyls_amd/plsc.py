@@ -13,10 +13,16 @@ Differences from the reference at this commit, on purpose:
   * ``permindices`` defaults to True, the documented default
     (pyls/structures.py:115-120); the shipped ``None`` makes
     BasePLS._single_perm treat index vectors as data.
-  * ``n_proc`` is accepted and ignored: the joblib process pool
-    (pyls/utils.py:252-279) is what the device replaces.
-  * When torch.distributed is initialised the resamples are sharded across
-    ranks and collected with one all-gather (pypyls_amd/parallel.py).
+  * ``n_proc`` counts GPUs, not CPU workers: the joblib pool of the reference
+    (pyls/utils.py:252-279) is what the devices replace.  ``n_proc=8`` (or
+    'max' / -1) on an 8-GPU node shards the resamples of THIS call over the
+    GPUs from this one process -- one context and one host thread per device,
+    ONE all-gather (pypyls_amd/team.py); ``device_ids=[...]`` names them
+    explicitly.  On a one-GPU box both reduce to the ordinary call.
+  * When torch.distributed is initialised (a script under torchrun: one
+    process per GPU) the resamples are sharded across the RANKS instead and
+    collected with one all-gather (pypyls_amd/parallel.py); ``n_proc`` /
+    ``device_ids`` are then ignored.
 """
 import warnings
 
@@ -79,6 +85,8 @@ class _PLSCRun(object):
         # per-phase wall times; (rank, world) of a world emulated on one GPU
         self.phases = kwargs.pop('_phases', None)
         self.emulate = kwargs.pop('_emulate', None)
+        self.device_ids = kwargs.pop('device_ids', None)
+        self.transport = kwargs.pop('_transport', 'auto')
         self.inputs = PLSInputs(X=X, Y=Y, groups=groups, n_cond=n_cond, **kwargs)
         # under torch.distributed every rank must draw the same index arrays
         self.rs = resampling.check_random_state(parallel.shared_seed(self.inputs.get('seed')))
@@ -166,11 +174,25 @@ class _PLSCRun(object):
         Tp = self.n_cells * Y.shape[1] if Y is not None else self.n_cells
         self.perm_given = self.boot_given = None
         from .engine import default_engine
-        eng = self.engine or default_engine()
+        from . import team as _team
+        devices = None
+        if self.engine is None and self.emulate is None and parallel._dist() is None:
+            # n_proc workers of the reference (pyls/utils.py:252-279) = GPUs of this node, driven from this process
+            devices = _team.resolve_devices(inp.get('n_proc'), self.device_ids)
+        self._mstreams = []
+        self.team = None
+        if devices is not None and len(devices) > 1:
+            self.team = _team.team_for(devices, self.transport)
+        elif devices is not None:
+            self.engine = default_engine(devices[0])
         draws = self._plan_draws(min(Tp, X.shape[1])).start()
-        self._mstream = None
-        ok = False
         try:
+            if self.team is not None:
+                # one host thread per device; the draws above are shared (drawn ONCE for all ranks)
+                return self.team.run(lambda rank, world, eng: self._run_device(
+                    X, Y, draws, eng, team=(rank, self.team)))
+            eng = self.engine or default_engine()
+            ok = False
             with eng.lock:                             # one analysis at a time per context (shared default engine)
                 try:
                     res = self._run_device(X, Y, draws, eng)
@@ -184,11 +206,12 @@ class _PLSCRun(object):
             return res
         finally:
             draws.thread.join()                        # never leave the generators running on an error
-            if self._mstream is not None:
-                self._mstream.close()
+            for ms in self._mstreams:
+                ms.close()
 
-    def _run_device(self, X, Y, draws, eng):
-        """The analysis after the draws started.  Everything B- or n_boot-sized stays on the device from the
+    def _run_device(self, X, Y, draws, eng, team=None):
+        """The analysis after the draws started (``team`` = (rank, Team): this thread is one rank of a
+        single-process team, team.py -- every rank runs its shard and the collective, rank 0 alone finishes).  Everything B- or n_boot-sized stays on the device from the
         H2D copy of X to the finished statistics: the sign convention, the original's scores, the resampling,
         THE one collective, percentile intervals, bootstrap ratios and the (T', L, n_boot) layout of the
         distributions all run there; what PLSResults holds comes back once, into page-locked memory that is
@@ -197,14 +220,15 @@ class _PLSCRun(object):
         import time
         import torch
         inp = self.inputs
-        phases = self.phases                           # dict: per-phase wall times (bench.py --mode analysis)
+        lead = team is None or team[0] == 0            # the rank that finishes the analysis and speaks for it
+        phases = self.phases if lead else None         # dict: per-phase wall times (bench.py --mode analysis)
 
         t_last = [time.perf_counter()]
 
         def tick(name):
             if phases is None:
                 return
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(eng.device)
             now = time.perf_counter()
             phases[name] = phases.get(name, 0.0) + 1e3 * (now - t_last[0])
             t_last[0] = now
@@ -233,7 +257,10 @@ class _PLSCRun(object):
         yw = d_yw.cpu().numpy()
         tick('decompose')
         emulate = self.emulate                         # (rank, world) of an emulated run on one GPU (bench.py)
-        rank, world = emulate if emulate is not None else parallel.rank_world()
+        if team is not None:
+            rank, world = team[0], team[1].world
+        else:
+            rank, world = emulate if emulate is not None else parallel.rank_world()
         rotate = bool(inp.get('rotate', True))
 
         # ---- resampling: this rank's contiguous shard of the permutations and chunk-cyclic share
@@ -256,8 +283,9 @@ class _PLSCRun(object):
             # split masks of this rank's permutations: produced block by block on their own host thread, from
             # now on, while the device runs the permutations and the bootstraps (permutation i uses
             # RandomState(i), base.py:705-708)
-            mstream = self._mstream = resampling.MaskStream(inp.groups, inp.n_cond, n_split, plo, phi,
-                                                            given=inp.get('_perm_splitsamples'))
+            mstream = resampling.MaskStream(inp.groups, inp.n_cond, n_split, plo, phi,
+                                            given=inp.get('_perm_splitsamples'))
+            self._mstreams.append(mstream)
         # the shard arrives in chunks: size the super-batch scratch once, for all of it
         eng.set_option('expect_resamples', max(phi - plo, sum(hi - lo for lo, hi in parallel.shard_chunks(
             n_boot_tot, rank, world)) if bstream is not None else 0))
@@ -288,18 +316,20 @@ class _PLSCRun(object):
         # host work that needs no device result runs while the device is busy: page-locked landing zones of
         # the results (56 us per MB to map), the index arrays in the reference's layout and dtype ((S, n)
         # C-contiguous int64), the host-sized scores of the original data
-        pin = {'xw': eng.pinned_like(d_xw), 'scores': eng.pinned_like(d_scores)}
-        if bstream is not None:
-            pin['bsr'], pin['se'] = eng.pinned_like(d_xw), eng.pinned_like(d_xw)
-            pin['dist'] = torch.empty((eng.Tp * L, n_boot_tot), dtype=torch.float64, pin_memory=True)
+        pin = {}
         permsamp = bootsamp = None
-        if pstream is not None:
-            permsamp = self.perm_given if self.perm_given is not None else pstream.samples
-        if bstream is not None:
-            bootsamp = self.boot_given if self.boot_given is not None else bstream.samples
+        if lead:
+            pin = {'xw': eng.pinned_like(d_xw), 'scores': eng.pinned_like(d_scores)}
+            if bstream is not None:
+                pin['bsr'], pin['se'] = eng.pinned_like(d_xw), eng.pinned_like(d_xw)
+                pin['dist'] = torch.empty((eng.Tp * L, n_boot_tot), dtype=torch.float64, pin_memory=True)
+            if pstream is not None:
+                permsamp = self.perm_given if self.perm_given is not None else pstream.samples
+            if bstream is not None:
+                bootsamp = self.boot_given if self.boot_given is not None else bstream.samples
         draws.join()
         for st in (pstream, bstream):
-            if st is not None:
+            if st is not None and lead:
                 st.warn()
         eng.sync()                 # numerical status of the launches above is raised HERE, for the batch that set it
         tick('bootstraps')
@@ -323,7 +353,7 @@ class _PLSCRun(object):
                             eng.mean_splits_into(vc, d_vc[a - plo:b - plo])
                     finally:
                         mstream.close()
-                    if mstream.duplicates:
+                    if mstream.duplicates and lead:
                         warnings.warn('WARNING: Duplicate split halves used.')
                 # ride along with the permutation block of the single collective
                 d_perm = torch.cat([d_perm, d_uc, d_vc], dim=1)
@@ -349,7 +379,9 @@ class _PLSCRun(object):
             totals.append(cv_splits.shape[1])
             tick('crossval')
         sums = [usum, usq] if usum is not None else []
-        full, summed = parallel.collect_device(slices, totals, sums, cyclic=cyclic, emulate=emulate)
+        full, summed = parallel.collect_device(slices, totals, sums, cyclic=cyclic, emulate=emulate, team=team)
+        if not lead:
+            return None                                # rank 0 holds everything the ranks computed: it finishes
         if usum is not None:
             usum, usq = summed
         tick('collective')
@@ -458,7 +490,8 @@ def behavioral_pls(X, Y, *, groups=None, n_cond=1, n_perm=5000, n_boot=5000, n_s
                    test_size=0.25, test_split=100, covariance=False, rotate=True, ci=95,
                    permsamples=None, bootsamples=None, seed=None, verbose=True, n_proc=None,
                    **kwargs):
-    """Behavioral PLS of X (S, B) against Y (S, T); see pyls.behavioral_pls."""
+    """Behavioral PLS of X (S, B) against Y (S, T); see pyls.behavioral_pls.  ``n_proc``: GPUs of this node to
+    shard the resamples over (module docstring); ``device_ids=[...]`` names them."""
     run = _PLSCRun('behavioral', np.asarray(X), np.asarray(Y), groups=groups, n_cond=n_cond,
                    n_perm=n_perm, n_boot=n_boot, n_split=n_split, test_size=test_size,
                    test_split=test_split, covariance=covariance, rotate=rotate, ci=ci,

@@ -61,7 +61,8 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
                    aggfunc='mean', permsamples=None, bootsamples=None, seed=None, verbose=True,
                    n_proc=None, **kwargs):
     """PLS regression of Y (S, T) or (S, T, C) on X (S, B) with SIMPLS; see
-    pyls.pls_regression."""
+    pyls.pls_regression.  ``n_proc``: GPUs of this node to shard the resamples over (one process, team.py);
+    ``device_ids=[...]`` names them."""
     from .engine import Engine
     X, Y = np.asarray(X), np.asarray(Y)
     if X.ndim != 2:
@@ -82,6 +83,8 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
     third = None                                   # (C, n_boot) third-axis resamples for 3-D Y
     bootsamples_out = None
     seed = parallel.shared_seed(seed)              # all ranks draw the same index arrays
+    device_ids = kwargs.pop('device_ids', None)
+    transport = kwargs.pop('_transport', 'auto')
     if Y.ndim == 3:
         # regression.py:208-235
         if not callable(aggfunc) and aggfunc not in _AGGFUNCS:
@@ -163,10 +166,25 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
                 raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'.format(S, bs.shape))
             bstream = resampling.IndexStream.of_array(check_index_array(bs, S))
     from .engine import default_engine
-    eng = kwargs.get('_engine') or default_engine()
+    from . import team as _team
+    eng = kwargs.get('_engine')
+    team = None
+    if eng is None and kwargs.get('_emulate') is None and parallel._dist() is None:
+        # n_proc workers of the reference (pyls/utils.py:252-279) = GPUs of this node, driven from this process
+        # (team.py: one context and one host thread per device, ONE all-gather)
+        devices = _team.resolve_devices(inputs.get('n_proc'), device_ids)
+        if devices is not None and len(devices) > 1:
+            team = _team.team_for(devices, transport)
+        elif devices is not None:
+            eng = default_engine(devices[0])
     draws = resampling.DrawThread(rs, jobs).start()
-    ok = False
     try:
+        if team is not None:
+            return team.run(lambda rank, world, e: _run_device(
+                X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples, bootsamples_out,
+                k, ci, e, kwargs.get('_phases') if rank == 0 else None, None, team=(rank, team)))
+        eng = eng or default_engine()
+        ok = False
         with eng.lock:                                 # one analysis at a time per context (shared default engine)
             try:
                 res = _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
@@ -182,16 +200,17 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
 
 
 def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,
-                bootsamples_out, k, ci, engine, phases=None, emulate=None):
+                bootsamples_out, k, ci, engine, phases=None, emulate=None, team=None):
     import time
     import torch
     S = len(X)
     t_last = [time.perf_counter()]
+    lead = team is None or team[0] == 0                 # the rank that finishes the analysis and speaks for it
 
     def tick(name):                                     # per-phase wall times (bench.py --mode analysis)
         if phases is None:
             return
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(engine.device)
         now = time.perf_counter()
         phases[name] = phases.get(name, 0.0) + 1e3 * (now - t_last[0])
         t_last[0] = now
@@ -234,7 +253,10 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     res['x_scores'] = x_scores
     # emulate = (rank, world) of an emulated run on one GPU (bench.py --mode analysis --emulate-world): own shard, the
     # all-gather replaced by a surrogate of the same volume (parallel._surrogate_gather)
-    rank, world = emulate if emulate is not None else parallel.rank_world()
+    if team is not None:
+        rank, world = team[0], team[1].world
+    else:
+        rank, world = emulate if emulate is not None else parallel.rank_world()
     tick('decompose')
 
     # this rank's shards (permutations contiguous, bootstraps chunk-cyclic), launched chunk by chunk as the index rows arrive; the
@@ -273,19 +295,21 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         eng.boot_finish(usum, usq)
     tick('bootstraps')
     permsamp = bootsamp = None
-    if pstream is not None:
+    if pstream is not None and lead:
         permsamp = np.asarray(permsamples) if permsamples is not None else pstream.samples
-    if bstream is not None:
+    if bstream is not None and lead:
         bootsamp = np.asarray(bootsamples) if bootsamples is not None else bstream.samples
     draws.join()
     for st in (pstream, bstream):
-        if st is not None:
+        if st is not None and lead:
             st.warn()
     eng.sync()                     # numerical status of the launches above is raised here
     slices = [t for t in (d_perm, d_yl) if t is not None]
     totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
     full, summed = parallel.collect_device(slices, totals, [usum, usq] if usum is not None else [], emulate=emulate,
-                                           cyclic=[len(slices) - 1] if d_yl is not None else [])
+                                           cyclic=[len(slices) - 1] if d_yl is not None else [], team=team)
+    if not lead:
+        return None                                     # rank 0 holds everything the ranks computed: it finishes
     full = [t.detach().cpu().numpy() for t in full]
     if usum is not None:
         usum, usq = summed

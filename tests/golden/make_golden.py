@@ -382,6 +382,45 @@ def main_reg_seed_envelope():
     print('wrote simpls_t20_seeds')
 
 
+def main_mpls_seed_envelope():
+    """Rank-deficient Procrustes (mean-centred PLS): the reference feeds the ARBITRARY null-space singular vectors
+    that randomized_svd returns into ``original.T @ permuted`` (compute.py:260), so the rotated bootstrap vectors
+    of ``BasePLS._single_boot`` (base.py:530-574) depend on the SVD seed.  Records what the reference returns for
+    analysis seeds 0 ... 5 on the first six bootstraps of two committed designs -- fixture ``mpls_3g2c_mc0`` (3 groups
+    x 2 conditions, 6 cells: 5 live LVs, one null) and ``mpls_2g2c_split`` (2 groups x 2 conditions) -- so that
+    the distance of the oracle / the device (which align live LVs with live LVs only) can be stated against the
+    reference's OWN seed-to-seed spread, per live LV (the ``simpls_t20_seeds`` pattern)."""
+    from pyls.types.meancentered import MeanCenteredPLS
+    out = {}
+    for tag, name in (('a', 'mpls_3g2c_mc0'), ('b', 'mpls_2g2c_split')):
+        g = np.load(os.path.join(HERE, name + '.npz'), allow_pickle=True)
+        X, groups, n_cond = g['X'], [int(v) for v in g['groups']], int(g['n_cond'])
+        mc = int(g['mean_centering']) if 'mean_centering' in g else 0
+        boots = g['ref_bootres__bootsamples'][:, :6]
+        pls = MeanCenteredPLS(X=X.copy(), groups=groups, n_cond=n_cond, mean_centering=mc, n_perm=0, n_boot=0,
+                              seed=1234, verbose=False)
+        res = pls.results
+        out[tag + '_fixture'] = np.asarray(name)
+        out[tag + '_X'], out[tag + '_groups'], out[tag + '_n_cond'] = X, np.asarray(groups), np.asarray(n_cond)
+        out[tag + '_mean_centering'] = np.asarray(mc)
+        out[tag + '_bootsamples'] = boots
+        out[tag + '_x_weights'], out[tag + '_singvals'] = res['x_weights'], res['singvals']
+        # the seed of an analysis reaches BOTH decompositions: the original's (run_pls: self.svd(X, Y, seed=self.rs),
+        # base.py:362-364 -- its null columns are part of ``original``) and every bootstrap's (base.py:503-506)
+        out[tag + '_seeds'] = np.arange(6)
+        for sd in range(6):
+            U0 = pls.svd(pls.inputs.X, pls.inputs.Y, groups=pls.dummy, seed=sd)[0]
+            ub = []
+            for i in range(boots.shape[1]):
+                _, U_boot = pls._single_boot(pls.inputs.X, pls.inputs.Y, boots[:, i], groups=pls.dummy,
+                                             original=U0, seed=sd)
+                ub.append(U_boot)
+            out['{}_ref_uboot_seed{}'.format(tag, sd)] = np.stack(ub, -1)          # (B, L, 6)
+            out['{}_ref_original_seed{}'.format(tag, sd)] = U0
+    np.savez_compressed(os.path.join(HERE, 'mpls_seeds.npz'), **out)
+    print('wrote mpls_seeds')
+
+
 def main_matimport():
     """pyls.matlab.import_matlab_result on the reference's own .mat fixtures
     (pyls/tests/data/*.mat, mirrored as data files under tests/golden/mat/):
@@ -427,6 +466,8 @@ if __name__ == '__main__':
         main_cv_cov()
     elif len(sys.argv) > 1 and sys.argv[1] == 'regseeds':
         main_reg_seed_envelope()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'mplsseeds':
+        main_mpls_seed_envelope()
     else:
         main()
         main_cv()
@@ -435,3 +476,4 @@ if __name__ == '__main__':
         main_matimport()
         main_reg_3d_nan()
         main_reg_seed_envelope()
+        main_mpls_seed_envelope()

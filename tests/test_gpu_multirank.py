@@ -100,7 +100,11 @@ dist.init_process_group('nccl', rank=rank, world_size=world,
 assert dist.get_backend() == 'nccl'
 import pypyls_amd as pls
 from pypyls_amd import parallel
-# the data collective is the C ABI's plsx_allgather on a communicator opened by plsx_comm_init ...
+# a pure query: nothing is opened behind the caller's back (ADVICE r5) ...
+assert parallel.collective_name().startswith('nccl all_gather_into_tensor')
+assert parallel.native_comm() is None
+# ... the data collective becomes the C ABI's plsx_allgather once every rank asks for it, explicitly
+assert parallel.open_native_comm() is not None, parallel._NATIVE['why']
 name = parallel.collective_name()
 assert name.startswith('plsx_allgather'), (name, parallel._NATIVE['why'])
 assert parallel.native_comm().comm_rank_world() == (rank, world)
@@ -110,7 +114,6 @@ res = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=4, see
 rr = pls.pls_regression(X, Y, n_components=3, n_perm=6, n_boot=5, seed=5, verbose=False)
 # ... and the process group's own all-gather (the fall-back) returns the same bits
 parallel.release_native_comm()
-parallel.USE_NATIVE_COLLECTIVE = False
 assert parallel.collective_name().startswith('nccl all_gather_into_tensor')
 res2 = pls.behavioral_pls(X, Y, n_perm=11, n_boot=9, n_split=3, test_split=4, seed=7, verbose=False)
 assert np.array_equal(res2.permres.perm_singval, res.permres.perm_singval)
@@ -212,12 +215,24 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env.pop('WORLD_SIZE', None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
            '--B', '20000', '--perms', '56', '--boots', '56', '--cpu-sample', '0']
-    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    small = ['--strong-resamples', '300', '--split-arrangements', '5', '--n-split', '12']
+    proc = subprocess.run(cmd + small, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
     line = [l for l in proc.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['value'] > 0 and out['value_dual'] > 0
     assert out['roofline']['bound'] in ('mfma', 'hbm') and out['config']['perms_per_step'] == 56
+    # the driver's one command per N also carries ONE sharded analysis (strong) and ONE sharded split-half leg, each
+    # with every rank's own times and the collective
+    sh = out['sharded']
+    assert 'error' not in sh['strong'] and 'error' not in sh['c4split'], sh
+    assert sh['strong']['scaling'] == 'strong' and sh['strong']['n_gpus'] == 2 and sh['strong']['value'] > 0
+    assert [p['rank'] for p in sh['strong']['per_rank_phases_ms']] == [0, 1]
+    assert all('bootstraps' in p and 'collective' in p for p in sh['strong']['per_rank_phases_ms'])
+    assert sh['strong']['collective_ms'] >= 0
+    assert sh['c4split']['scaling'] == 'strong' and sh['c4split']['value'] > 0
+    assert [p['rank'] for p in sh['c4split']['per_rank']] == [0, 1]
+    assert sh['c4split']['collective_ms_per_step'] >= 0 and '5 arrangements' in sh['c4split']['workload']
     # strong mode: one analysis split over the two ranks, index generation inside the clock
     proc = subprocess.run(cmd + ['--mode', 'strong', '--perms', '120', '--boots', '112', '--no-primal'], env=env,
                           capture_output=True, text=True, timeout=900)

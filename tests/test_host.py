@@ -250,7 +250,8 @@ def test_every_c_abi_entry_is_guarded_and_reads_no_environment():
     header = open(os.path.join(ROOT, 'include', 'plsx.h')).read()
     declared = set(re.findall(r'\b(plsx_\w+)\s*\(', header))
     trivial = {'plsx_version', 'plsx_max_tprime', 'plsx_last_error', 'plsx_num_lv', 'plsx_tprime',
-               'plsx_kernel_class_name', 'plsx_option_name', 'plsx_boot_route', 'plsx_split_route', 'plsx_comm_rank'}
+               'plsx_kernel_class_name', 'plsx_option_name', 'plsx_boot_route', 'plsx_split_route', 'plsx_comm_rank',
+               'plsx_comm_transport'}
     defined, unguarded = set(), []
     for i, ln in enumerate(lines):
         m = re.match(r'^(?:int|const char\*) (plsx_\w+)\(', ln)
@@ -317,3 +318,71 @@ def test_collect_device_emulated_world_orders_and_sums_like_a_real_one():
     t = torch.ones(3, 2, dtype=torch.float64)
     full, summed = parallel.collect_device([t], [3], [t])
     assert full[0] is t and summed[0] is t
+
+
+def test_team_collect_bookkeeping_on_cpu_threads():
+    """parallel.collect_device(team=(rank, team)) -- the collective of ONE process driving several device contexts
+    (pypyls_amd/team.py) -- with the device transport replaced by a host barrier: three rank threads with uneven
+    contiguous and chunk-cyclic shards get the full arrays in global order and the rank-ordered sums, like the gloo
+    ranks of test_collect_multiprocess_gloo do."""
+    import threading
+    import torch
+    from pypyls_amd import parallel
+
+    class Eng(object):
+        device = torch.device('cpu')
+
+    class HostTeam(object):
+        def __init__(self, world):
+            self.world, self.engines = world, [Eng() for _ in range(world)]
+            self.barrier, self.slots = threading.Barrier(world), [None] * world
+
+        def allgather(self, rank, flat):
+            self.slots[rank] = flat
+            self.barrier.wait()
+            out = torch.stack(list(self.slots))
+            self.barrier.wait()
+            return out
+
+    world, n_perm, n_boot = 3, 10, 11
+    perm = torch.arange(n_perm * 4, dtype=torch.float64).reshape(n_perm, 4)
+    dist = torch.arange(n_boot * 6, dtype=torch.float64).reshape(n_boot, 2, 3) * 0.5
+    team = HostTeam(world)
+    got = [None] * world
+
+    def work(r):
+        lo, hi = parallel.shard_bounds(n_perm, r, world)
+        rows = parallel.shard_rows(n_boot, r, world)
+        sums = [torch.full((5, 2), float(r + 1), dtype=torch.float64)]
+        got[r] = parallel.collect_device([perm[lo:hi], dist[rows]], [n_perm, n_boot], sums, cyclic=[1], team=(r, team))
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for r in range(world):
+        full, summed = got[r]
+        assert torch.equal(full[0], perm) and torch.equal(full[1], dist)
+        assert torch.equal(summed[0], torch.full((5, 2), 6.0, dtype=torch.float64))
+
+
+def test_resolve_devices_maps_n_proc_to_gpus(monkeypatch):
+    """n_proc (the reference's worker count, pyls/structures.py:162-168) -> device ordinals of a team."""
+    import torch
+    from pypyls_amd import team
+    from pypyls_amd.structures import PLSInputs
+    assert team.resolve_devices(4) is None or torch.cuda.is_available()      # no GPU here: the ordinary call
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 2)
+    assert team.resolve_devices(None) is None and team.resolve_devices(1) is None
+    assert team.resolve_devices(3) == [2, 3, 4]
+    assert team.resolve_devices(PLSInputs(n_proc='max').n_proc) == [2, 3, 4, 5, 6, 7, 0, 1]
+    assert team.resolve_devices(PLSInputs(n_proc=-1).n_proc) == [2, 3, 4, 5, 6, 7, 0, 1]
+    assert team.resolve_devices(2, device_ids=[5, 6, 7]) == [5, 6, 7]        # explicit ids win
+    assert team.resolve_devices(None, device_ids=[2]) is None                  # the current device: the ordinary call
+    assert team.resolve_devices(None, device_ids=[4]) == [4]
+    assert team.resolve_devices(None, device_ids=[0, 0]) == [0, 0]
+    import pytest
+    with pytest.raises(ValueError):
+        team.resolve_devices(None, device_ids=[8])

@@ -417,8 +417,8 @@ def main_mpls_seed_envelope():
                 ub.append(U_boot)
             out['{}_ref_uboot_seed{}'.format(tag, sd)] = np.stack(ub, -1)          # (B, L, 6)
             out['{}_ref_original_seed{}'.format(tag, sd)] = U0
-    np.savez_compressed(os.path.join(HERE, 'mpls_seeds.npz'), **out)
-    print('wrote mpls_seeds')
+    np.savez_compressed(os.path.join(HERE, 'seeds_mpls.npz'), **out)
+    print('wrote seeds_mpls')
 
 
 def main_matimport():

@@ -175,3 +175,59 @@ def test_config_c5_regression_1000x100000():
     bsr, se = ref.boot_rel(W0, us, uq, 3)
     assert_close(res.bootres.y_loadings_boot, np.stack(yl, -1), 1e-6, what='c5 y_loadings_boot')
     assert_close(res.bootres.x_weights_stderr, se, 1e-5, what='c5 x_weights_stderr')
+
+
+def test_config_c5_one_batch_of_2304_takes_the_timed_solver_instantiations():
+    """What bench.py times at c5 is ONE solver batch of 5000 resamples: above 2048 resamples per batch the solver runs
+    its three-waves-per-SIMD instantiations (k_sd_post0 / k_sd_step<0, false, 8> / k_sd_final with SD_RC = 8,
+    csrc/plsx_simpls.h), which the 2 + 2 test above never launches.  Here 8 distinct permutations and 8 distinct
+    bootstraps at the LITERAL c5 shape (1000 x 100 000, T = 20, k = 15) are submitted as ONE batch of 2304 each
+    (index columns replicated, the distinct ones spread over the batch incl. its first and last slot), and every
+    distinct resample is compared with the oracle's exact SIMPLS (regression.py:279-373): permutation statistic,
+    bootstrap y-loadings, and the accumulated weight sums (replication-weighted) through the quadratic-form closing
+    pass that such a series takes."""
+    from pypyls_amd.engine import Engine
+    from pypyls_amd import resampling as rsmp
+    S, B, T, k = 1000, 100000, 20, 15
+    X, Y = _synth(S, B, T, seed=2)
+    Xc = X - X.mean(axis=0, keepdims=True)
+    Yc = Y - Y.mean(axis=0, keepdims=True)
+    n, nd = 2304, 8
+    perms = rsmp.gen_permsamp([S], 1, nd, seed=4321, verbose=False)
+    boots = rsmp.gen_bootsamp([S], 1, nd, seed=4322, verbose=False)
+    which = np.arange(n) % nd                                   # slot -> distinct resample
+    which[[0, 1, n - 2, n - 1]] = [5, 2, 7, 0]                  # (the ends of the batch hold other ones than the cycle)
+    eng = Engine()
+    try:
+        eng.set_data_regression(Xc, Yc, k)
+        W, pct, cvec, yl = eng.simpls_decompose()
+        signs = np.sign(W[np.argmax(np.abs(W), axis=0), np.arange(k)])
+        signs[signs == 0] = 1.0
+        W = W * signs
+        eng.simpls_set_original(W)
+        big_p = np.asarray(eng.simpls_perm(perms[:, which]))              # (k, n)
+        us, uq, ylb = eng.simpls_boot(boots[:, which])
+        assert eng.boot_begin(n) == 1                                     # such a series takes the quadratic-form route
+        eng.boot_finish(eng._zeros((B, k)), eng._zeros((B, k)))
+        us, uq, ylb = us.cpu().numpy(), uq.cpu().numpy(), np.asarray(ylb)
+    finally:
+        eng.close()
+    # replicated slots agree among themselves (same rows -> same result, whatever wave and slot ran them) ...
+    for d in range(nd):
+        cols = np.flatnonzero(which == d)
+        assert np.ptp(big_p[:, cols], axis=1).max() <= 1e-12 * np.abs(big_p[:, cols]).max(), d
+        assert np.ptp(ylb[..., cols], axis=-1).max() <= 1e-11 * np.abs(ylb[..., cols]).max(), d
+    # ... and with the oracle
+    want_us, want_uq = np.zeros((B, k)), np.zeros((B, k))
+    for d in range(nd):
+        first = int(np.flatnonzero(which == d)[0])
+        want = ref.regression_single_perm(Xc, Yc, perms[:, d], k)
+        assert_close(big_p[:, first], want, 1e-6, what='c5 permutation {} (slot {}) vs oracle'.format(d, first))
+        ylw, w = ref.regression_single_boot(Xc, Yc, boots[:, d], k, W)
+        assert_close(ylb[..., first], ylw, 1e-6, what='c5 bootstrap {} y-loadings vs oracle'.format(d))
+        mult = int(np.sum(which == d))
+        want_us += mult * w
+        want_uq += mult * w ** 2
+    for c in range(k):
+        assert_close(us[:, c], want_us[:, c], 1e-6, what='c5 sum of weights, component {}'.format(c))
+        assert_close(uq[:, c], want_uq[:, c], 1e-6, what='c5 sum of squared weights, component {}'.format(c))

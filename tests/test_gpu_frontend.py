@@ -377,7 +377,7 @@ def test_results_are_bit_reproducible(method, monkeypatch):
 @pytest.mark.parametrize('two_pass', [False, True])
 def test_mpls_bootstrap_sums_against_the_reference_seed_envelope(tag, two_pass):
     """The device's rotated bootstrap vectors of mean-centred PLS (rank-deficient Procrustes) against
-    tests/golden/mpls_seeds.npz: the reference's own BasePLS._single_boot for analysis seeds 0 .. 5 on six bootstraps
+    tests/golden/seeds_mpls.npz: the reference's own BasePLS._single_boot for analysis seeds 0 .. 5 on six bootstraps
     (tests/test_oracle.py::test_mpls_oracle_against_the_reference_seed_envelope has the numbers).  The kernels return
     the SUM of the rotated vectors: it equals the oracle's sum tightly on the live LVs (both routes of the unscaled
     bootstrap) and lies as close to every reference run as the reference runs lie to each other."""

@@ -268,9 +268,9 @@ def test_simpls_t20_oracle_within_the_reference_seed_envelope():
 
 
 def _mpls_envelope(tag):
-    """Reference runs (analysis seeds 0 .. 5) of tests/golden/mpls_seeds.npz for design ``tag`` and the oracle's
+    """Reference runs (analysis seeds 0 .. 5) of tests/golden/seeds_mpls.npz for design ``tag`` and the oracle's
     rotated bootstrap vectors of the same six bootstraps; distances are column-wise relative 2-norms."""
-    g = load_golden('mpls_seeds')
+    g = load_golden('seeds_mpls')
     X, groups = g[tag + '_X'], [int(v) for v in g[tag + '_groups']]
     spec = ref.Spec('meancentered', groups, int(g[tag + '_n_cond']), mean_centering=int(g[tag + '_mean_centering']))
     seeds = [int(s) for s in g[tag + '_seeds']]
@@ -293,7 +293,7 @@ def test_mpls_oracle_against_the_reference_seed_envelope(tag):
     """Rank-deficient Procrustes (mean-centred PLS, BASELINE config c3's method) has no 1e-5-reproducible reference
     answer: compute.procrustes (compute.py:260) multiplies the NULL-space singular vectors randomized_svd happens to
     return -- of the original and of every bootstrap -- into the polar factor, so BasePLS._single_boot
-    (base.py:530-574) returns rotated vectors that move with the analysis seed.  tests/golden/mpls_seeds.npz holds
+    (base.py:530-574) returns rotated vectors that move with the analysis seed.  tests/golden/seeds_mpls.npz holds
     the reference's own runs for seeds 0 .. 5 on two committed designs (3 groups x 2 conditions: 3 live LVs of 6;
     2 x 2: 2 live of 4): they differ from EACH OTHER by up to 2.2 % / 6.2 % / 18 % (design a, per live LV) and 2.9 % /
     4.5 % (design b).  The oracle (procrustes_live: live LVs against live LVs only -- the deliberate deviation of

@@ -221,7 +221,7 @@ int plsx_split_half_batch_y(plsx_ctx* ctx, const int32_t* d_perm_idx, const doub
                             double* d_ucorr, double* d_vcorr, void* stream);
 
 /* Route of the LAST split-half pass on this context: 1 = one reader pass over the raw first-half sums of the splits
- * (behavioral PLS in correlation mode with T' = 17..20, 33..36 or 49..52 and <= 7 cells: the compact cross-product
+ * (behavioral PLS in correlation mode with T' = 17 .. 52 (every value), L = T' and <= 7 cells: the compact cross-product
  * blocks store C_1 once per split and ONE kernel rebuilds both z-scored halves from it and forms both products),
  * 0 = both halves written and read by two kernels (every other shape / mode, and option "split_two_readers").
  * Same statistics to rounding either way. */

@@ -62,6 +62,18 @@ def lib():
     L = _find()
     c_int, c_char_p, c_void_p, c_size_t = ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t
     P = ctypes.POINTER
+    # hid_t is 64-bit from HDF5 1.10 on; a 1.8.x library returns 32-bit ids whose upper halves would be read as
+    # garbage: H5get_libversion needs no hid_t, so ask it first and refuse anything older
+    try:
+        ver = [ctypes.c_uint(0) for _ in range(3)]
+        L.H5get_libversion.argtypes, L.H5get_libversion.restype = [P(ctypes.c_uint)] * 3, c_int
+        ok = L.H5get_libversion(*[ctypes.byref(v) for v in ver]) >= 0
+    except AttributeError:
+        ok = False
+    version = tuple(v.value for v in ver) if ok else (0, 0, 0)
+    if version < (1, 10, 0):
+        raise ImportError('the HDF5 C library found is {} -- this binding needs >= 1.10 (64-bit hid_t)'.format(
+            '.'.join(str(v) for v in version) if ok else 'of unknown version'))
     sig = {
         'H5open': ([], c_int), 'H5Eset_auto2': ([hid_t, c_void_p, c_void_p], c_int),
         'H5get_libversion': ([P(ctypes.c_uint)] * 3, c_int),
@@ -93,8 +105,13 @@ def lib():
         'H5Adelete': ([hid_t, c_char_p], c_int),
     }
     for name, (args, res) in sig.items():
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:                             # e.g. a build without the deprecated H5Gget_*_by_idx /
+            raise ImportError('the HDF5 C library {} lacks {} (built without deprecated symbols?)'.format(   # H5Dvlen_reclaim
+                '.'.join(str(v) for v in version), name))
         fn.argtypes, fn.restype = args, res
+    L._version = version
     if L.H5open() < 0:
         raise ImportError('H5open failed')
     L.H5Eset_auto2(0, None, None)                          # errors are reported through return values -> H5Error

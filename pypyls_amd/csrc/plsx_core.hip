@@ -423,8 +423,20 @@ try {
     if (method == PLSX_REGRESSION && simpls_step_lds_bytes(S, T, ncomp) > 158 * 1024)
         return fail(ctx, PLSX_ERR_UNSUPPORTED,
                     "SIMPLS: S / T too large for the on-chip component step (8 (T^2 + S) bytes must fit 158 KB)");
-    if ((long long)B + Tp > 2000000LL)
-        return fail(ctx, PLSX_ERR_UNSUPPORTED, "more than 2,000,000 feature columns (32-bit buffer offsets)");
+    // 32-bit buffer offsets (the kernels address one resample's cross-covariance matrix R_r, T'pp x Bpad doubles, through a
+    // buffer resource whose byte offsets are 31 bits; offsets beyond read as zero): ONE R_r must stay below 2 GB.  That is
+    // the real limit -- it allows 5.1 million features at the headline T' = 50 and 16 million for mean-centred designs,
+    // and it refuses e.g. T' = 200 with 1.4 million features, which the old flat "2,000,000 columns" rule let through
+    // to kernels that would have read zeros.  (Columns alone: a 4-row k-step of X, 32 Bpad bytes, fits up to 67 million.)
+    {
+        const long long tpp = ((long long)Tp + 3) / 4 * 4, bpad = ((long long)B + std::min(Tp, B) + 127) / 128 * 128;
+        if (tpp * bpad * 8 >= (1LL << 31) || bpad > 16000000LL) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "T' x B too large: one cross-covariance matrix (%lld x %lld doubles = %.2f GB) must "
+                     "stay below 2 GB, and B below 16,000,000 (32-bit buffer offsets)", tpp, bpad, tpp * bpad * 8 / 1073741824.0);
+            return fail(ctx, PLSX_ERR_UNSUPPORTED, msg);
+        }
+    }
     if (Tp > PLSX_MAX_TP || J > PLSX_MAX_CELLS || (method != PLSX_BEHAVIORAL && Tp > PLSX_BLOCK_TP)) {
         char msg[200];
         snprintf(msg, sizeof msg, "stacked dimension T' = %d (cells J = %d) exceeds the limit (T' <= %d for "

@@ -242,7 +242,7 @@ static __global__ void k_scale_cols(const double* __restrict__ in, long long cou
 // out[r][c] = in[r][c] - mean_c in[r][:]   (rows x cols row-major, one block per row, fixed summation order; in == out
 // allowed): the column-centred original x_weights of the SIMPLS sign alignment, held transposed (k, B)
 static __global__ __launch_bounds__(256)
-void k_center_rows(const double* __restrict__ in, long long cols, double* __restrict__ out)
+void k_center_rows(const double* in, long long cols, double* out)       // in == out allowed: no __restrict__
 {
     __shared__ double red[256];
     const double* src = in + (size_t)blockIdx.x * cols;

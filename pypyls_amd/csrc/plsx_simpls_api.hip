@@ -86,13 +86,12 @@ int run_simpls_dual(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, b
         LAUNCHCHK();
     }
     const size_t lds_step = (size_t)wpb * step_wave;
-    // (the Jacobi solve above T = 32 always takes the any-T instantiation with 36 rows per lane: a 16-rows-per-lane
-    // variant returned a wrong leading vector at T = 44 / 56 > S, see k_sd_step; the path is rare -- T > S, T > 64 or
-    // the option -- and not time critical)
+    // (Jacobi eigen-solve -- T > S, T > 64 or the option: rare, not time critical -- per class of T like everything else;
+    // the 16-rows-per-lane instantiation of 32 < T <= 64 is back, see k_sd_step)
     const bool jac = a.jacobi_eig || T > 64 || T > S;
     void (*step_kernel)(SdArgs) =
         jac ? (T <= 32 ? (big ? k_sd_step<0, true, 8> : k_sd_step<0, true, 16>)
-                       : k_sd_step<2, true, 16>)
+                       : (T <= 64 ? k_sd_step<1, true, 16> : k_sd_step<2, true, 16>))
             : (T <= 32 ? (big ? k_sd_step<0, false, 8> : k_sd_step<0, false, 16>)
                        : (big ? k_sd_step<1, false, 8> : k_sd_step<1, false, 16>));
     HIPCHK(set_lds(step_kernel, lds_step));

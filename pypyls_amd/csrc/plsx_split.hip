@@ -7,8 +7,8 @@ using namespace plsxi;
 
 namespace plsxi {
 
-// The one-pass reader (plsx_splitfused.h) is instantiated for ceil(T'/4) = 5, 9, 13 row blocks (T' = 17..20, 33..36,
-// 49..52 -- the headline shape is 50): there the last tile of T' and of L always holds <= 4 live rows / LVs.
+// The one-pass reader (plsx_splitfused.h) is instantiated for every ceil(T'/4) = 5 .. 13 row blocks, i.e. T' = 17 .. 52
+// (the headline shape is 50; nine instantiations), L = T', <= 7 cells, one R slot below 2 GB.
 bool split_reader_ok(const plsx_ctx* ctx)
 {
     const int nb = ctx->nks_t;

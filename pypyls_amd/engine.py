@@ -316,9 +316,10 @@ class Engine(object):
         self._check(self.lib.plsx_allgather(self.ctx, send.data_ptr(), recv.data_ptr(), nbytes, self._stream()))
         return recv
 
-    def numeric_report(self, warn=True):
+    def numeric_report(self, warn=True, stacklevel=2):
         """(refined, unrefined) resample counts of graded spectra since the last call
-        (plsx_numeric_report); warns when some could not be refined."""
+        (plsx_numeric_report); warns when some could not be refined (``stacklevel``: whose line the warning
+        is attributed to)."""
         a, b = ctypes.c_longlong(), ctypes.c_longlong()
         self._check(self.lib.plsx_numeric_report(self.ctx, ctypes.byref(a), ctypes.byref(b)))
         self.refined += a.value
@@ -329,21 +330,36 @@ class Engine(object):
                           'value that could not be refined on the cross-covariance matrix (a dual-space route on '
                           'data whose original spectrum was not graded): singular values below ~6e-6 of the largest may differ from an '
                           'SVD of R by more than 1e-5 relative'.format(b.value), GradedSpectrumWarning,
-                          stacklevel=2)
+                          stacklevel=stacklevel)
         return a.value, b.value
 
     def end_analysis(self, warn=True):
-        """Close an analysis on this context, on the success AND on the error path of a front-end: forget the
-        announced shard size (``expect_resamples``) and drain the refined / unrefined counters so that neither
-        leaks into the next call.  ``warn``: raise the GradedSpectrumWarning of this analysis (success path);
-        after an exception the counters are dropped silently and a failing device is not allowed to mask the
-        exception that is already propagating."""
+        """Close an analysis on this context, on the success AND on the error path of a front-end (it runs inside
+        their ``finally``): forget the announced shard size (``expect_resamples``) and drain the refined / unrefined
+        counters so that neither leaks into the next call.  It never warns itself -- a warning raised inside a
+        ``finally`` would, under ``-W error``, replace the computed result: the count of unrefined
+        decompositions is returned and the front-end warns AFTER its try block (:func:`warn_unrefined`), attributed to
+        the user's call.  ``warn=False`` (an exception is already propagating): a failing device is not allowed to
+        mask it."""
         try:
             self.set_option('expect_resamples', 0)
-            self.numeric_report(warn=warn)
+            return self.numeric_report(warn=False)[1]
         except PlsxError:
             if warn:
                 raise
+            return 0
+
+    @staticmethod
+    def warn_unrefined(n, stacklevel=3):
+        """The GradedSpectrumWarning of an analysis that left ``n`` decompositions unrefined, attributed to the
+        caller of the public front-end (stacklevel 3 from behavioral_pls / meancentered_pls / pls_regression's own
+        frame: warn_unrefined <- run / pls_regression <- the public function <- USER)."""
+        if n:
+            import warnings
+            warnings.warn('{} decomposition(s) had live latent variables below 1e-5 of the largest singular '
+                          'value that could not be refined on the cross-covariance matrix (a dual-space route on '
+                          'data whose original spectrum was not graded): singular values below ~6e-6 of the largest may differ from an '
+                          'SVD of R by more than 1e-5 relative'.format(n), GradedSpectrumWarning, stacklevel=stacklevel)
 
     # -- data -------------------------------------------------------------
     def set_data(self, X, Y, cell_of_row, n_groups, n_cond, method, mean_centering=0,

@@ -34,17 +34,34 @@ from .structures import PLSInputs, PLSResults
 _METHOD_CODE = {'behavioral': 0, 'meancentered': 1}
 
 # The B- and n_boot-sized result arrays (x_weights, bootstrap ratios / standard errors, the (T', L, n_boot)
-# distributions: 440 MB at the headline shape) land in page-locked memory and PLSResults holds numpy VIEWS of it: no
-# second pass over them (55 ms of the call's 41 ms fixed cost would come back), but that memory stays locked for as
-# long as the caller keeps the results.  A caller that stores many results (a parameter sweep) sets this to True --
-# or copies what it keeps with np.array(...) -- and gets ordinary arrays.
-COPY_RESULTS_OUT_OF_PINNED = False
+# distributions: 440 MB at the headline shape) LAND in page-locked memory (57 GB/s instead of 8 - 10 pageable) that is
+# mapped while the device resamples.  PLSResults holds ordinary numpy arrays, like the reference's: they are copied out
+# of the page-locked landing zone by a few host threads (a memcpy releases the GIL; 440 MB in ~10 ms, one thread needs
+# 55) and the landing zone is released with the call -- a caller that keeps many results (sweeps, per-subject loops)
+# does not accumulate unswappable memory.  ``COPY_RESULTS_OUT_OF_PINNED = False`` hands out views of the
+# page-locked memory instead (no second pass; that memory then stays locked for as long as the results live).
+COPY_RESULTS_OUT_OF_PINNED = True
+_COPY_THREADS = 8
+_COPY_POOL = None
 
 
 def _host_array(t):
     a = t.numpy()
-    return np.array(a) if COPY_RESULTS_OUT_OF_PINNED else a
-
+    if not COPY_RESULTS_OUT_OF_PINNED:
+        return a
+    out = np.empty_like(a)
+    n = a.size
+    if n * a.itemsize < (8 << 20) or not a.flags.c_contiguous:
+        np.copyto(out, a)
+        return out
+    global _COPY_POOL
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix='plsx-copy')
+    src, dst = a.reshape(-1), out.reshape(-1)
+    step = -(-n // _COPY_THREADS)
+    list(_COPY_POOL.map(lambda lo: np.copyto(dst[lo:lo + step], src[lo:lo + step]), range(0, n, step)))
+    return out
 
 
 def _as_float_array(A, name):
@@ -187,22 +204,28 @@ class _PLSCRun(object):
             self.engine = default_engine(devices[0])
         draws = self._plan_draws(min(Tp, X.shape[1])).start()
         try:
+            unrefined = 0
             if self.team is not None:
                 # one host thread per device; the draws above are shared (drawn ONCE for all ranks)
-                return self.team.run(lambda rank, world, eng: self._run_device(
+                res = self.team.run(lambda rank, world, eng: self._run_device(
                     X, Y, draws, eng, team=(rank, self.team)))
-            eng = self.engine or default_engine()
-            ok = False
-            with eng.lock:                             # one analysis at a time per context (shared default engine)
-                try:
-                    res = self._run_device(X, Y, draws, eng)
-                    ok = True
-                finally:
-                    # state that must not leak into the next analysis on this context, whatever happened:
-                    # the announced shard size and the refined / unrefined counters (a stale count would raise
-                    # a spurious GradedSpectrumWarning -- and stale scratch sizing -- in an unrelated call)
-                    if getattr(eng, 'ctx', None):
-                        eng.end_analysis(warn=ok)
+                unrefined = self.team.unrefined
+            else:
+                eng = self.engine or default_engine()
+                ok = False
+                with eng.lock:                         # one analysis at a time per context (shared default engine)
+                    try:
+                        res = self._run_device(X, Y, draws, eng)
+                        ok = True
+                    finally:
+                        # state that must not leak into the next analysis on this context, whatever happened:
+                        # the announced shard size and the refined / unrefined counters (a stale count would raise
+                        # a spurious GradedSpectrumWarning -- and stale scratch sizing -- in an unrelated call)
+                        if getattr(eng, 'ctx', None):
+                            unrefined = eng.end_analysis(warn=ok) or 0
+            # outside every finally: under -W error the warning must not replace a computed result half-way, and it
+            # is attributed to the user's call (run <- behavioral_pls / meancentered_pls <- USER)
+            Engine.warn_unrefined(unrefined, stacklevel=4)
             return res
         finally:
             draws.thread.join()                        # never leave the generators running on an error
@@ -289,10 +312,18 @@ class _PLSCRun(object):
         # the shard arrives in chunks: size the super-batch scratch once, for all of it
         eng.set_option('expect_resamples', max(phi - plo, sum(hi - lo for lo, hi in parallel.shard_chunks(
             n_boot_tot, rank, world)) if bstream is not None else 0))
+        # verbose=True: the reference's tqdm bars (pyls/utils.py:128-152), counting resamples the DEVICE has finished;
+        # they only appear when a leg is still running after 2 s (progress.py)
+        from .progress import Bar
+        show = lead and bool(inp.get('verbose')) and (emulate is None) and (parallel.rank_world()[0] == 0)
+        bars = []
         if pstream is not None:
             d_perm = eng._zeros((phi - plo, L))
+            bar = Bar('Running permutations', phi - plo, show, eng.device)
+            bars.append(bar)
             for a, b in pstream.chunks(plo, phi, first=first):
                 eng.perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - plo:b - plo], rotate=rotate)
+                bar.queued(b - a)
         elif ystack is not None:
             host = eng.perm_ystack(ystack[plo:phi], rotate=rotate) if phi > plo else np.zeros((L, 0))
             d_perm = torch.from_numpy(np.ascontiguousarray(host.T)).to(eng.device)
@@ -307,10 +338,15 @@ class _PLSCRun(object):
             # the series of this rank's bootstraps: where the weights are linear in the (unscaled) features the
             # library accumulates S x S moments per batch and passes the features once, in boot_finish
             eng.boot_begin(sum(hi - lo for lo, hi in bchunks))
+            bar = Bar('Running bootstraps', sum(hi - lo for lo, hi in bchunks), show, eng.device)
+            bars.append(bar)
             for blo, bhi in bchunks:
                 for a, b in bstream.chunks(blo, bhi, first=first):
                     eng.boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                   d_dist[off + a - blo:off + b - blo])
+                    for done in bars:
+                        done.poll()
+                    bar.queued(b - a)
                 off += bhi - blo
             eng.boot_finish(usum, usq)
         # host work that needs no device result runs while the device is busy: page-locked landing zones of
@@ -331,7 +367,13 @@ class _PLSCRun(object):
         for st in (pstream, bstream):
             if st is not None and lead:
                 st.warn()
-        eng.sync()                 # numerical status of the launches above is raised HERE, for the batch that set it
+        for bar in bars:
+            bar.watch()
+        try:
+            eng.sync()             # numerical status of the launches above is raised HERE, for the batch that set it
+        finally:
+            for bar in bars:
+                bar.close()
         tick('bootstraps')
         orig_splits = self.orig_splits
         slices, totals = [], []
@@ -341,6 +383,7 @@ class _PLSCRun(object):
                 # masks arrive, the mean over splits (base.py:770) taken on the device; nothing visits the host
                 d_uc, d_vc = eng._zeros((phi - plo, L)), eng._zeros((phi - plo, L))
                 if mstream is not None:
+                    sbar = Bar('Running split-half resampling of the permutations', phi - plo, show, eng.device)
                     try:
                         for a, b, masks in mstream:
                             dm = torch.from_numpy(masks).to(eng.device)
@@ -351,7 +394,11 @@ class _PLSCRun(object):
                             eng.split_half_into(dp, dm, uc, vc, ystack_dev=dy)
                             eng.mean_splits_into(uc, d_uc[a - plo:b - plo])
                             eng.mean_splits_into(vc, d_vc[a - plo:b - plo])
+                            sbar.queued(b - a)
+                        sbar.watch()
+                        eng.sync()
                     finally:
+                        sbar.close()
                         mstream.close()
                     if mstream.duplicates and lead:
                         warnings.warn('WARNING: Duplicate split halves used.')

@@ -179,21 +179,25 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
             eng = default_engine(devices[0])
     draws = resampling.DrawThread(rs, jobs).start()
     try:
+        unrefined = 0
         if team is not None:
-            return team.run(lambda rank, world, e: _run_device(
+            res = team.run(lambda rank, world, e: _run_device(
                 X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples, bootsamples_out,
                 k, ci, e, kwargs.get('_phases') if rank == 0 else None, None, team=(rank, team)))
-        eng = eng or default_engine()
-        ok = False
-        with eng.lock:                                 # one analysis at a time per context (shared default engine)
-            try:
-                res = _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
-                                  bootsamples, bootsamples_out, k, ci, eng, kwargs.get('_phases'),
-                                  kwargs.get('_emulate'))
-                ok = True
-            finally:
-                if getattr(eng, 'ctx', None):
-                    eng.end_analysis(warn=ok)          # nothing of this call leaks into the next one on the context
+            unrefined = team.unrefined
+        else:
+            eng = eng or default_engine()
+            ok = False
+            with eng.lock:                             # one analysis at a time per context (shared default engine)
+                try:
+                    res = _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples,
+                                      bootsamples, bootsamples_out, k, ci, eng, kwargs.get('_phases'),
+                                      kwargs.get('_emulate'))
+                    ok = True
+                finally:
+                    if getattr(eng, 'ctx', None):      # nothing of this call leaks into the next one on the context
+                        unrefined = eng.end_analysis(warn=ok) or 0
+        Engine.warn_unrefined(unrefined, stacklevel=3)  # (outside the finally; attributed to the caller of pls_regression)
         return res
     finally:
         draws.thread.join()
@@ -264,13 +268,18 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     d_perm = d_yl = usum = usq = None
     n_perm_tot = pstream.n if pstream is not None else 0
     n_boot_tot = bstream.n if bstream is not None else 0
+    from .progress import Bar                            # verbose=True: the reference's bars (pyls/utils.py:128-152)
+    show = lead and bool(inputs.get('verbose')) and emulate is None and parallel.rank_world()[0] == 0
+    bars = []
     if pstream is not None:
         lo, hi = parallel.shard_bounds(n_perm_tot, rank, world)
         d_perm = eng._zeros((hi - lo, k))
+        bars.append(Bar('Running permutations', hi - lo, show, eng.device))
         # (a solver batch is a latency chain of ~3 k launches whatever its size: few, large chunks -- the first 2048 rows
         # are drawn in 5 ms)
         for a, b in pstream.chunks(lo, hi, first=2048):
             eng.simpls_perm_into(eng.rows_tensor(pstream.rows[a:b]), d_perm[a - lo:b - lo])
+            bars[-1].queued(b - a)
     tick('permutations')
     if bstream is not None:
         bchunks = parallel.shard_chunks(n_boot_tot, rank, world)     # chunk-cyclic share of the bootstraps
@@ -278,6 +287,7 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
         d_yl = eng._zeros((sum(hi - lo for lo, hi in bchunks), T, k))
         off = 0
         eng.boot_begin(sum(hi - lo for lo, hi in bchunks))     # (plsx_boot_begin: the feature pass may move to boot_finish)
+        bars.append(Bar('Running bootstraps', sum(hi - lo for lo, hi in bchunks), show, eng.device))
         for lo, hi in bchunks:
             for a, b in bstream.chunks(lo, hi, first=2048 if third is None else 256, grow=4 if third is None else 1,
                                        limit=None if third is None else 256):
@@ -291,6 +301,9 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
                     ystack = eng._dev(ystack, np.float64)
                 eng.simpls_boot_into(eng.rows_tensor(bstream.rows[a:b]), usum, usq,
                                      d_yl[off + a - lo:off + b - lo], ystack=ystack)
+                for done in bars:
+                    done.poll()
+                bars[-1].queued(b - a)
             off += hi - lo
         eng.boot_finish(usum, usq)
     tick('bootstraps')
@@ -303,7 +316,13 @@ def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsa
     for st in (pstream, bstream):
         if st is not None and lead:
             st.warn()
-    eng.sync()                     # numerical status of the launches above is raised here
+    for bar in bars:
+        bar.watch()
+    try:
+        eng.sync()                 # numerical status of the launches above is raised here
+    finally:
+        for bar in bars:
+            bar.close()
     slices = [t for t in (d_perm, d_yl) if t is not None]
     totals = [n for t, n in ((d_perm, n_perm_tot), (d_yl, n_boot_tot)) if t is not None]
     full, summed = parallel.collect_device(slices, totals, [usum, usq] if usum is not None else [], emulate=emulate,

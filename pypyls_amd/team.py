@@ -96,6 +96,7 @@ class Team(object):
         self._recv = [None] * self.world
         self._streams = [None] * self.world
         self._rc = 0
+        self.unrefined = 0
         self.run_lock = threading.Lock()                # one analysis at a time per team
 
     def collective_name(self):
@@ -151,6 +152,7 @@ class Team(object):
         import torch
         errors = [None] * self.world
         out = [None] * self.world
+        counts = [0] * self.world
 
         def work(rank):
             eng = self.engines[rank]
@@ -163,7 +165,7 @@ class Team(object):
                         ok = True
                     finally:
                         if getattr(eng, 'ctx', None):
-                            eng.end_analysis(warn=ok and rank == 0)
+                            counts[rank] = eng.end_analysis(warn=ok) or 0
             except BaseException as exc:                # noqa: BLE001 -- re-raised by the caller's thread
                 errors[rank] = exc
                 self.barrier.abort()
@@ -188,6 +190,7 @@ class Team(object):
             for e in errors:
                 if e is not None:
                     raise e
+            self.unrefined = sum(counts)                    # graded resamples no rank could refine: the front-end warns
         return out[0]
 
 

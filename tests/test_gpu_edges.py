@@ -436,3 +436,72 @@ def test_a_failed_analysis_leaves_no_state_on_the_shared_engine(monkeypatch):
         assert np.array_equal(out[i].singvals, a.singvals)
         assert np.array_equal(out[i].bootres.x_weights_normed, a.bootres.x_weights_normed)
         assert np.array_equal(out[i].permres.perm_singval, a.permres.perm_singval)
+
+
+def test_more_than_two_million_features():
+    """the flat "B <= 2,000,000" rule is gone.  What bounds the shape is one cross-covariance
+    matrix R_r (T'pp x Bpad doubles) below 2 GB -- the kernels address it through 31-bit buffer offsets --, i.e. 5.1
+    million features at the headline T' = 50 (voxel-wise data at 1 mm has ~1.8 M), 16 M for mean-centred designs.
+    The reference takes any shape (pyls/base.py:254-283).  At B = 2.6 M an oracle pass costs 15 s per decomposition,
+    so the check is in two steps: the device's cross-covariance matrices against the oracle's xcorr on column windows
+    (first, middle, LAST columns), then everything downstream of R -- singular values, weights, permutation null on
+    both routes, rotated bootstrap sums -- against numpy working on the device's own R of the same resample.  SIMPLS:
+    the original fit against the oracle.  And the shape the old rule let through to kernels that would have read zeros
+    (T' = 200 x 1.4 M features: 2.2 GB per R_r) is refused loudly."""
+    from pypyls_amd.engine import Engine, PlsxError
+    from pypyls_amd import resampling as rsmp
+    rs = np.random.RandomState(5)
+    S, B, T = 30, 2600000, 3
+    X = rs.randn(S, B)
+    Y = rs.randn(S, T) + 0.5 * X[:, :T]
+    perms = rsmp.gen_permsamp([S], 1, 2, seed=1, verbose=False)
+    boots = rsmp.gen_bootsamp([S], 1, 2, seed=2, verbose=False)
+    eng = Engine()
+    try:
+        eng.set_data(X, Y, rsmp.cell_of_row([S], 1), 1, 1, 0)
+        ident = np.arange(S)[:, None]
+        R0 = eng.crosscov(n=1)[0]
+        Rp = eng.crosscov(ysrc=perms)
+        Rb = eng.crosscov(xsrc=boots, ysrc=boots)
+        for lo in (0, B // 2 - 500, B - 1000):
+            w = slice(lo, lo + 1000)
+            assert_close(R0[:, w], ref.xcorr(X[:, w], Y), 1e-10, what='R columns %d..' % lo)
+            assert_close(Rp[1][:, w], ref.xcorr(X[:, w], Y[perms[:, 1]]), 1e-10, what='permuted R columns %d..' % lo)
+            assert_close(Rb[0][:, w], ref.xcorr(X[boots[:, 0]][:, w], Y[boots[:, 0]]), 1e-10, what='bootstrap R columns %d..' % lo)
+        xw, sv, yw = eng.decompose()
+        U0, d0, V0t = np.linalg.svd(R0.T, full_matrices=False)           # R^T = U d V^T, as compute.svd (compute.py:10-52)
+        assert_close(sv, d0, 1e-10, what='singvals')
+        sg = np.sign(np.sum(xw * U0, axis=0))
+        assert_close(xw * sg, U0, 1e-8, what='x_weights')
+        assert np.abs(xw[-5:]).max() > 0                                 # the last columns are real columns
+        eng.set_original(xw, sv, yw)
+        pd_ = eng.perm(perms, rotate=True)
+        eng.set_perm_path(False)
+        pf = eng.perm(perms, rotate=True)
+        eng.set_perm_path(True)
+        assert_close(pd_, pf, 1e-9, what='permutation null: S x S route vs feature pass')
+        for i in range(2):
+            Up, dp, Vpt = np.linalg.svd(Rp[i].T, full_matrices=False)
+            rot = ref.procrustes(yw, Vpt.T, np.diag(dp))
+            assert_close(pf[:, i], np.sqrt(np.sum(rot ** 2, axis=0)), 1e-9, what='permutation %d' % i)
+        usum, usq, dist = eng.boot(boots)
+        want = np.zeros((B, T))
+        for i in range(2):
+            Ub, db, _ = np.linalg.svd(Rb[i].T, full_matrices=False)
+            want += ref.procrustes(xw, Ub, np.diag(db))
+        assert_close(usum.cpu().numpy(), want, 1e-8, what='sum of rotated bootstrap weights')
+    finally:
+        eng.close()
+    import pypyls_amd as pls
+    rr = pls.pls_regression(X, Y, n_components=2, n_perm=0, n_boot=0, verbose=False)
+    fit = ref.simpls(X - X.mean(0), Y - Y.mean(0), 2)
+    sg = np.sign(np.sum(rr.x_weights * fit['x_weights'], axis=0))
+    assert_close(rr.x_weights * sg, fit['x_weights'], 1e-7, what='simpls x_weights')
+    assert_close(rr.varexp, fit['pctvar'][1], 1e-8, what='simpls pctvar')
+    pls.release_default_engine()
+    eng = Engine()
+    try:
+        with pytest.raises(PlsxError, match='below 2 GB'):
+            eng.set_data(np.zeros((10, 1400000)), np.zeros((10, 200)), np.zeros(10, np.int32), 1, 1, 0)
+    finally:
+        eng.close()

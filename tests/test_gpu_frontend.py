@@ -284,22 +284,26 @@ def test_default_engine_is_reused_and_rebinding_changes_nothing():
     assert engine.default_engine() is not eng
 
 
-def test_results_can_be_copied_out_of_page_locked_memory(monkeypatch):
-    """the large result arrays are views of page-locked staging buffers by default (no second pass over
-    440 MB at the headline shape); plsc.COPY_RESULTS_OUT_OF_PINNED = True returns ordinary arrays with the same
-    values."""
+def test_results_are_ordinary_arrays_by_default(monkeypatch):
+    """PLSResults holds ordinary numpy arrays (copied out of the page-locked landing zone by a few host
+    threads), so that a caller who keeps many results does not accumulate unswappable memory;
+    plsc.COPY_RESULTS_OUT_OF_PINNED = False hands out views of the page-locked buffers instead (no second pass).  Same
+    values either way, also for arrays large enough to take the threaded copy (> 8 MB)."""
     import pypyls_amd as pls
     from pypyls_amd import plsc
     rs = np.random.RandomState(8)
-    X, Y = rs.randn(40, 700), rs.randn(40, 3)
-    kw = dict(n_perm=10, n_boot=12, test_split=0, seed=2, verbose=False)
-    a = pls.behavioral_pls(X, Y, **kw)
-    monkeypatch.setattr(plsc, 'COPY_RESULTS_OUT_OF_PINNED', True)
+    X, Y = rs.randn(40, 400000), rs.randn(40, 3)
+    kw = dict(n_perm=4, n_boot=4, test_split=0, seed=2, verbose=False)
+    assert plsc.COPY_RESULTS_OUT_OF_PINNED is True
     b = pls.behavioral_pls(X, Y, **kw)
+    monkeypatch.setattr(plsc, 'COPY_RESULTS_OUT_OF_PINNED', False)
+    a = pls.behavioral_pls(X, Y, **kw)
+    assert b.x_weights.nbytes > (8 << 20)
     for key in ('x_weights',):
         assert np.array_equal(a[key], b[key]) and b[key].flags.owndata and not a[key].flags.owndata
     for key in ('x_weights_normed', 'x_weights_stderr'):
         assert np.array_equal(a.bootres[key], b.bootres[key]) and b.bootres[key].flags.owndata
+    assert np.array_equal(a.bootres.y_loadings_boot, b.bootres.y_loadings_boot)
 
 
 @pytest.mark.parametrize('n_perm,n_boot', [(0, 0), (7, 0), (0, 7)])
@@ -410,3 +414,27 @@ def test_mpls_bootstrap_sums_against_the_reference_seed_envelope(tag, two_pass):
     # ORIGINAL (fixed within an analysis, different between seeds) does not
     assert np.all(od[live] <= 2.0 * spread[live]), (od[live], spread[live])
     assert spread[live].max() > 5e-3                       # percents: there is no 1e-5 reference answer to pin here
+
+
+def test_verbose_prints_the_references_progress_bars(monkeypatch, capfd):
+    """``verbose=True`` (the reference's default) drives tqdm bars named like the reference's (pyls/utils.py:128-152,
+    pyls/base.py:484, 641): here they count resamples the DEVICE has finished (an event per asynchronous chunk) and
+    appear only when a leg runs longer than progress.DELAY_S -- forced to 0 for the test.  verbose=False: silence."""
+    import pypyls_amd as pls
+    from pypyls_amd import progress
+    rs = np.random.RandomState(3)
+    X, Y = rs.randn(60, 4000), rs.randn(60, 4)
+    monkeypatch.setattr(progress, 'DELAY_S', 0.0)
+    quiet = pls.behavioral_pls(X, Y, n_perm=600, n_boot=600, n_split=2, test_split=0, seed=5, verbose=False)
+    err = capfd.readouterr().err
+    assert 'Running' not in err
+    loud = pls.behavioral_pls(X, Y, n_perm=600, n_boot=600, n_split=2, test_split=0, seed=5, verbose=True)
+    err = capfd.readouterr().err
+    for name in ('Running permutations', 'Running bootstraps', 'Running split-half'):
+        assert name in err, (name, err[-400:])
+    assert '600/600' in err
+    assert np.array_equal(quiet.permres.perm_singval, loud.permres.perm_singval)
+    assert np.array_equal(quiet.bootres.x_weights_normed, loud.bootres.x_weights_normed)
+    rr = pls.pls_regression(X, Y, n_components=2, n_perm=300, n_boot=300, seed=5, verbose=True)
+    err = capfd.readouterr().err
+    assert 'Running permutations' in err and 'Running bootstraps' in err and rr.varexp.shape == (2,)

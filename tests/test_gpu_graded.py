@@ -338,3 +338,36 @@ def test_wide_graded_spectrum_is_refined(S, B, T, groups, n_cond, kind, ratio):
     got_ratio, worst = run_case(X, Y, groups, n_cond, 'behavioral', n=3 if T == 600 else 4, null_lvs=None)
     print('wide T\' = {}: target {:g}, d1/dL = {:.3g}, worst per-LV error {:.2e}'.format(
         len(groups) * n_cond * T, ratio, got_ratio, worst))
+
+
+def test_graded_warning_points_at_the_callers_line_and_is_raised_after_the_work():
+    """the GradedSpectrumWarning of a public call is attributed to the USER's line (not engine.py) and is
+    raised after the front-end's try / finally -- under ``-W error`` it surfaces as an ordinary exception from the
+    call, the context is closed properly (no stale counters, lock released) and the next call works."""
+    import warnings
+    import pypyls_amd as pls
+    from pypyls_amd.engine import Engine, GradedSpectrumWarning
+    S, B, T = 80, 3000, 8
+    rs = np.random.RandomState(101)
+    X = rs.randn(S, B)
+    Y = graded_behaviours(rs, S, T, 3e5, 'mix')
+    eng = Engine(options={'no_refine': 1})
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            res = pls.behavioral_pls(X, Y, n_perm=4, n_boot=4, test_split=0, seed=3, verbose=False, _engine=eng)
+        mine = [w for w in rec if issubclass(w.category, GradedSpectrumWarning)]
+        assert len(mine) == 1 and mine[0].filename == __file__, [(w.filename, w.lineno) for w in mine]
+        assert res.singvals.shape == (T,)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error', GradedSpectrumWarning)
+            with pytest.raises(GradedSpectrumWarning):
+                pls.behavioral_pls(X, Y, n_perm=4, n_boot=4, test_split=0, seed=3, verbose=False, _engine=eng)
+            assert eng.numeric_report(warn=False) == (0, 0)          # drained by the call that raised
+            assert eng.lock.acquire(blocking=False)
+            eng.lock.release()
+            eng.set_option('no_refine', 0)
+            ok = pls.behavioral_pls(X, Y, n_perm=4, n_boot=4, test_split=0, seed=3, verbose=False, _engine=eng)
+        assert np.allclose(ok.singvals[:3], res.singvals[:3], rtol=1e-8)
+    finally:
+        eng.close()

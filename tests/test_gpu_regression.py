@@ -300,3 +300,33 @@ def test_wide_y_takes_the_solver_instantiations_of_its_class(S, B, T, k):
     assert_close(res['permres']['perm_singval'], want['permres']['perm_singval'], 1e-6, what='perm')
     for key in ('x_weights_normed', 'x_weights_stderr', 'y_loadings_boot'):
         assert_close(res['bootres'][key], want['bootres'][key], 1e-5, what='oracle ' + key)
+
+
+@pytest.mark.parametrize('S,B,T,k', [(90, 400, 40, 5), (120, 300, 64, 4), (40, 120, 44, 3), (50, 200, 56, 3), (70, 260, 33, 3)])
+def test_jacobi_eigen_solve_of_the_middle_class_of_t(S, B, T, k):
+    """32 < T <= 64 with the one-sided Jacobi eigen-solve (k_sd_step<1, true, 16>: wave_jacobi_cols<16>, 16 rows per
+    lane) -- taken when T > S (rank-deficient H: the shapes on which round 5 saw a wrong leading vector, T = 44 / 56)
+    and, forced with the ``simpls_jacobi`` option, on full-rank problems -- against the oracle's exact SIMPLS
+    (regression.py:56-186) and against the leading-eigenpair solver where that one applies.  tools/jacobi16_probe.py
+    is the wider version (seven code-generation variants, bit-identical to the 36-row instantiation)."""
+    from pypyls_amd.engine import Engine
+    rs = np.random.RandomState(S + T)
+    X = rs.randn(S, B) + rs.rand(1, B)
+    Y = rs.randn(S, T)
+    Y[:, :8] += 0.5 * X[:, :8]
+    Xc, Yc = X - X.mean(0), Y - Y.mean(0)
+    fit = ref.simpls(Xc, Yc, k)
+    got = {}
+    for forced in ((1,) if T > S else (1, 0)):
+        eng = Engine(options={'simpls_jacobi': forced})
+        try:
+            eng.set_data_regression(Xc, Yc, k)
+            W, pct, cvec, yl = eng.simpls_decompose()
+        finally:
+            eng.close()
+        sg = np.sign(np.sum(W * fit['x_weights'], axis=0))
+        assert_close(W * sg, fit['x_weights'], 1e-9, what='x_weights (jacobi forced = {})'.format(forced))
+        assert_close(pct, fit['pctvar'][1], 1e-10, what='pctvar (jacobi forced = {})'.format(forced))
+        got[forced] = W * sg
+    if 0 in got:
+        assert_close(got[1], got[0], 1e-10, what='Jacobi vs leading-eigenpair solver')

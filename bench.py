@@ -1009,12 +1009,34 @@ def measure(args, wl, env):
                 tot = 2 * kk * per_launch('k_sd_step') + 2 * per_launch('k_sd_init') + 2 * per_launch('k_sd_post0') \
                     + per_launch('k_sd_final')
                 if tot > 0:
+                    # ALGORITHMIC bytes of the solver: what must cross HBM per resample given that
+                    # nothing S x T-sized fits a wave's share of LDS (13 KB at three waves per SIMD; Z0 alone is 8 S T =
+                    # 160 KB) while the shared Y (160 KB for ALL resamples) and K stay in L2:
+                    #   k_sd_init   writes the S x (T + 1) operand of GEMM 0, reads the index row       8 S (T + 2)
+                    #   k_sd_post0  reads GEMM 0's S x (T + 1), writes Z0 (T-major) and K cnt            8 S (2 T + 2)
+                    #   k_sd_step c reads Z0 once, every earlier basis pair (t_j, K beta_j) once, K beta_{c-1}; writes
+                    #               t_c, beta_c and the scattered GEMM operand                            8 S (T + 2 c + 4)
+                    #   k_sd_final  (bootstraps) reads the k score vectors, writes the k scattered weights 8 S (2 k)
+                    # one pass over each array that is needed -- DESIGN.md section 5 ("c5 solver: a denominator")
+                    Ss, Tt = wl.S, wl.T
+                    steps_b = sum(8.0 * Ss * (Tt + 2 * c + 4) for c in range(kk))
+                    per_perm = 8.0 * Ss * (Tt + 2) + 8.0 * Ss * (2 * Tt + 2) + steps_b
+                    per_boot = per_perm + 8.0 * Ss * 2 * kk
+                    alg = wl.perms * per_perm + wl.boots * per_boot
                     roof['solver_hbm'] = {'kernels': 'k_sd_init / k_sd_post0 / k_sd_step / k_sd_final', 'bound': 'hbm',
                                           'traffic_per_step': tot, 'ms_per_step': sd_ms,
                                           'achieved': tot / (sd_ms * 1e-3) / 1e12, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s',
-                                          'frac': tot / (sd_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-                                          'note': 'counter traffic of full-size launches (5000 resamples) from the '
-                                                  'traffic file; valid for the literal 5000 + 5000 step only'}
+                                          'frac': alg / (sd_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                                          'frac_counter_traffic': tot / (sd_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                                          'algorithmic_bytes_per_step': alg,
+                                          'algorithmic_bytes_per_resample': {'permutation': per_perm, 'bootstrap': per_boot},
+                                          'waste_ratio': tot / alg,
+                                          'work': 'per resample: 8 S (T + 2) [init] + 8 S (2 T + 2) [post0] + sum_c 8 S (T + 2 c + 4) '
+                                                  '[step c: Z0 once, every earlier basis pair once] (+ 8 S 2 k [final, bootstraps])',
+                                          'note': 'frac = algorithmic bytes / solver time / 8 TB/s (a true roofline fraction); '
+                                                  'frac_counter_traffic = PMC bytes of full-size launches (5000 resamples) from the '
+                                                  'traffic file / time / peak = bandwidth utilisation; waste_ratio = counter / '
+                                                  'algorithmic.  Valid for the literal 5000 + 5000 step only'}
         except Exception:
             pass
     roof['measured_mfma_f64_peak_tflops'] = eng.mfma_f64_peak()

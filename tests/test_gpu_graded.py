@@ -357,7 +357,8 @@ def test_graded_warning_points_at_the_callers_line_and_is_raised_after_the_work(
             warnings.simplefilter('always')
             res = pls.behavioral_pls(X, Y, n_perm=4, n_boot=4, test_split=0, seed=3, verbose=False, _engine=eng)
         mine = [w for w in rec if issubclass(w.category, GradedSpectrumWarning)]
-        assert len(mine) == 1 and mine[0].filename == __file__, [(w.filename, w.lineno) for w in mine]
+        import os
+        assert len(mine) == 1 and os.path.samefile(mine[0].filename, __file__), [(w.filename, w.lineno) for w in mine]
         assert res.singvals.shape == (T,)
         with warnings.catch_warnings():
             warnings.simplefilter('error', GradedSpectrumWarning)

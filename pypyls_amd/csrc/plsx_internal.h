@@ -40,13 +40,13 @@ enum {
     OPT_NO_REFINE = 0, OPT_MIN_BATCH, OPT_INBLOCK_MOMENTS, OPT_NO_COMPACT_BOOT, OPT_COMPACT_BOOT_ALWAYS,
     OPT_SEPMOM_ALWAYS, OPT_NO_GRAM4, OPT_UROT_GENERIC, OPT_UROT_NO_TAIL4, OPT_NO_FIXED_X, OPT_NO_DUAL_PERM,
     OPT_TWO_PASS_BOOT, OPT_SPLIT_INBLOCK, OPT_NO_SPLIT_FUSE, OPT_SPLIT_TWO_READERS, OPT_EXPECT_RESAMPLES,
-    OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_COUNT
+    OPT_SIMPLS_JACOBI, OPT_PERCENTILE_SORT, OPT_QUAD_SUMS, OPT_SPLIT_READER8, OPT_COUNT
 };
 static const char* const kOptionNames[OPT_COUNT] = {
     "no_refine", "min_batch", "inblock_moments", "no_compact_boot", "compact_boot_always",
     "sepmom_always", "no_gram4", "urot_generic", "urot_no_tail4", "no_fixed_x", "no_dual_perm",
     "two_pass_boot", "split_inblock", "no_split_fuse", "split_two_readers", "expect_resamples",
-    "simpls_jacobi", "percentile_sort", "quad_sums"};
+    "simpls_jacobi", "percentile_sort", "quad_sums", "split_reader8"};
 
 struct plsx_ctx {
     int device = 0;

@@ -111,6 +111,15 @@ int launch_split_fused(plsx_ctx* ctx, const SplitFusedArgs& a, int blocks, size_
     return 0;
 }
 
+template <int NB>
+int launch_split_fused12(plsx_ctx* ctx, const SplitFusedArgs& a, int blocks, size_t lds, hipStream_t st)
+{
+    HIPCHK(set_lds(k_split_fused12<NB>, lds));
+    hipLaunchKernelGGL((k_split_fused12<NB>), dim3(blocks), dim3(768), lds, st, a);
+    LAUNCHCHK();
+    return 0;
+}
+
 int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mvd, hipStream_t st, int* nchunk_u)
 {
     const int NB = ctx->nks_t, LT = ctx->LT, J = ctx->J, Tp = ctx->Tp, rows = ceil_div(Tp, 16) * 16;
@@ -146,8 +155,11 @@ int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mv
     {
         KTimer tm(ctx, KC_UCORR, st);
         int rc;
+        // 12-wave block with dedicated construction waves (round 6); option "split_reader8": the round-5 block whose
+        // matrix waves build the tiles themselves (the A/B, and the same results to the last bit: same products, same order)
+        const bool twelve = !ctx->opt[OPT_SPLIT_READER8];
         switch (NB) {
-#define SFCASE(N) case N: rc = launch_split_fused<N>(ctx, a, blocks, lds, st); break;
+#define SFCASE(N) case N: rc = twelve ? launch_split_fused12<N>(ctx, a, blocks, lds, st) : launch_split_fused<N>(ctx, a, blocks, lds, st); break;
             SFCASE(5) SFCASE(6) SFCASE(7) SFCASE(8) SFCASE(9) SFCASE(10) SFCASE(11) SFCASE(12) SFCASE(13)
 #undef SFCASE
             default: return fail(ctx, PLSX_ERR_STATE, "split reader: unsupported T'");

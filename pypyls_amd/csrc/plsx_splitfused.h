@@ -350,3 +350,303 @@ void k_split_fused(SplitFusedArgs a)
     }
     split_fused_wave<NB, 4>(a, sm_sf, chunk, sp);
 }
+
+// ---- round 6: the same reader as a 12-wave block with DEDICATED construction waves ---------------------------------
+// In the 8-wave block every matrix wave also builds its share of the next tile, and the block runs in lock step: the
+// construction of a stage (constant reads, ~40 fp64 operations, five LDS stores, lgkmcnt(0)) sits on the critical path
+// of every wave once per stage -- measured 7700 cycles per stage against 5408 of matrix issue (0.70 busy).  Here waves
+// 8 .. 11 (one per SIMD) do nothing but stream C_1 / R_p / the column constants and build the NEXT tile while waves
+// 0 .. 3 (cross-Gram, 4x4x4) and 4 .. 7 (projections, 16x16x4) only read operands and multiply; the per-stage barrier
+// stays (it hands the double buffer over) but what a matrix wave does between two barriers is matrix issue only.
+// Three waves per SIMD: 168 VGPRs per wave -- the Gram waves read their R_p operands one row block at a time (the
+// 8-wave kernel keeps up to five in registers), the builders carry two (row, column pair) items per thread.
+template <int NB, int ROLE>      // ROLE 0..3: Gram wave; 4: projection wave (unit = wave - 4); 5: construction wave
+__device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp)
+{
+    constexpr int ROWS = 4 * NB, P = SF_PITCH, TILE = ROWS * P + SF_TILE_PAD, LT = (NB + 3) / 4;
+    constexpr bool TAIL = (NB % 4) == 1;
+    constexpr int LF = TAIL ? LT - 1 : LT;
+    constexpr int NPAIR = (LT + 1) / 2;
+    constexpr int NTHR = 768, NBLD = 256, NITEM = (ROWS * 8 + NBLD - 1) / NBLD;
+    static_assert(TILE % 8 == 4, "tile stride must be 4 mod 8 doubles (bank layout of the Gram operand reads)");
+    static_assert(NITEM <= 2, "two (row, column pair) items per construction thread cover T' <= 64");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int J = a.J, nseg = 9 * J, ldr = a.ldr;
+    double* sD = sm;                                    // [2][5][TILE]: D_1a, D_2a, D_1b, D_2b, R_p
+    double* sC = sD + 2 * 5 * TILE;                     // [2][nseg][16]
+    double* sM = sC + 2 * nseg * 16;                    // [NB][NPAIR][64][2]
+    double* sR = sM + (size_t)NB * NPAIR * 128;         // [ROWS][10] row constants
+    const int sa = 2 * sp, sb = min(2 * sp + 1, a.nsplits - 1);
+    const bool has_b = 2 * sp + 1 < a.nsplits;
+    const int col0 = chunk * a.stages_per_chunk * SF_COLS;
+    const int nst = min(a.stages_per_chunk, (a.B - col0 + SF_COLS - 1) / SF_COLS);
+
+    for (int idx = tid; idx < NB * NPAIR * 64; idx += NTHR) {
+        const int ln = idx & 63, pp = (idx >> 6) % NPAIR, ks = idx / (64 * NPAIR);
+        const int toff_l = (ln & 48) + (ln & 3) - ln;
+        d2 v = (d2){0.0, 0.0};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = 2 * pp + e;
+            if (t < LF) v[e] = a.Mfrag[(ks * LT + t) * 64 + ln];
+            else if (TAIL && t == LF) v[e] = a.Mfrag[(ks * LT + LF) * 64 + ln + toff_l];
+        }
+        *reinterpret_cast<d2*>(sM + 2 * (size_t)idx) = v;
+    }
+    for (int idx = tid; idx < ROWS * 10; idx += NTHR) {
+        const int r = idx / 10, c = idx - r * 10;
+        const int sp_ = c < 4 ? sa : sb, cc_ = c < 4 ? c : (c < 8 ? c - 4 : 4);
+        sR[idx] = (c == 9) ? 0.0 : a.rowc[((size_t)(c == 8 ? sa : sp_) * a.rows_rc + r) * 5 + cc_];
+    }
+    const d2 zero2 = (d2){0.0, 0.0};
+
+    if constexpr (ROLE == 5) {
+        // ================= construction waves =================
+        const int b = tid - 512;                        // 0 .. 255
+        bool on[NITEM];
+        int row[NITEM], jr[NITEM];
+        const int cp = b & 7;
+        const double* pa[NITEM];
+        const double* pb[NITEM];
+        const double* pr[NITEM];
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            const int item = b + it * NBLD;
+            on[it] = item < ROWS * 8;
+            row[it] = on[it] ? item >> 3 : 0;
+            jr[it] = min(row[it] / max(a.T, 1), J - 1);
+            const size_t roff = (size_t)row[it] * ldr + col0 + 2 * cp;
+            pa[it] = a.C1 + (size_t)sa * a.strideR + roff;
+            pb[it] = a.C1 + (size_t)sb * a.strideR + roff;
+            pr[it] = a.Rp + roff;
+        }
+        const bool lthread = b < nseg * 8;
+        const int seg = lthread ? b >> 3 : 0;
+        const double* pc;
+        if (seg < 8 * J) {
+            const int sl = seg / (4 * J), rem = seg - sl * 4 * J, j = rem >> 2, kk = rem & 3;
+            pc = a.cc + ((size_t)(sl ? sb : sa) * J + j) * 4 * ldr + (size_t)kk * ldr + col0 + 2 * cp;
+        } else {
+            pc = a.sFt + (size_t)(seg - 8 * J) * ldr + col0 + 2 * cp;
+        }
+        auto write_const = [&](int buf, d2 v) {
+            if (lthread) *reinterpret_cast<d2*>(sC + (size_t)buf * nseg * 16 + seg * 16 + 2 * cp) = v;
+        };
+        auto ld2 = [&](const double* p, int st, bool ok) -> d2 {
+            return (ok && st < nst) ? *reinterpret_cast<const d2*>(p + (size_t)st * SF_COLS) : zero2;
+        };
+        auto construct = [&](int st, int it, d2 ca, d2 cb, d2 rp) {
+            if (!on[it]) return;
+            const int buf = st & 1, r = row[it], j = jr[it];
+            const double* cs = sC + (size_t)buf * nseg * 16 + 2 * cp;
+            const d2 u1a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 0) * 16);
+            const d2 v1a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 1) * 16);
+            const d2 u2a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 2) * 16);
+            const d2 v2a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 3) * 16);
+            const d2 u1b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 0) * 16);
+            const d2 v1b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 1) * 16);
+            const d2 u2b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 2) * 16);
+            const d2 v2b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 3) * 16);
+            const d2 sf = *reinterpret_cast<const d2*>(cs + (8 * J + j) * 16);
+            const d2 r01 = *reinterpret_cast<const d2*>(sR + r * 10), r23 = *reinterpret_cast<const d2*>(sR + r * 10 + 2);
+            const d2 r45 = *reinterpret_cast<const d2*>(sR + r * 10 + 4), r67 = *reinterpret_cast<const d2*>(sR + r * 10 + 6);
+            const double sy1a = r01[0], al1a = r01[1], sy2a = r23[0], al2a = r23[1];
+            const double sy1b = r45[0], al1b = r45[1], sy2b = r67[0], al2b = r67[1], rc4 = sR[r * 10 + 8];
+            const int gc = col0 + st * SF_COLS + 2 * cp;
+            d2 o1a, o2a, o1b, o2b, orp;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool lv = gc + e < a.B;                    // features only: score / padding columns stay out
+                const double cf = rp[e] * (rc4 * sf[e]);          // C_full
+                o1a[e] = lv ? (ca[e] - sy1a * u1a[e]) * (al1a * v1a[e]) : 0.0;
+                o2a[e] = lv ? ((cf - ca[e]) - sy2a * u2a[e]) * (al2a * v2a[e]) : 0.0;
+                o1b[e] = lv ? (cb[e] - sy1b * u1b[e]) * (al1b * v1b[e]) : 0.0;
+                o2b[e] = lv ? ((cf - cb[e]) - sy2b * u2b[e]) * (al2b * v2b[e]) : 0.0;
+                orp[e] = lv ? rp[e] : 0.0;
+            }
+            double* d = sD + (size_t)buf * 5 * TILE + r * P + 2 * cp;
+            *reinterpret_cast<d2*>(d) = o1a;
+            *reinterpret_cast<d2*>(d + TILE) = o2a;
+            *reinterpret_cast<d2*>(d + 2 * TILE) = o1b;
+            *reinterpret_cast<d2*>(d + 3 * TILE) = o2b;
+            *reinterpret_cast<d2*>(d + 4 * TILE) = orp;
+        };
+        // prologue: stage 0 built, stage 1 in registers, constants of stages 1 (LDS) and 2 (registers)
+        write_const(0, ld2(pc, 0, lthread));
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it)
+            construct(0, it, ld2(pa[it], 0, on[it]), ld2(pb[it], 0, on[it]), ld2(pr[it], 0, on[it]));
+        write_const(1, ld2(pc, 1, lthread));
+        d2 ra_[NITEM], rb_[NITEM], rr_[NITEM];
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it) {
+            ra_[it] = ld2(pa[it], 1, on[it]); rb_[it] = ld2(pb[it], 1, on[it]); rr_[it] = ld2(pr[it], 1, on[it]);
+        }
+        d2 cv = ld2(pc, 2, lthread);
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            if (st + 1 < nst) {
+#pragma unroll
+                for (int it = 0; it < NITEM; ++it) construct(st + 1, it, ra_[it], rb_[it], rr_[it]);
+            }
+            write_const(st & 1, cv);
+#pragma unroll
+            for (int it = 0; it < NITEM; ++it) {
+                ra_[it] = ld2(pa[it], st + 2, on[it]); rb_[it] = ld2(pb[it], st + 2, on[it]); rr_[it] = ld2(pr[it], st + 2, on[it]);
+            }
+            cv = ld2(pc, st + 3, lthread);
+            // the LDS stores above must have landed; the global loads just issued must NOT be waited for
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    } else {
+        // ================= matrix waves =================
+        constexpr int NP2 = NB * NB;
+        constexpr int P0 = (ROLE < 4) ? NP2 * ROLE / 4 : 0, P1 = (ROLE < 4) ? NP2 * (ROLE + 1) / 4 : 1;
+        constexpr int NACC = P1 - P0, N0 = P0 / NB, N1 = (P1 - 1) / NB, NU = N1 - N0 + 1;
+        double acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+        double ss[LT][4], sq[LT][4], sx[LT][4];
+#pragma unroll
+        for (int l = 0; l < LT; ++l)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ss[l][i] = sq[l][i] = sx[l][i] = 0.0;
+        __syncthreads();
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const double* D = sD + (size_t)(st & 1) * 5 * TILE;
+            if constexpr (ROLE < 4) {
+                const int k = lane >> 4, blk = (lane >> 2) & 3, i = lane & 3;
+                const double* xa = D + blk * TILE + i * P + 2 * k;
+                const double* ua = D + 4 * TILE + i * P + 2 * k;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    d2 x[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) x[q] = *reinterpret_cast<const d2*>(xa + 4 * q * P + 8 * h);
+#pragma unroll
+                    for (int n = 0; n < NU; ++n) {      // one R_p row block at a time: 4 live registers instead of 4 NU
+                        const d2 u = *reinterpret_cast<const d2*>(ua + 4 * (N0 + n) * P + 8 * h);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+#pragma unroll
+                            for (int q = 0; q < NB; ++q) {
+                                const int p = (N0 + n) * NB + q;
+                                if (p >= P0 && p < P1) acc[p - P0] = mfma_f64_4x4(x[q][e], u[e], acc[p - P0]);
+                            }
+                    }
+                }
+            } else {
+                const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+                const int k = lane >> 4, n = lane & 15, half = n >> 3, c8 = n & 7;
+                const double* ba = D + (2 * s + half) * TILE + k * P + 8 * cg + c8;
+                d4 e[LF > 0 ? LF : 1];
+                double et = 0.0;
+#pragma unroll
+                for (int l = 0; l < LF; ++l) e[l] = (d4){0.0, 0.0, 0.0, 0.0};
+                const double* mA = sM + 2 * lane;
+                // operands of k-step ks + 1 are fetched while k-step ks multiplies, and no further ahead: left to
+                // itself hipcc hoists every read of the stage to its top (17 ds_read_b128 + 13 ds_read_b64 = 94
+                // registers) and spills the running sums at three waves per SIMD
+                d2 av[NPAIR];
+                double bq = ba[0];
+#pragma unroll
+                for (int pp = 0; pp < NPAIR; ++pp) av[pp] = *reinterpret_cast<const d2*>(mA + (size_t)pp * 128);
+#pragma unroll
+                for (int ks = 0; ks < NB; ++ks) {
+                    d2 nav[NPAIR];
+                    double nb = 0.0;
+                    if (ks + 1 < NB) {
+                        nb = ba[4 * (ks + 1) * P];
+#pragma unroll
+                        for (int pp = 0; pp < NPAIR; ++pp)
+                            nav[pp] = *reinterpret_cast<const d2*>(mA + (size_t)((ks + 1) * NPAIR + pp) * 128);
+                    }
+#pragma unroll
+                    for (int pp = 0; pp < NPAIR; ++pp)
+#pragma unroll
+                        for (int ee = 0; ee < 2; ++ee) {
+                            const int t = 2 * pp + ee;
+                            if (t < LF) e[t] = mfma_f64(av[pp][ee], bq, e[t]);
+                            else if (TAIL && t == LF) et = mfma_f64_4x4(av[pp][ee], bq, et);
+                        }
+                    asm volatile("" ::: "memory");
+                    if (ks + 1 < NB) {
+                        bq = nb;
+#pragma unroll
+                        for (int pp = 0; pp < NPAIR; ++pp) av[pp] = nav[pp];
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < LF; ++l)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double x = e[l][i], y = dpp_f64<0x128>(x);      // row_ror:8 -> the other half's value
+                        ss[l][i] += x; sq[l][i] += x * x; sx[l][i] += x * y;
+                    }
+                if constexpr (TAIL) {
+                    const double x = et, y = dpp_f64<0x128>(x);
+                    ss[LT - 1][0] += x; sq[LT - 1][0] += x * x; sx[LT - 1][0] += x * y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+
+        // ---- results (formats of the 8-wave kernel) ----
+        if constexpr (ROLE < 4) {
+            const int oi = lane >> 4, ob = (lane >> 2) & 3, oj = lane & 3;
+            if (ob >= 2 && !has_b) return;
+            const int slot = 4 * sp + ob;
+            double* out = a.gpart + (((size_t)chunk * 2 * a.nsplits + slot) * 2) * 4096 + 4096;
+#pragma unroll
+            for (int n = 0; n < NU; ++n)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int p = (N0 + n) * NB + q;
+                    if (p >= P0 && p < P1) out[(4 * q + oi) * 64 + 4 * (N0 + n) + oj] = acc[p - P0];
+                }
+        } else {
+            const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+            if (s == 1 && !has_b) return;
+            const int n = lane & 15;
+            double* up = a.upart + (((size_t)(2 * chunk + cg) * a.nsplits + (s ? sb : sa)) * 5) * a.lpad;
+#pragma unroll
+            for (int l = 0; l < LT; ++l)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (TAIL && l == LT - 1 && i > 0) break;
+                    double v0 = ss[l][i], v1 = sq[l][i], v2 = sx[l][i];
+                    v0 += dpp_f64<SD_DPP_XOR1>(v0); v1 += dpp_f64<SD_DPP_XOR1>(v1); v2 += dpp_f64<SD_DPP_XOR1>(v2);
+                    v0 += dpp_f64<SD_DPP_XOR2>(v0); v1 += dpp_f64<SD_DPP_XOR2>(v1); v2 += dpp_f64<SD_DPP_XOR2>(v2);
+                    v0 += dpp_f64<SD_DPP_HALF_MIRROR>(v0); v1 += dpp_f64<SD_DPP_HALF_MIRROR>(v1); v2 += dpp_f64<SD_DPP_HALF_MIRROR>(v2);
+                    const int lv = 16 * l + (lane >> 4) + 4 * i;
+                    if (n == 0) { up[0 * a.lpad + lv] = v0; up[2 * a.lpad + lv] = v1; up[4 * a.lpad + lv] = v2; }
+                    if (n == 8) { up[1 * a.lpad + lv] = v0; up[3 * a.lpad + lv] = v1; }
+                }
+        }
+    }
+}
+
+// grid as k_split_fused; 768 threads (three waves per SIMD).
+template <int NB>
+__global__ __launch_bounds__(768)
+void k_split_fused12(SplitFusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm_sf[];
+    const int npb = (a.nsplits + 1) / 2;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+    const int chunk = (w / npb) * 8 + xcd, sp = w % npb;
+    if (chunk >= a.nchunk) return;
+    const int wave = threadIdx.x >> 6;
+    switch (wave) {
+    case 0: split_fused12_wave<NB, 0>(a, sm_sf, chunk, sp); return;
+    case 1: split_fused12_wave<NB, 1>(a, sm_sf, chunk, sp); return;
+    case 2: split_fused12_wave<NB, 2>(a, sm_sf, chunk, sp); return;
+    case 3: split_fused12_wave<NB, 3>(a, sm_sf, chunk, sp); return;
+    case 4: case 5: case 6: case 7: split_fused12_wave<NB, 4>(a, sm_sf, chunk, sp); return;
+    default: break;
+    }
+    split_fused12_wave<NB, 5>(a, sm_sf, chunk, sp);
+}

@@ -149,6 +149,8 @@ int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mv
     a.J = J; a.T = ctx->T; a.Tp = Tp; a.B = ctx->B;
     a.stages_per_chunk = spc; a.nchunk = nchunk; a.nsplits = m;
     a.gpart = ptr<double>(ctx->part); a.upart = ptr<double>(ctx->part2); a.lpad = lpad;
+    // option split_reader8: 0 = 12-wave block, 1 = 8-wave block; + 2 = the other wave -> role map (A/B, tools/simd_probe.hip)
+    a.wmap = (ctx->opt[OPT_SPLIT_READER8] & 2) ? 1 : 0;
     const size_t lds = ((size_t)2 * 5 * (4 * NB * SF_PITCH + SF_TILE_PAD) + (size_t)2 * 9 * J * 16 +
                         (size_t)NB * ((LT + 1) / 2) * 128 + (size_t)4 * NB * 10) * 8;
     const int blocks = 8 * ceil_div(nchunk, 8) * npb;
@@ -157,7 +159,7 @@ int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mv
         int rc;
         // 12-wave block with dedicated construction waves (round 6); option "split_reader8": the round-5 block whose
         // matrix waves build the tiles themselves (the A/B, and the same results to the last bit: same products, same order)
-        const bool twelve = !ctx->opt[OPT_SPLIT_READER8];
+        const bool twelve = (ctx->opt[OPT_SPLIT_READER8] & 1) == 0;
         switch (NB) {
 #define SFCASE(N) case N: rc = twelve ? launch_split_fused12<N>(ctx, a, blocks, lds, st) : launch_split_fused<N>(ctx, a, blocks, lds, st); break;
             SFCASE(5) SFCASE(6) SFCASE(7) SFCASE(8) SFCASE(9) SFCASE(10) SFCASE(11) SFCASE(12) SFCASE(13)

@@ -89,11 +89,13 @@ struct SplitFusedArgs {
     double* gpart;           // Gram partials, k_gram's format: [chunk][2 nsplits][2][4096], product 1
     double* upart;           // [2 chunk + column group][nsplits][5][lpad]
     int lpad;
+    int wmap;                // which wave plays which role (see k_split_fused / k_split_fused12): 0 = kinds in runs of four
+                             // waves, 1 = kinds interleaved wave by wave
 };
 
 // ROLE 0..3: Gram wave W = ROLE; ROLE 4: projection wave (unit = wave - 4)
 template <int NB, int ROLE>
-__device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp)
+__device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp, int unit)
 {
     constexpr int ROWS = 4 * NB, P = SF_PITCH, TILE = ROWS * P + SF_TILE_PAD, LT = (NB + 3) / 4;
     constexpr bool TAIL = (NB % 4) == 1;                // the last tile of L holds <= 4 live LVs: it runs on the 4x4x4 shape
@@ -253,7 +255,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
             build_next(st);
         } else {
             build_next(st);
-            const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+            const int s = unit >> 1, cg = unit & 1;
             const int k = lane >> 4, n = lane & 15, half = n >> 3, c8 = n & 7;
             const double* ba = D + (2 * s + half) * TILE + k * P + 8 * cg + c8;
             double bfr[NB];
@@ -309,7 +311,7 @@ __device__ __forceinline__ void split_fused_wave(const SplitFusedArgs& a, double
     } else {
         // fold the 8 features of a lane group (lane bits 0..2); lane n = 0 then holds S1, S11, S12 of its LV,
         // lane n = 8 S2, S22.  The two column groups of a split are two "chunks" of the partial buffer.
-        const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+        const int s = unit >> 1, cg = unit & 1;
         if (s == 1 && !has_b) return;
         const int n = lane & 15;
         double* up = a.upart + (((size_t)(2 * chunk + cg) * a.nsplits + (s ? sb : sa)) * 5) * a.lpad;
@@ -341,14 +343,19 @@ void k_split_fused(SplitFusedArgs a)
     const int chunk = (w / npb) * 8 + xcd, sp = w % npb;
     if (chunk >= a.nchunk) return;
     const int wave = threadIdx.x >> 6;
-    switch (wave) {
-    case 0: split_fused_wave<NB, 0>(a, sm_sf, chunk, sp); return;
-    case 1: split_fused_wave<NB, 1>(a, sm_sf, chunk, sp); return;
-    case 2: split_fused_wave<NB, 2>(a, sm_sf, chunk, sp); return;
-    case 3: split_fused_wave<NB, 3>(a, sm_sf, chunk, sp); return;
+    // wmap 0: waves 0 .. 3 multiply the cross-Gram, 4 .. 7 the projections; wmap 1: even waves Gram, odd waves
+    // projections (which of the two puts one wave of either kind on every SIMD depends on how the dispatcher deals the
+    // waves of a workgroup over the four SIMDs: tools/simd_probe.hip)
+    const int role = a.wmap ? ((wave & 1) ? 4 : wave >> 1) : (wave < 4 ? wave : 4);
+    const int unit = a.wmap ? wave >> 1 : wave - 4;
+    switch (role) {
+    case 0: split_fused_wave<NB, 0>(a, sm_sf, chunk, sp, 0); return;
+    case 1: split_fused_wave<NB, 1>(a, sm_sf, chunk, sp, 0); return;
+    case 2: split_fused_wave<NB, 2>(a, sm_sf, chunk, sp, 0); return;
+    case 3: split_fused_wave<NB, 3>(a, sm_sf, chunk, sp, 0); return;
     default: break;
     }
-    split_fused_wave<NB, 4>(a, sm_sf, chunk, sp);
+    split_fused_wave<NB, 4>(a, sm_sf, chunk, sp, unit);
 }
 
 // ---- round 6: the same reader as a 12-wave block with DEDICATED construction waves ---------------------------------
@@ -361,7 +368,7 @@ void k_split_fused(SplitFusedArgs a)
 // Three waves per SIMD: 168 VGPRs per wave -- the Gram waves read their R_p operands one row block at a time (the
 // 8-wave kernel keeps up to five in registers), the builders carry two (row, column pair) items per thread.
 template <int NB, int ROLE>      // ROLE 0..3: Gram wave; 4: projection wave (unit = wave - 4); 5: construction wave
-__device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp)
+__device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, double* sm, int chunk, int sp, int unit)
 {
     constexpr int ROWS = 4 * NB, P = SF_PITCH, TILE = ROWS * P + SF_TILE_PAD, LT = (NB + 3) / 4;
     constexpr bool TAIL = (NB % 4) == 1;
@@ -402,7 +409,7 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
 
     if constexpr (ROLE == 5) {
         // ================= construction waves =================
-        const int b = tid - 512;                        // 0 .. 255
+        const int b = unit * 64 + lane;                 // 0 .. 255: construction wave `unit`
         bool on[NITEM];
         int row[NITEM], jr[NITEM];
         const int cp = b & 7;
@@ -420,17 +427,26 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
             pb[it] = a.C1 + (size_t)sb * a.strideR + roff;
             pr[it] = a.Rp + roff;
         }
-        const bool lthread = b < nseg * 8;
-        const int seg = lthread ? b >> 3 : 0;
-        const double* pc;
-        if (seg < 8 * J) {
-            const int sl = seg / (4 * J), rem = seg - sl * 4 * J, j = rem >> 2, kk = rem & 3;
-            pc = a.cc + ((size_t)(sl ? sb : sa) * J + j) * 4 * ldr + (size_t)kk * ldr + col0 + 2 * cp;
-        } else {
-            pc = a.sFt + (size_t)(seg - 8 * J) * ldr + col0 + 2 * cp;
+        // constant loader: 16-byte pieces of the 9 J segments, up to two per thread (9 x 7 x 8 = 504 pieces at most)
+        constexpr int NCI = 2;
+        static_assert(9 * SF_MAXJ * 8 <= NCI * NBLD, "constant pieces per construction thread");
+        bool lthread[NCI];
+        int seg[NCI];
+        const double* pc[NCI];
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) {
+            const int piece = b + ci * NBLD;
+            lthread[ci] = piece < nseg * 8;
+            seg[ci] = lthread[ci] ? piece >> 3 : 0;
+            if (seg[ci] < 8 * J) {
+                const int sl = seg[ci] / (4 * J), rem = seg[ci] - sl * 4 * J, j = rem >> 2, kk = rem & 3;
+                pc[ci] = a.cc + ((size_t)(sl ? sb : sa) * J + j) * 4 * ldr + (size_t)kk * ldr + col0 + 2 * cp;
+            } else {
+                pc[ci] = a.sFt + (size_t)(seg[ci] - 8 * J) * ldr + col0 + 2 * cp;
+            }
         }
-        auto write_const = [&](int buf, d2 v) {
-            if (lthread) *reinterpret_cast<d2*>(sC + (size_t)buf * nseg * 16 + seg * 16 + 2 * cp) = v;
+        auto write_const = [&](int buf, int ci, d2 v) {
+            if (lthread[ci]) *reinterpret_cast<d2*>(sC + (size_t)buf * nseg * 16 + seg[ci] * 16 + 2 * cp) = v;
         };
         auto ld2 = [&](const double* p, int st, bool ok) -> d2 {
             return (ok && st < nst) ? *reinterpret_cast<const d2*>(p + (size_t)st * SF_COLS) : zero2;
@@ -472,30 +488,36 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
             *reinterpret_cast<d2*>(d + 4 * TILE) = orp;
         };
         // prologue: stage 0 built, stage 1 in registers, constants of stages 1 (LDS) and 2 (registers)
-        write_const(0, ld2(pc, 0, lthread));
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) write_const(0, ci, ld2(pc[ci], 0, lthread[ci]));
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NITEM; ++it)
             construct(0, it, ld2(pa[it], 0, on[it]), ld2(pb[it], 0, on[it]), ld2(pr[it], 0, on[it]));
-        write_const(1, ld2(pc, 1, lthread));
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) write_const(1, ci, ld2(pc[ci], 1, lthread[ci]));
         d2 ra_[NITEM], rb_[NITEM], rr_[NITEM];
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             ra_[it] = ld2(pa[it], 1, on[it]); rb_[it] = ld2(pb[it], 1, on[it]); rr_[it] = ld2(pr[it], 1, on[it]);
         }
-        d2 cv = ld2(pc, 2, lthread);
+        d2 cv[NCI];
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci) cv[ci] = ld2(pc[ci], 2, lthread[ci]);
         __syncthreads();
         for (int st = 0; st < nst; ++st) {
             if (st + 1 < nst) {
 #pragma unroll
                 for (int it = 0; it < NITEM; ++it) construct(st + 1, it, ra_[it], rb_[it], rr_[it]);
             }
-            write_const(st & 1, cv);
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci) write_const(st & 1, ci, cv[ci]);
 #pragma unroll
             for (int it = 0; it < NITEM; ++it) {
                 ra_[it] = ld2(pa[it], st + 2, on[it]); rb_[it] = ld2(pb[it], st + 2, on[it]); rr_[it] = ld2(pr[it], st + 2, on[it]);
             }
-            cv = ld2(pc, st + 3, lthread);
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci) cv[ci] = ld2(pc[ci], st + 3, lthread[ci]);
             // the LDS stores above must have landed; the global loads just issued must NOT be waited for
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
@@ -539,7 +561,7 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
                     }
                 }
             } else {
-                const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+                const int s = unit >> 1, cg = unit & 1;
                 const int k = lane >> 4, n = lane & 15, half = n >> 3, c8 = n & 7;
                 const double* ba = D + (2 * s + half) * TILE + k * P + 8 * cg + c8;
                 d4 e[LF > 0 ? LF : 1];
@@ -608,7 +630,7 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
                     if (p >= P0 && p < P1) out[(4 * q + oi) * 64 + 4 * (N0 + n) + oj] = acc[p - P0];
                 }
         } else {
-            const int unit = wave - 4, s = unit >> 1, cg = unit & 1;
+            const int s = unit >> 1, cg = unit & 1;
             if (s == 1 && !has_b) return;
             const int n = lane & 15;
             double* up = a.upart + (((size_t)(2 * chunk + cg) * a.nsplits + (s ? sb : sa)) * 5) * a.lpad;
@@ -640,13 +662,18 @@ void k_split_fused12(SplitFusedArgs a)
     const int chunk = (w / npb) * 8 + xcd, sp = w % npb;
     if (chunk >= a.nchunk) return;
     const int wave = threadIdx.x >> 6;
-    switch (wave) {
-    case 0: split_fused12_wave<NB, 0>(a, sm_sf, chunk, sp); return;
-    case 1: split_fused12_wave<NB, 1>(a, sm_sf, chunk, sp); return;
-    case 2: split_fused12_wave<NB, 2>(a, sm_sf, chunk, sp); return;
-    case 3: split_fused12_wave<NB, 3>(a, sm_sf, chunk, sp); return;
-    case 4: case 5: case 6: case 7: split_fused12_wave<NB, 4>(a, sm_sf, chunk, sp); return;
+    // wmap 0: waves 0 .. 3 Gram, 4 .. 7 projections, 8 .. 11 construction; wmap 1: wave 3 s is Gram wave s, 3 s + 1
+    // projection wave s, 3 s + 2 construction wave s (see k_split_fused and tools/simd_probe.hip)
+    int role, unit;
+    if (a.wmap == 0) { role = wave < 4 ? wave : (wave < 8 ? 4 : 5); unit = wave & 3; }
+    else { const int kind = wave % 3; unit = wave / 3; role = kind == 0 ? unit : (kind == 1 ? 4 : 5); }
+    switch (role) {
+    case 0: split_fused12_wave<NB, 0>(a, sm_sf, chunk, sp, 0); return;
+    case 1: split_fused12_wave<NB, 1>(a, sm_sf, chunk, sp, 0); return;
+    case 2: split_fused12_wave<NB, 2>(a, sm_sf, chunk, sp, 0); return;
+    case 3: split_fused12_wave<NB, 3>(a, sm_sf, chunk, sp, 0); return;
+    case 4: split_fused12_wave<NB, 4>(a, sm_sf, chunk, sp, unit); return;
     default: break;
     }
-    split_fused12_wave<NB, 5>(a, sm_sf, chunk, sp);
+    split_fused12_wave<NB, 5>(a, sm_sf, chunk, sp, unit);
 }

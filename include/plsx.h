@@ -360,8 +360,9 @@ int plsx_set_perm_path(plsx_ctx* ctx, int dual);
  *   any time: "no_refine" (graded spectra: skip the refinement on R), "two_pass_boot", "no_compact_boot",
  *     "compact_boot_always", "sepmom_always", "no_split_fuse" (split halves: two passes), "split_two_readers"
  *     (fused split blocks read by the Gram and the projection kernel instead of the one-pass reader),
- *     "split_reader8" (the one-pass reader as the round-5 8-wave block whose matrix waves build the tiles
- *     themselves, instead of the 12-wave block with dedicated construction waves),
+ *     "split_reader8" (bit 0: the one-pass reader as the round-5 8-wave block whose matrix waves build the tiles
+ *     themselves, instead of the 12-wave block with dedicated construction waves; bit 1: wave kinds in runs of
+ *     four waves instead of interleaved wave by wave),
  *     "split_inblock", "no_gram4", "urot_generic", "urot_no_tail4", "simpls_jacobi" (SIMPLS: full Jacobi instead
  *     of the leading-eigenpair solver), "quad_sums" (plsx_boot_begin: 1 = the quadratic-form route whenever it
  *     applies, -1 = never), "percentile_sort" (plsx_percentile_ci: always the full sort instead of the tail

@@ -149,8 +149,10 @@ int run_split_reader(plsx_ctx* ctx, int m, const double* Rfull, const double* Mv
     a.J = J; a.T = ctx->T; a.Tp = Tp; a.B = ctx->B;
     a.stages_per_chunk = spc; a.nchunk = nchunk; a.nsplits = m;
     a.gpart = ptr<double>(ctx->part); a.upart = ptr<double>(ctx->part2); a.lpad = lpad;
-    // option split_reader8: 0 = 12-wave block, 1 = 8-wave block; + 2 = the other wave -> role map (A/B, tools/simd_probe.hip)
-    a.wmap = (ctx->opt[OPT_SPLIT_READER8] & 2) ? 1 : 0;
+    // option split_reader8: 0 = 12-wave block, 1 = 8-wave block; + 2 = the kinds in runs of four waves instead of
+    // interleaved wave by wave (A/B; measured on two boxes, ms per 800 splits: 12-wave interleaved 66.1 / 67.9, 12-wave runs
+    // 68.2 / 69.3, 8-wave interleaved 69.2 / 70.2, 8-wave runs -- the round-5 kernel -- 69.7 / 71.2)
+    a.wmap = (ctx->opt[OPT_SPLIT_READER8] & 2) ? 0 : 1;
     const size_t lds = ((size_t)2 * 5 * (4 * NB * SF_PITCH + SF_TILE_PAD) + (size_t)2 * 9 * J * 16 +
                         (size_t)NB * ((LT + 1) / 2) * 128 + (size_t)4 * NB * 10) * 8;
     const int blocks = 8 * ceil_div(nchunk, 8) * npb;

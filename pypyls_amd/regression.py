@@ -53,7 +53,10 @@ def _row_ok(A):
     nan = np.isnan(A)
     allnan, anynan = nan.all(axis=1), nan.any(axis=1)
     if np.any(anynan & ~allnan):
-        raise NotImplementedError('rows with some (not all) NaN entries are not supported')
+        raise NotImplementedError(
+            'rows with some (not all) NaN entries are not supported: the reference masks only rows that are NaN '
+            'throughout (get_mask, pyls/types/regression.py:48-53) and lets a partly-NaN row poison the whole fit '
+            '(NaN weights, :313, :324-325); impute or drop such rows before the call')
     return ~allnan
 
 
@@ -62,7 +65,12 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
                    n_proc=None, **kwargs):
     """PLS regression of Y (S, T) or (S, T, C) on X (S, B) with SIMPLS; see
     pyls.pls_regression.  ``n_proc``: GPUs of this node to shard the resamples over (one process, team.py);
-    ``device_ids=[...]`` names them."""
+    ``device_ids=[...]`` names them.
+
+    Missing data: rows of X or Y that are NaN THROUGHOUT are masked like the reference's ``get_mask`` masks them
+    (pyls/types/regression.py:48-53).  A row that is only PARTLY NaN raises NotImplementedError here; in the
+    reference it is not masked and turns the weights of the whole fit into NaN (regression.py:313, 324-325) --
+    a behavioural difference of this drop-in, on purpose: impute or drop such rows first."""
     from .engine import Engine
     X, Y = np.asarray(X), np.asarray(Y)
     if X.ndim != 2:

@@ -665,7 +665,7 @@ class SplitHalf(object):
         per_kernel = {}
         for key, label, w in (('k_xprod', 'k_xprod_compact<4,3,8,true> (raw first-half sums, one split per block)'
                                if one_pass else 'k_xprod_compact<4,3,5,true> (both z-scored halves)', 0.5 * 2.0 * S * Tp * B),
-                              ('k_ucorr_partial', 'k_split_fused<13> (one reader pass per pair of splits)' if one_pass
+                              ('k_ucorr_partial', 'k_split_fused12<13> (one reader pass per pair of splits; 12-wave block with dedicated construction waves)' if one_pass
                                else 'k_ucorr_partial (projections; the cross-Gram is timed under k_gram)', 8.0 * Tp * L * B)):
             if key in kt and kt[key][0] > 0:
                 ms, n = kt[key]

@@ -451,19 +451,25 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
         auto ld2 = [&](const double* p, int st, bool ok) -> d2 {
             return (ok && st < nst) ? *reinterpret_cast<const d2*>(p + (size_t)st * SF_COLS) : zero2;
         };
-        auto construct = [&](int st, int it, d2 ca, d2 cb, d2 rp) {
+        // The 9 column-constant pieces of a stage are read from the LDS ring ONCE per thread and serve both of its items
+        // when their rows lie in one cell (always with one cell).  (The construction runs beside the matrix waves: every LDS instruction and fp64
+        // operation it does not issue is one they do not wait behind -- knock-out timings,
+        // profiles/r06_split_reader_experiments.txt.  Row constants in registers as well: 36 VGPRs that spill at 168.)
+        const bool same1 = NITEM < 2 || jr[NITEM - 1] == jr[0];
+        auto read_consts = [&](int st, int j, d2* kc) {
+            const double* cs = sC + (size_t)(st & 1) * nseg * 16 + 2 * cp;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                kc[q] = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + q) * 16);
+                kc[4 + q] = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + q) * 16);
+            }
+            kc[8] = *reinterpret_cast<const d2*>(cs + (8 * J + j) * 16);
+        };
+        auto construct = [&](int st, int it, d2 ca, d2 cb, d2 rp, const d2* kc, auto full) {
             if (!on[it]) return;
-            const int buf = st & 1, r = row[it], j = jr[it];
-            const double* cs = sC + (size_t)buf * nseg * 16 + 2 * cp;
-            const d2 u1a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 0) * 16);
-            const d2 v1a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 1) * 16);
-            const d2 u2a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 2) * 16);
-            const d2 v2a = *reinterpret_cast<const d2*>(cs + ((0 * J + j) * 4 + 3) * 16);
-            const d2 u1b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 0) * 16);
-            const d2 v1b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 1) * 16);
-            const d2 u2b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 2) * 16);
-            const d2 v2b = *reinterpret_cast<const d2*>(cs + ((1 * J + j) * 4 + 3) * 16);
-            const d2 sf = *reinterpret_cast<const d2*>(cs + (8 * J + j) * 16);
+            const int buf = st & 1, r = row[it];
+            const d2 u1a = kc[0], v1a = kc[1], u2a = kc[2], v2a = kc[3];
+            const d2 u1b = kc[4], v1b = kc[5], u2b = kc[6], v2b = kc[7], sf = kc[8];
             const d2 r01 = *reinterpret_cast<const d2*>(sR + r * 10), r23 = *reinterpret_cast<const d2*>(sR + r * 10 + 2);
             const d2 r45 = *reinterpret_cast<const d2*>(sR + r * 10 + 4), r67 = *reinterpret_cast<const d2*>(sR + r * 10 + 6);
             const double sy1a = r01[0], al1a = r01[1], sy2a = r23[0], al2a = r23[1];
@@ -472,7 +478,7 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
             d2 o1a, o2a, o1b, o2b, orp;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const bool lv = gc + e < a.B;                    // features only: score / padding columns stay out
+                const bool lv = decltype(full)::value || gc + e < a.B;    // features only: score / padding columns stay out
                 const double cf = rp[e] * (rc4 * sf[e]);          // C_full
                 o1a[e] = lv ? (ca[e] - sy1a * u1a[e]) * (al1a * v1a[e]) : 0.0;
                 o2a[e] = lv ? ((cf - ca[e]) - sy2a * u2a[e]) * (al2a * v2a[e]) : 0.0;
@@ -487,16 +493,30 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
             *reinterpret_cast<d2*>(d + 3 * TILE) = o2b;
             *reinterpret_cast<d2*>(d + 4 * TILE) = orp;
         };
+        auto build = [&](int st, const d2* ra, const d2* rb, const d2* rr) {
+            d2 kc[9];
+            read_consts(st, jr[0], kc);
+            auto go = [&](auto f) {
+                construct(st, 0, ra[0], rb[0], rr[0], kc, f);
+                if constexpr (NITEM > 1) {
+                    if (!same1) read_consts(st, jr[NITEM - 1], kc);       // (another cell: its own pieces)
+                    construct(st, NITEM - 1, ra[NITEM - 1], rb[NITEM - 1], rr[NITEM - 1], kc, f);
+                }
+            };
+            go(std::false_type());   // (a second, test-free instantiation for stages inside the B features spills at 168 VGPRs)
+        };
         // prologue: stage 0 built, stage 1 in registers, constants of stages 1 (LDS) and 2 (registers)
 #pragma unroll
         for (int ci = 0; ci < NCI; ++ci) write_const(0, ci, ld2(pc[ci], 0, lthread[ci]));
         __syncthreads();
+        d2 ra_[NITEM], rb_[NITEM], rr_[NITEM];
 #pragma unroll
-        for (int it = 0; it < NITEM; ++it)
-            construct(0, it, ld2(pa[it], 0, on[it]), ld2(pb[it], 0, on[it]), ld2(pr[it], 0, on[it]));
+        for (int it = 0; it < NITEM; ++it) {
+            ra_[it] = ld2(pa[it], 0, on[it]); rb_[it] = ld2(pb[it], 0, on[it]); rr_[it] = ld2(pr[it], 0, on[it]);
+        }
+        build(0, ra_, rb_, rr_);
 #pragma unroll
         for (int ci = 0; ci < NCI; ++ci) write_const(1, ci, ld2(pc[ci], 1, lthread[ci]));
-        d2 ra_[NITEM], rb_[NITEM], rr_[NITEM];
 #pragma unroll
         for (int it = 0; it < NITEM; ++it) {
             ra_[it] = ld2(pa[it], 1, on[it]); rb_[it] = ld2(pb[it], 1, on[it]); rr_[it] = ld2(pr[it], 1, on[it]);
@@ -506,10 +526,7 @@ __device__ __forceinline__ void split_fused12_wave(const SplitFusedArgs& a, doub
         for (int ci = 0; ci < NCI; ++ci) cv[ci] = ld2(pc[ci], 2, lthread[ci]);
         __syncthreads();
         for (int st = 0; st < nst; ++st) {
-            if (st + 1 < nst) {
-#pragma unroll
-                for (int it = 0; it < NITEM; ++it) construct(st + 1, it, ra_[it], rb_[it], rr_[it]);
-            }
+            if (st + 1 < nst) build(st + 1, ra_, rb_, rr_);
 #pragma unroll
             for (int ci = 0; ci < NCI; ++ci) write_const(st & 1, ci, cv[ci]);
 #pragma unroll

@@ -1236,7 +1236,12 @@ def main():
     world = dist.get_world_size() if dist.is_initialized() else 1
     if dist.is_initialized():
         from pypyls_amd import parallel
-        parallel.open_native_comm()                        # EXPLICIT collective open of the communicator behind plsx_allgather (every rank)
+        # EXPLICIT collective open of the communicator behind plsx_allgather (every rank).  With more than one rank only on
+        # request (PLSX_BENCH_NATIVE_COLLECTIVE=1): that open -- a second RCCL communicator next to the process group's
+        # -- has never run with N > 1 on hardware, and the first multi-GPU lease should yield a scaling curve rather than
+        # test it; the process group's own all_gather_into_tensor is RCCL all the same.  `config.collective` says which ran.
+        if world == 1 or os.environ.get('PLSX_BENCH_NATIVE_COLLECTIVE') == '1':
+            parallel.open_native_comm()
         collective = parallel.collective_name()           # a pure query: which all-gather the steps will issue
     env = {'world': world, 'rank': rank, 'dev': dev, 'backend': backend, 'collective': collective}
 

@@ -1189,6 +1189,9 @@ def main():
     ap.add_argument('--split-arrangements', type=int, default=64,
                     help='--gpus N > 1, default run: arrangements (x n_split = 100) of the ONE sharded split-half leg '
                          'embedded under "sharded"')
+    ap.add_argument('--sharded-timeout', type=float, default=600.0,
+                    help='--gpus N > 1, default run: seconds the sharded sub-records may take before the headline line is '
+                         'printed without them')
     ap.add_argument('--n-split', type=int, default=0, help='--config c4split: splits per arrangement (default 100)')
     ap.add_argument('--emulate-world', default='',
                     help='strong mode, one GPU: comma-separated world sizes N; times the critical path of one '
@@ -1259,7 +1262,19 @@ def main():
         elif world > 1 and args.config == 'c4' and args.mode == 'weak' and not args.no_configs:
             del wl                                          # (its engine and scratch go with it)
             torch.cuda.empty_cache()
+            # The sub-records are collective calls that have never run on several real GPUs: if they hang (a rank that
+            # raised while its peers wait in a collective), the weak headline measured above must still reach the driver.
+            # A watchdog on every rank prints it (rank 0) and leaves the process after `--sharded-timeout` seconds.
+            def bail():
+                if rank == 0 and out is not None:
+                    out['sharded'] = {'error': 'sub-records did not finish within {} s; headline only'.format(args.sharded_timeout)}
+                    os.write(real_stdout, (json.dumps(out) + '\n').encode())
+                os._exit(0)
+            dog = threading.Timer(args.sharded_timeout, bail)
+            dog.daemon = True
+            dog.start()
             sharded = sharded_records(args, env)            # collective: every rank
+            dog.cancel()
             if rank == 0 and out is not None:
                 out['sharded'] = sharded
     if rank == 0 and out is not None:

@@ -874,6 +874,49 @@ def default_engine(device=None, replica=0):
     return eng
 
 
+# The cached engines keep the resident X and the super-batch scratch (up to tens of GB) mapped so that the NEXT call
+# does not pay for mapping them again (25 ms per GB of recycled VRAM).  A process that has stopped calling should not
+# sit on that memory for ever (a surprise-OOM for other work sharing the GPU): IDLE_RELEASE_S
+# seconds after the last front-end call finished, the cached engines (and teams) nobody is using are released -- the
+# next call simply builds new ones.  0 / None disables; release_default_engine() does it at once.
+IDLE_RELEASE_S = 300.0
+_IDLE = {'timer': None}
+
+
+def touch_idle_release():
+    """(Re)start the idle clock; the front-ends call this when a call ends."""
+    if not IDLE_RELEASE_S:
+        return
+    with _DEFAULT_LOCK:
+        old = _IDLE['timer']
+        if old is not None:
+            old.cancel()
+        t = threading.Timer(float(IDLE_RELEASE_S), _idle_fire)
+        t.daemon = True
+        _IDLE['timer'] = t
+        t.start()
+
+
+def _idle_fire():
+    try:
+        with _DEFAULT_LOCK:
+            engines = list(_DEFAULT.values())
+        held = []
+        for eng in engines:
+            if eng.lock.acquire(blocking=False):
+                held.append(eng)
+        try:
+            if len(held) == len(engines):               # nobody is in a call: give the memory back
+                release_default_engine()
+            else:
+                touch_idle_release()                    # a call is running: look again later
+        finally:
+            for eng in held:
+                eng.lock.release()
+    except Exception:                                   # noqa: BLE001 -- a timer thread must never raise (interpreter exit)
+        pass
+
+
 def release_default_engine(device=None):
     """Destroy the cached default engine(s) and free their device memory."""
     from . import team as _team

@@ -229,6 +229,8 @@ class _PLSCRun(object):
             return res
         finally:
             draws.thread.join()                        # never leave the generators running on an error
+            from .engine import touch_idle_release
+            touch_idle_release()                       # (the cached engines are released after IDLE_RELEASE_S idle seconds)
             for ms in self._mstreams:
                 ms.close()
 

@@ -209,6 +209,8 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
         return res
     finally:
         draws.thread.join()
+        from .engine import touch_idle_release
+        touch_idle_release()                       # (the cached engines are released after IDLE_RELEASE_S idle seconds)
 
 
 def _run_device(X, Y, Y_agg, agg, third, inputs, pstream, bstream, draws, permsamples, bootsamples,

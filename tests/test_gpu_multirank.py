@@ -41,13 +41,23 @@ dist.destroy_process_group()
 '''
 
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
 def test_two_ranks_equal_one_rank(tmp_path):
     out = str(tmp_path / 'two.npz')
     script = tmp_path / 'w.py'
     script.write_text(_WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29541', str(script)]
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
     two = np.load(out)
@@ -195,7 +205,7 @@ def _run_nccl(tmp_path, world, port):
 def test_collective_on_rccl_one_rank(tmp_path):
     """The single all-gather of the front-ends on the RCCL backend (GPU-side pack /
     unpack, parallel.gather_device) with a 1-rank group -- what a 1-GPU box can run."""
-    _run_nccl(tmp_path, 1, 29551)
+    _run_nccl(tmp_path, 1, _free_port())
 
 
 def test_collective_on_rccl_two_ranks(tmp_path):
@@ -203,7 +213,7 @@ def test_collective_on_rccl_two_ranks(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
-    _run_nccl(tmp_path, 2, 29552)
+    _run_nccl(tmp_path, 2, _free_port())
 
 
 def test_bench_launches_its_own_ranks(tmp_path):

@@ -12,6 +12,15 @@ from conftest import ROOT
 from oracle import cpu_ref as ref
 
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
 def test_library_exports_every_declared_symbol():
     from pypyls_amd import _build, engine
     _build.build()
@@ -166,10 +175,11 @@ print('rank', rank, 'ok')
 def test_collect_multiprocess_gloo(tmp_path, world):
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29512 + world))
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
            '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
-           '--master-port', str(29512 + world), str(script)]
+           '--master-port', str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count('ok') == world
@@ -229,7 +239,7 @@ def test_shared_seed_multiprocess_gloo(tmp_path):
     script = tmp_path / 'seed_worker.py'
     script.write_text(_SEED_WORKER.format(root=ROOT))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29533', str(script)]
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
     out = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'), capture_output=True,
                          text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr

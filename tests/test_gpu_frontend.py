@@ -438,3 +438,31 @@ def test_verbose_prints_the_references_progress_bars(monkeypatch, capfd):
     rr = pls.pls_regression(X, Y, n_components=2, n_perm=300, n_boot=300, seed=5, verbose=True)
     err = capfd.readouterr().err
     assert 'Running permutations' in err and 'Running bootstraps' in err and rr.varexp.shape == (2,)
+
+
+def test_cached_engine_is_released_after_an_idle_period(monkeypatch):
+    """the cached default engine keeps X and the scratch mapped between calls (re-mapping costs
+    25 ms per GB) -- but not for ever: engine.IDLE_RELEASE_S seconds after the last call ended it is released, and
+    the next call builds a new one with the same results."""
+    import time
+    import pypyls_amd as pls
+    from pypyls_amd import engine
+    rs = np.random.RandomState(4)
+    X, Y = rs.randn(30, 500), rs.randn(30, 3)
+    kw = dict(n_perm=6, n_boot=6, test_split=0, seed=9, verbose=False)
+    monkeypatch.setattr(engine, 'IDLE_RELEASE_S', 0.4)
+    a = pls.behavioral_pls(X, Y, **kw)
+    eng = engine.default_engine()
+    assert eng.ctx
+    engine.touch_idle_release()
+    for _ in range(50):
+        if not eng.ctx:
+            break
+        time.sleep(0.1)
+    assert not eng.ctx and not engine._DEFAULT
+    b = pls.behavioral_pls(X, Y, **kw)
+    assert engine.default_engine() is not eng
+    assert np.array_equal(a.permres.perm_singval, b.permres.perm_singval)
+    assert np.array_equal(a.bootres.x_weights_normed, b.bootres.x_weights_normed)
+    monkeypatch.setattr(engine, 'IDLE_RELEASE_S', 0)       # (no timer left behind for the tests that follow)
+    engine.touch_idle_release()

@@ -190,8 +190,9 @@ class _PLSCRun(object):
         Y = None if self.method == 'meancentered' else _as_float_array(inp.Y, 'Y')
         Tp = self.n_cells * Y.shape[1] if Y is not None else self.n_cells
         self.perm_given = self.boot_given = None
-        from .engine import default_engine
+        from .engine import default_engine, touch_idle_release
         from . import team as _team
+        touch_idle_release()                           # (a pending idle release is pushed back before the engine is looked up)
         devices = None
         if self.engine is None and self.emulate is None and parallel._dist() is None:
             # n_proc workers of the reference (pyls/utils.py:252-279) = GPUs of this node, driven from this process

@@ -173,8 +173,9 @@ def pls_regression(X, Y, *, n_components=None, n_perm=5000, n_boot=5000, rotate=
             if bs.ndim != 2 or bs.shape[0] != S:
                 raise ValueError('resampling array must have shape (S, n) with S = {}; got {}'.format(S, bs.shape))
             bstream = resampling.IndexStream.of_array(check_index_array(bs, S))
-    from .engine import default_engine
+    from .engine import default_engine, touch_idle_release
     from . import team as _team
+    touch_idle_release()                               # (a pending idle release is pushed back before the engine is looked up)
     eng = kwargs.get('_engine')
     team = None
     if eng is None and kwargs.get('_emulate') is None and parallel._dist() is None:

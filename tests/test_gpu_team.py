@@ -206,3 +206,31 @@ def test_team_on_two_gpus():
     peer = pls.behavioral_pls(X, Y, device_ids=[0, 1], _transport='peer', **kw)
     _same_analysis(one, peer)
     assert np.array_equal(two.bootres.x_weights_normed, peer.bootres.x_weights_normed)
+
+
+def test_team_with_prepermuted_y_and_3d_regression():
+    """The less travelled inputs through the team path: pre-permuted Y stacks (``permindices=False``,
+    pyls/base.py:636-639) with split-half, and pls_regression with a 3-D Y (subjects AND the third axis resampled,
+    pyls/types/regression.py:208-235) and NaN rows -- each rank works on its slice of the stack / of the bootstraps."""
+    import pypyls_amd as pls
+    X, Y = _data(S=36, B=260, T=4, seed=2)
+    rs = np.random.RandomState(3)
+    ystack = np.stack([Y[rs.permutation(len(Y))] for _ in range(9)])
+    kw = dict(n_perm=9, n_boot=8, n_split=2, test_split=0, permsamples=ystack, permindices=False, seed=4, verbose=False)
+    one = pls.behavioral_pls(X, Y, **kw)
+    two = pls.behavioral_pls(X, Y, device_ids=[0, 0], **kw)
+    assert np.array_equal(one.permres.perm_singval, two.permres.perm_singval)
+    assert np.array_equal(one.permres.pvals, two.permres.pvals)
+    for key in ('ucorr', 'vcorr', 'ucorr_pvals', 'vcorr_pvals'):
+        assert np.array_equal(one.splitres[key], two.splitres[key]), key
+    np.testing.assert_allclose(one.bootres.x_weights_normed, two.bootres.x_weights_normed, rtol=1e-9, atol=1e-12)
+    Y3 = np.stack([Y + 0.1 * rs.randn(*Y.shape) for _ in range(5)], axis=-1)
+    Xn = X.copy()
+    Xn[5] = np.nan                                           # an all-NaN row of X is masked (get_mask)
+    rk = dict(n_components=3, n_perm=7, n_boot=9, seed=6, verbose=False)
+    ra = pls.pls_regression(Xn, Y3, **rk)
+    rb = pls.pls_regression(Xn, Y3, device_ids=[0, 0, 0], **rk)
+    assert np.array_equal(ra.permres.perm_singval, rb.permres.perm_singval)
+    assert np.array_equal(ra.bootres.y_loadings_boot, rb.bootres.y_loadings_boot)
+    np.testing.assert_allclose(ra.bootres.x_weights_normed, rb.bootres.x_weights_normed, rtol=1e-9, atol=1e-12)
+    assert np.isnan(ra.x_scores[5]).all() and np.isnan(rb.x_scores[5]).all()

@@ -38,8 +38,8 @@ int launch_cboot(plsx_ctx* ctx, int nres, int nks_c, SplitEpi se, hipStream_t st
                             : launch_xprod_cboot<2, 6>(ctx, nres, nks_c, se, st);
         case 3: return tail ? launch_xprod_cboot<3, 4, true>(ctx, nres, nks_c, se, st)
                             : launch_xprod_cboot<3, 4>(ctx, nres, nks_c, se, st);
-        case 4: return tail ? launch_xprod_cboot<4, 3, true>(ctx, nres, nks_c, se, st)
-                            : launch_xprod_cboot<4, 3>(ctx, nres, nks_c, se, st);
+        case 4: return tail ? launch_xprod_cboot<4, PLSX_CKT, true>(ctx, nres, nks_c, se, st)
+                            : launch_xprod_cboot<4, PLSX_CKT>(ctx, nres, nks_c, se, st);
         // 64 < T' <= 208: 5 .. 13 tiles, 3 or 2 waves per SIMD (the accumulators of two column tiles)
 #define PLSX_CB(M, K) case M: return tail ? launch_xprod_cboot<M, K, true>(ctx, nres, nks_c, se, st) \
                                           : launch_xprod_cboot<M, K>(ctx, nres, nks_c, se, st);
@@ -88,8 +88,8 @@ int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, 
                                 : launch_xprod_compact<2, 6, false, 8>(ctx, m, nks_c, se, st);
             case 3: return tail ? launch_xprod_compact<3, 4, true, 8>(ctx, m, nks_c, se, st)
                                 : launch_xprod_compact<3, 4, false, 8>(ctx, m, nks_c, se, st);
-            case 4: return tail ? launch_xprod_compact<4, 3, true, 8>(ctx, m, nks_c, se, st)
-                                : launch_xprod_compact<4, 3, false, 8>(ctx, m, nks_c, se, st);
+            case 4: return tail ? launch_xprod_compact<4, PLSX_CKT, true, 8>(ctx, m, nks_c, se, st)
+                                : launch_xprod_compact<4, PLSX_CKT, false, 8>(ctx, m, nks_c, se, st);
             default: return fail(ctx, PLSX_ERR_STATE, "raw compact split blocks: T' outside 17..52");
         }
     }
@@ -99,8 +99,8 @@ int launch_csplit(plsx_ctx* ctx, int m, int nks_c, SplitEpi se, hipStream_t st, 
                             : launch_xprod_compact<2, 6>(ctx, m, nks_c, se, st);
         case 3: return tail ? launch_xprod_compact<3, 4, true>(ctx, m, nks_c, se, st)
                             : launch_xprod_compact<3, 4>(ctx, m, nks_c, se, st);
-        default: return tail ? launch_xprod_compact<4, 3, true>(ctx, m, nks_c, se, st)
-                             : launch_xprod_compact<4, 3>(ctx, m, nks_c, se, st);
+        default: return tail ? launch_xprod_compact<4, PLSX_CKT, true>(ctx, m, nks_c, se, st)
+                             : launch_xprod_compact<4, PLSX_CKT>(ctx, m, nks_c, se, st);
     }
 }
 

@@ -48,6 +48,12 @@ static const char* const kOptionNames[OPT_COUNT] = {
     "two_pass_boot", "split_inblock", "no_split_fuse", "split_two_readers", "expect_resamples",
     "simpls_jacobi", "percentile_sort", "quad_sums", "split_reader8"};
 
+// k-steps per LDS stage of the 4-tile compact cross-product blocks (T' = 49 .. 64: the headline shape).  A/B lever of
+// tools/ckt_probe.sh (measured: profiles/r06_compact_kt.txt); other tile counts keep 12 / MT.
+#ifndef PLSX_CKT
+#define PLSX_CKT 3
+#endif
+
 struct plsx_ctx {
     int device = 0;
     std::string err;

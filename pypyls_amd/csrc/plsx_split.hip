@@ -21,7 +21,7 @@ int run_split_compact(plsx_ctx* ctx, const int* perm, const uint8_t* masks, int 
 {
     const bool raw = split_reader_ok(ctx);
     ctx->split_raw = raw ? 1 : 0;
-    const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = 12 / MTc, rows = MTc * 16;
+    const int J = ctx->J, S = ctx->S, MTc = ceil_div(ctx->Tp, 16), KT = MTc == 4 ? PLSX_CKT : 12 / MTc, rows = MTc * 16;
     ctx->last_compact_n = 0;                            // (the row tables are about to hold this pass's splits)
     if (!ctx->has_cellS) {
         if (int e = ensure(ctx, ctx->cellS, (size_t)2 * J * ctx->Bpad * 8, true)) return e;

@@ -277,7 +277,7 @@ bool compact_boot_ok(const plsx_ctx* ctx)
 int run_xprod_cboot(plsx_ctx* ctx, const int* xsrc, const int* ysrc, int nres, hipStream_t st,
                     const double* ystack, long long ystride)
 {
-    const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = std::max(1, 12 / MTc);      // (two column tiles per wave)
+    const int S = ctx->S, J = ctx->J, MTc = ceil_div(ctx->Tp, 16), KT = MTc == 4 ? PLSX_CKT : std::max(1, 12 / MTc);      // (two column tiles per wave)
     const int nks_c = round_up(ceil_div(S, 4), KT);
     const int npairs = nres * J;
     const MomLayout ml = moment_layout(ctx, npairs);
